@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.  Run in the build
+container only (it needs /root/reference to build oracle/_ref):
+
+    python tests/golden/make_golden.py
+
+What each fixture is, and what produced its expected values:
+
+scalar_tables.npz      seeded operand tables + outputs of the REFERENCE's own
+                       complex<float> / complex<double>
+                       (/root/reference/DeviceArray/include/cuda_complex.hpp, compiled by
+                       g++ from where it lies into oracle/_ref/liboracle_ref.so), and of the
+                       dual-complex restatement instantiated over that class.
+test_csfd_known_answers.json
+                       the values the reference's test_CSFD demo prints
+                       (Experiments/test_CSFD/main.cpp:113-219), recorded from a run of the
+                       unmodified demo in the survey container.
+survey_reference_kernel_figures.json
+                       counts recorded in SURVEY.md §6 from the reference kernel bodies run
+                       on scene S1 in the survey session.
+pipeline_s1_n64.npz / pipeline_s1_n96.npz
+                       scene S1 through the restated pipeline instantiated over the
+                       reference's complex class (oracle/_ref): sampled voxels, map pixels,
+                       ICP normal equations and poses.  Kernel control flow is the
+                       restatement's, arithmetic is the reference header's.
+hessian_s1_n64.npz     dual-complex Hessian / real loss kernels on the same scene.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc  # noqa: E402
+
+synth = importlib.import_module("x-slam_amd.synth")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def scalar_tables(ref):
+    rng = np.random.default_rng(0xC5FD)
+    n = 256
+    out = {}
+    # CSFD-regime operands: O(1) real parts, imaginary parts ~1e-7 x real
+    a = np.stack([rng.uniform(-2, 2, n), rng.uniform(-3e-7, 3e-7, n)], -1).astype(np.float32)
+    b = np.stack([rng.uniform(-2, 2, n), rng.uniform(-3e-7, 3e-7, n)], -1).astype(np.float32)
+    # general operands
+    ga = rng.uniform(-2, 2, (n, 2)).astype(np.float32)
+    gb = rng.uniform(-2, 2, (n, 2)).astype(np.float32)
+    # positive-real operands for sqrt/log on the branch the kernels use
+    pa = np.stack([rng.uniform(1e-3, 30, n), rng.uniform(-3e-6, 3e-6, n)], -1).astype(np.float32)
+    # wide dynamic range for division scaling
+    wa = (rng.uniform(-2, 2, (n, 2)) * 10.0 ** rng.integers(-12, 12, (n, 1))).astype(np.float32)
+    wb = (rng.uniform(-2, 2, (n, 2)) * 10.0 ** rng.integers(-12, 12, (n, 1))).astype(np.float32)
+    out.update(csfd_a=a, csfd_b=b, gen_a=ga, gen_b=gb, pos_a=pa, wide_a=wa, wide_b=wb)
+    for tag, x, y in (("csfd", a, b), ("gen", ga, gb), ("wide", wa, wb)):
+        for op in ("add", "sub", "mul", "div", "div_scalar", "scalar_div", "mul_scalar", "scalar_sub"):
+            out[f"c_{tag}_{op}"] = ref.cop(op, x, y)
+    for tag, x in (("csfd", a), ("gen", ga), ("pos", pa)):
+        for op in ("sqrt", "abs", "exp", "sin", "cos", "sinh", "cosh", "sin_new", "sinh_new", "norm", "arg", "conj"):
+            out[f"c_{tag}_{op}"] = ref.cop(op, x)
+    out["c_pos_log"] = ref.cop("log", pa)
+    out["c_gen_log"] = ref.cop("log", ga)
+    out["c_pos_pow"] = ref.cop("pow", pa, b)
+    out["c_gen_polar"] = ref.cop("polar", np.abs(ga), gb)
+    # complex<double> (devComplexICP)
+    da, db = ga.astype(np.float64) + 1e-9, gb.astype(np.float64) - 1e-9
+    out.update(f64_a=da, f64_b=db)
+    for op in ("add", "sub", "mul", "div", "sqrt"):
+        out[f"c64_{op}"] = ref.cop_f64(op, da, db)
+    # dual complex: value O(1), first-order seeds ~1e-6, second-order ~1e-12
+    sc = np.array([1.0, 1e-6, 1e-6, 1e-12])
+    d1 = (rng.uniform(-2, 2, (n, 4)) * sc).astype(np.float32)
+    d2 = (rng.uniform(-2, 2, (n, 4)) * sc).astype(np.float32)
+    dp = d1.copy()
+    dp[:, 0] = np.abs(dp[:, 0]) + 0.05
+    out.update(d_a=d1, d_b=d2, d_pos=dp)
+    for op in ("add", "sub", "mul", "div", "mul_scalar", "div_scalar", "add_scalar", "scalar_sub"):
+        out[f"d_{op}"] = ref.dop(op, d1, d2)
+    out["d_sqrt"] = ref.dop("sqrt", dp)
+    out["d_abs"] = ref.dop("abs", dp)
+    np.savez_compressed(os.path.join(OUT, "scalar_tables.npz"), **out)
+
+
+def known_answers():
+    ka = {
+        "source": "printed by the reference's unmodified test_CSFD demo (Experiments/test_CSFD/main.cpp:113-219), "
+                  "recorded in BASELINE.md section 2 / SURVEY.md section 6; 6 significant digits as printed",
+        "inputs": {"a": [0.5, 1e-6], "b": [-1.5, 1e-6], "h": 1e-6, "t0": 0.5, "pow_n": 3},
+        "mul_our": [-0.75, -1e-06], "mul_std": [-0.75, -1e-06],
+        "div_our": [-0.333333, -8.88889e-07], "div_std": [-0.333333, -8.88889e-07],
+        "exp_our": [0.367879, 7.35759e-07], "exp_std": [0.367879, 7.35759e-07],
+        "sin_our": [-0.841471, 1.0806e-06], "sin_std": [-0.841471, 1.0806e-06],
+        "pow_our": [-1.0, 5.6982e-06], "pow_std": [-1.0, 6e-06],
+        "dcsfd_gradient": 2.73911, "dcsfd_second": 9.26892, "chain_gradient": 2.73911, "chain_second": 9.26892,
+    }
+    json.dump(ka, open(os.path.join(OUT, "test_csfd_known_answers.json"), "w"), indent=1)
+    sv = {
+        "source": "SURVEY.md section 6 / BASELINE.md section 2: reference tsdfFusionKernal / rayCastKernel bodies run on "
+                  "scene S1 frame 0 (wall + sphere, identity pose, 7.68 m cube) in the survey session",
+        "integrate_U": {"256": 253946, "512": 1930365},
+        "raycast_hits": {"256": 294135, "512": 294338},
+        "tolerance": "U within 0.01 % (SURVEY 8d: rounding flips); hits within 2 pixels",
+    }
+    json.dump(sv, open(os.path.join(OUT, "survey_reference_kernel_figures.json"), "w"), indent=1)
+
+
+def pipeline(ref, n, frames, name):
+    rng = np.random.default_rng(0xC5FD + n)
+    prm = synth.s1_params(n)
+    kf = orc.OracleKinFu(ref, orc.params_from_dict(prm))
+    nv = n ** 3
+    vox = np.sort(rng.choice(nv, 4096, replace=False))
+    pix = np.sort(rng.choice(synth.WIDTH * synth.HEIGHT, 1024, replace=False))
+    py, px = pix // synth.WIDTH, pix % synth.WIDTH
+    out = dict(voxel_index=vox, pixel_index=pix, n=np.int32(n), frames=np.array(frames, np.int32))
+    depth_sums = []
+    for k in range(max(frames) + 1):
+        d = synth.s1_frame(k)
+        depth_sums.append(int(d.astype(np.uint64).sum()))
+        assert kf.process_frame(d) == 1
+        out[f"w2c_{k}"] = kf.world2camera()
+        if k in frames:
+            v, w, g = kf.volume()
+            out[f"value_{k}"], out[f"weight_{k}"], out[f"grad_{k}"] = v[vox], w[vox], g[vox]
+            out[f"sums_{k}"] = np.array([v.astype(np.float64).sum(), np.abs(v).astype(np.float64).sum(),
+                                         g.astype(np.float64).sum() / 1e-7, w.astype(np.float64).sum(), float(kf.last_U()),
+                                         float(kf.last_hits())])
+            vm, nm = kf.map("vmaps_g_prev", 0), kf.map("nmaps_g_prev", 0)
+            H = synth.HEIGHT
+            out[f"vmap_{k}"] = np.stack([vm[py + p * H, px] for p in range(3)])
+            out[f"nmap_{k}"] = np.stack([nm[py + p * H, px] for p in range(3)])
+            out[f"icp_{k}"] = kf.icp_log()
+    out["depth_checksums"] = np.array(depth_sums, np.uint64)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    kf.close()
+
+
+def hessian(ref, n):
+    """Hessian / loss kernels: gt = the TSDF after frame 0, probed at the pose of frame 1."""
+    prm = synth.s1_params(n)
+    o = orc.Oracle()  # the real loss kernel has no complex arithmetic; either build serves
+    kf = orc.OracleKinFu(ref, orc.params_from_dict(prm))
+    assert kf.process_frame(synth.s1_frame(0)) == 1
+    gt, _, _ = kf.volume()
+    trunc = kf.tranc_dist()
+    w2v = np.eye(4)
+    w2v[:3, 3] = [prm["init_x"], prm["init_y"], prm["init_z"]]
+    res = [n, n, n]
+    intr = [prm["fx"], prm["fy"], prm["cx"], prm["cy"]]
+    out = dict(n=np.int32(n), trunc=np.float32(trunc))
+    for tag, k in (("a", 1), ("b", 4)):
+        c2w = synth.s1_pose(k)
+        v2c = np.linalg.inv(w2v @ c2w)
+        depth = o.scale_depth(synth.s1_frame(k))
+        R = np.zeros((3, 3, 4), np.float32)
+        R[..., 0] = v2c[:3, :3]
+        t = np.zeros((3, 4), np.float32)
+        t[:, 0] = v2c[:3, 3]
+        h = 1e-6
+        t[0, 1] = h  # first-order seed on t_x
+        t[0, 2] = h  # second seed on the same entry -> d2/dtx2
+        out[f"R_{tag}"], out[f"t_{tag}"] = R, t
+        out[f"hess_{tag}"] = ref.tsdf_hessian(depth, res, prm["tsdf_voxel_size"], R, t, trunc, intr, gt)
+        out[f"loss_{tag}"] = o.tsdf_loss(depth, res, prm["tsdf_voxel_size"], v2c[:3, :3], v2c[:3, 3], trunc, intr, gt)
+    np.savez_compressed(os.path.join(OUT, f"hessian_s1_n{n}.npz"), **out)
+    kf.close()
+
+
+if __name__ == "__main__":
+    orc.build(ref=True)
+    ref = orc.Oracle(ref=True)
+    scalar_tables(ref)
+    known_answers()
+    pipeline(ref, 64, [0, 1, 4], "pipeline_s1_n64.npz")
+    pipeline(ref, 96, [0, 1, 4], "pipeline_s1_n96.npz")
+    hessian(ref, 64)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
