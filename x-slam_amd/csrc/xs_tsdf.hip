@@ -1,0 +1,225 @@
+// xs_tsdf.hip — TSDF volume kernels for gfx950: initialise, depth scaling, per-voxel complex
+// integrate.  Replaces XKinectFusion/src/TsdfFusion.cu:4-43 (initVolume), :68-82
+// (scaleDepthKernal), :85-201 (tsdfFusionKernal / integrateTsdfVolume).
+//
+// Volume layout (TsdfVolume.cpp:17-20): value f32, weight i32, grad f32, each a pitched 2-D
+// array with rows = Y*Z and cols = X; voxel (x,y,z) at row (y + z*Y), column x.  A z-slab
+// [z0, z1) owned by one GPU is the row range [z0*Y, z1*Y); the pointers passed here are the
+// base of the slab's own storage and z runs over global indices.
+//
+// Integrate design (CDNA4).  A wave is 64 consecutive x of one (y, z-chunk): every load and
+// store of value/weight/grad is a 256 B coalesced row segment.  A thread walks z.  The part
+// of Rv2c*v_g that does not depend on z is formed once per thread in the reference's own
+// operation order (x term + y term), so each z step adds one product and the translation —
+// the same additions the reference performs, hence the same bits.  A voxel whose projection
+// falls outside the image by more than one pixel is rejected on the un-divided coordinates
+// (u*fx vs c*(bound)), before the two IEEE divides; anything within a pixel of the border
+// takes the exact path.  Only voxels that pass the reference's predicate touch memory.
+#include "xs_device.h"
+#include "../../include/xslam_amd.h"
+
+using namespace xs;
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_init_volume(float *value, int *weight, float *grad, size_t step, int X, long long rows) {
+    // one thread per 4 consecutive x of one row; rows = Y * (z1 - z0)
+    int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    long long row = blockIdx.y;
+    for (; row < rows; row += gridDim.y) {
+        if (x4 + 3 < X && (step % 16) == 0) {
+            float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(row_ptr(value, step, 0) + (size_t)row * (step / 4) + x4) = z4;
+            *reinterpret_cast<int4 *>(row_ptr(weight, step, 0) + (size_t)row * (step / 4) + x4) = make_int4(0, 0, 0, 0);
+            *reinterpret_cast<float4 *>(row_ptr(grad, step, 0) + (size_t)row * (step / 4) + x4) = z4;
+        } else {
+            for (int x = x4; x < X && x < x4 + 4; ++x) {
+                ((float *)((char *)value + (size_t)row * step))[x] = 0.f;
+                ((int *)((char *)weight + (size_t)row * step))[x] = 0;
+                ((float *)((char *)grad + (size_t)row * step))[x] = 0.f;
+            }
+        }
+    }
+}
+
+extern "C" int xs_init_volume(float *value, int *weight, float *grad, size_t step_bytes, const int *res, int z0, int z1, void *stream) {
+    if (!value || !weight || !grad || !res || z1 < z0) return xs_set_error(hipErrorInvalidValue, "xs_init_volume: bad argument");
+    long long rows = (long long)res[1] * (z1 - z0);
+    if (rows == 0 || res[0] == 0) return 0;
+    dim3 block(64, 1);
+    dim3 grid(div_up(div_up(res[0], 4), 64), (unsigned)(rows < 65535 ? rows : 65535));
+    hipLaunchKernelGGL(k_init_volume, grid, block, 0, (hipStream_t)stream, value, weight, grad, step_bytes, res[0], rows);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scale_depth(const uint16_t *depth, size_t dstep, int rows, int cols, float *scaled, size_t sstep) {
+    int x = threadIdx.x + blockIdx.x * blockDim.x;
+    int y = threadIdx.y + blockIdx.y * blockDim.y;
+    if (x >= cols || y >= rows) return;
+    int Dp = row_ptr(depth, dstep, y)[x];
+    float r = 0.f;
+    if (!(Dp > 5000 || Dp < 200)) r = float(Dp) / 1000.f;  // metres
+    row_ptr(scaled, sstep, y)[x] = r;
+}
+
+extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step, void *stream) {
+    if (!depth || !scaled) return xs_set_error(hipErrorInvalidValue, "xs_scale_depth: null pointer");
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
+    hipLaunchKernelGGL(k_scale_depth, grid, block, 0, (hipStream_t)stream, depth, depth_step, rows, cols, scaled, scaled_step);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+struct IntegrateArgs {
+    const float *depth; size_t dstep; int drows, dcols;
+    float *value; int *weight; float *grad; size_t vstep;
+    int X, Y, Z;        // full resolution
+    int z0, z1;         // slab owned by this launch; storage starts at z0
+    int zchunk;         // z range per blockIdx.z
+    float tranc_dist, tranc_dist_inv; int max_weight;
+    MatS33 R; cfloat3 t;
+    Intr intr; float voxel_size, threshold;
+    unsigned long long *updated;  // optional device counter
+};
+
+template <bool BILINEAR>
+__global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
+    const int x = threadIdx.x + blockIdx.x * 64;
+    const int y = threadIdx.y + blockIdx.y * 4;
+    unsigned n_upd = 0;
+    if (x < a.X && y < a.Y) {
+        const float vgx = (x + 0.5f) * a.voxel_size;
+        const float vgy = (y + 0.5f) * a.voxel_size;
+        // z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy); v_g has zero
+        // imaginary part, so each complex product is (re*vg, im*vg)
+        cfloat base[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
+        const float fx = a.intr.fx, fy = a.intr.fy, cx = a.intr.cx, cy = a.intr.cy;
+        // conservative image window in un-divided form (one pixel of slack on each side)
+        const float ulo = 1.5f - cx, uhi = (a.dcols - 0.5f) - cx + 1.0f;
+        const float vlo = 1.5f - cy, vhi = (a.drows - 0.5f) - cy + 1.0f;
+        int zb = a.z0 + blockIdx.z * a.zchunk;
+        int ze = min(zb + a.zchunk, a.z1);
+        size_t row = (size_t)(zb - a.z0) * a.Y + y;
+        float *pos = row_ptr(a.value, a.vstep, 0) + row * (a.vstep / 4) + x;
+        int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
+        float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
+        const size_t zstride = (size_t)a.Y * (a.vstep / 4);
+        for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
+            const float vgz = (z + 0.5f) * a.voxel_size;
+            cfloat3 v_c;
+            v_c.x = (base[0] + a.R.data[0].z * vgz) + a.t.x;
+            v_c.y = (base[1] + a.R.data[1].z * vgz) + a.t.y;
+            v_c.z = (base[2] + a.R.data[2].z * vgz) + a.t.z;
+            const float c = v_c.z.re;
+            if (c < 0) continue;  // Re(1/v_c.z) < 0
+            const cfloat px = v_c.x * fx, py = v_c.y * fy;
+            // early reject: |true image coordinate - (px/c + cx)| << 1 pixel
+            if (c > 0) {
+                if (px.re < ulo * c || px.re > uhi * c) continue;
+                if (py.re < vlo * c || py.re > vhi * c) continue;
+            }
+            const cfloat inv_z = 1.0f / v_c.z;
+            const cfloat image_x = px * inv_z + cx;
+            const cfloat image_y = py * inv_z + cy;
+            const int coo_x = __float2int_rd(image_x.re - 0.5f);
+            const int coo_y = __float2int_rd(image_y.re - 0.5f);
+            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
+            const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
+            cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
+            if (BILINEAR) {
+                const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
+                const float d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
+                const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x];
+                const float d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+                const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
+                const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
+                if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+                    const cfloat one(1.0f, 0.0f);
+                    const cfloat fa = image_x - cfloat(coo_x + 0.5f, 0.0f);
+                    const cfloat fb = image_y - cfloat(coo_y + 0.5f, 0.0f);
+                    Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+                }
+            }
+            const cfloat xl = (image_x - cx) / fx;
+            const cfloat yl = (image_y - cy) / fy;
+            const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
+            const cfloat sdf = norm(v_c_1) - norm(v_c);
+            if (Dp.re > 0 && sdf.re >= -a.tranc_dist) {
+                cfloat tsdf = sdf * a.tranc_dist_inv;
+                if (sdf.re > a.tranc_dist) tsdf = cfloat(1.0f, 0.0f);
+                const cfloat tsdf_prev(*pos, *gpos);
+                const int weight_prev = *wpos;
+                const cfloat tsdf_new = (tsdf_prev * __int2float_rn(weight_prev) + 1.0f * tsdf) / __int2float_rn(weight_prev + 1);
+                *pos = tsdf_new.re;
+                *wpos = min(weight_prev + 1, a.max_weight);
+                *gpos = tsdf_new.im;
+                ++n_upd;
+            }
+        }
+    }
+    if (a.updated) {
+        unsigned s = wave_sum_u32(n_upd);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.updated, (unsigned long long)s);
+    }
+}
+
+static void load_mat(const float *p, MatS33 &m) {
+    for (int r = 0; r < 3; ++r) {
+        m.data[r].x = cfloat(p[r * 6 + 0], p[r * 6 + 1]);
+        m.data[r].y = cfloat(p[r * 6 + 2], p[r * 6 + 3]);
+        m.data[r].z = cfloat(p[r * 6 + 4], p[r * 6 + 5]);
+    }
+}
+static void load_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
+
+extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
+                                   const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
+                                   float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
+                                   unsigned long long *updated_dev, void *stream) {
+    if (!depth_scaled || !intr4 || !res || !Rv2c18 || !tv2c6 || !value || !weight || !grad)
+        return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: null pointer");
+    if (z0 < 0 || z1 > res[2] || z1 < z0 || (vol_step % 4) != 0 || vol_step < (size_t)res[0] * 4)
+        return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: bad slab or pitch");
+    if (z1 == z0 || res[0] == 0 || res[1] == 0) return 0;
+    IntegrateArgs a;
+    a.depth = depth_scaled; a.dstep = scaled_step; a.drows = rows; a.dcols = cols;
+    a.value = value; a.weight = weight; a.grad = grad; a.vstep = vol_step;
+    a.X = res[0]; a.Y = res[1]; a.Z = res[2]; a.z0 = z0; a.z1 = z1;
+    a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist; a.max_weight = max_weight;
+    load_mat(Rv2c18, a.R); load_vec(tv2c6, a.t);
+    a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev;
+    // enough workgroups to fill 256 CUs several times over: split z so that grid >= ~4096 blocks
+    dim3 block(64, 4);
+    int gx = div_up(a.X, 64), gy = div_up(a.Y, 4);
+    int nz = z1 - z0;
+    int zsplit = 1;
+    while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
+    a.zchunk = div_up(nz, zsplit);
+    dim3 grid(gx, gy, div_up(nz, a.zchunk));
+    if (threshold > 0.0f)
+        hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, (hipStream_t)stream, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The reference's launcher (TsdfFusion.cu:173-201): u16 millimetres in, scale then integrate.
+// depth_scaled is caller-owned workspace (rows x cols floats) — the reference allocates and
+// frees it on every call (:180,:198); here it is resident.
+extern "C" int xs_integrate_tsdf_volume(const uint16_t *depth, size_t depth_step, int rows, int cols, const float *intr4, int max_weight,
+                                        const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
+                                        float *value, int *weight, float *grad, size_t vol_step, float *depth_scaled,
+                                        size_t scaled_step, float threshold, int z0, int z1, unsigned long long *updated_dev,
+                                        void *stream) {
+    int rc = xs_scale_depth(depth, depth_step, rows, cols, depth_scaled, scaled_step, stream);
+    if (rc) return rc;
+    return xs_integrate_scaled(depth_scaled, scaled_step, rows, cols, intr4, max_weight, res, voxel_size, Rv2c18, tv2c6, tranc_dist, value,
+                               weight, grad, vol_step, threshold, z0, z1, updated_dev, stream);
+}
