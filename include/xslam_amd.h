@@ -61,6 +61,78 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
                         int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
                         unsigned long long *updated_dev, void *stream);
 
+/* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */
+size_t xs_tsdf_reduce_workspace_bytes(void);
+/* float4 ComputeLocalTsdf_hessian(depth, Intr, depthScaled, res, voxel_size, const MatD33& Rv2c,
+ *     const devDComplex3& tv2c, tranc_dist, threshold, k, gt, real, grad, hessian, count)
+ *                                                  TsdfFusion.h:55-60, TsdfFusion.cu:204-331
+ * One fused pass: the reference's kernel + 4 thrust::reduce.  out4_dev = {loss, grad, hessian,
+ * count} as doubles.  gt: dense unpitched TSDF of the slab [z0, z1).  The four per-voxel
+ * volumes (indexed like gt) are optional: all four or none.  threshold / k are unused by the
+ * reference kernel and absent here. */
+int xs_compute_local_tsdf_hessian(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4,
+                                  const int *res, float voxel_size, const float *Rv2c36, const float *tv2c12, float tranc_dist,
+                                  const float *gt, float *real_out, float *grad_out, float *hess_out, int *count_out, int z0, int z1,
+                                  void *workspace, double *out4_dev, void *stream);
+/* float2 ComputeLocalTsdf_loss(..., const Mat33& Rv2c, const float3& tv2c, ..., gt, real, count)
+ *                                                  TsdfFusion.h:48-52, TsdfFusion.cu:335-447 */
+int xs_compute_local_tsdf_loss(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
+                               float voxel_size, const float *Rv2c9, const float *tv2c3, float tranc_dist, const float *gt,
+                               float *real_out, int *count_out, int z0, int z1, void *workspace, double *out2_dev, void *stream);
+
+/* ---- Depth / vertex / normal maps (Map.h:16-54) ------------------------------------------ */
+/* bilateralFilter(const DeviceArray2D<ushort>& src, MapArr& dst)            Map.cu:155-199, 262-271 */
+int xs_bilateral_filter(const uint16_t *src, size_t src_step, int rows, int cols, float *dst, size_t dst_step, void *stream);
+/* pyrDown(const MapArr& src, MapArr& dst); dst is (rows/2) x (cols/2)        Map.cu:202-230, 274-283 */
+int xs_pyr_down(const float *src, size_t src_step, int src_rows, int src_cols, float *dst, size_t dst_step, void *stream);
+/* createVMap(const Intr&, const MapArr& depth, MapArr& vmap)                 Map.cu:8-29, 73-86 */
+int xs_create_vmap(const float *intr4, const float *depth, size_t depth_step, int rows, int cols, float *vmap, size_t vmap_step,
+                   void *stream);
+/* createNMap(const MapArr& vmap, MapArr& nmap); rows = rows of one plane     Map.cu:32-70, 89-102 */
+int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, int rows, int cols, void *stream);
+/* resizeVMap / resizeNMap(const MapArr& in, MapArr& out); src_rows = rows of one input plane
+ *                                                                            Map.cu:105-152, 233-259 */
+int xs_resize_vmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream);
+int xs_resize_nmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream);
+
+/* ---- Raycast ------------------------------------------------------------------------------ */
+/* raycast(const Intr&, const MatS33& Rc2v, const devComplex3& tc2v, const MatS33& Rv2w,
+ *         const devComplex3& tv2w, float tranc_dist, const int3& res, float voxel_size,
+ *         const PtrStep<float>& value, const PtrStep<float>& grad, MapArr& vmap, MapArr& nmap)
+ *                                                  RayCaster.h:21-25, RayCaster.cu:197-368
+ * rows / cols: one map plane.  hits_dev: optional device counter of pixels given a vertex. */
+int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+               float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+               float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, void *stream);
+
+/* ---- ICP normal equations ----------------------------------------------------------------- */
+size_t xs_icp_workspace_bytes(void);
+/* Device half of estimateCombined (ICP.h:24-31, ICP.cu:166-281 + 120-164): sums_dev receives 55
+ * doubles — the 27 complex<double> sums in the reference's mbuf order, then the inlier count.
+ * workspace replaces gbuf.  [y0, y1): pixel rows covered.  No synchronisation. */
+int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                      const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                      const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
+                      void *workspace, double *sums_dev, void *stream);
+/* estimateCombined(...) whole: accumulate, synchronise the stream, download, unpack into the
+ * symmetric A (36 complex<double>, A[i*6+j] = A[j*6+i]) and b (6)          ICP.cu:365-429 */
+int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                         const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                         const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
+                         void *workspace, double *sums_dev, double *A72_host, double *b12_host, long long *inliers, void *stream);
+/* ICP.cu:419-428 on host data: 27 (re, im) sums -> A[36], b[6] */
+void xs_icp_unpack(const double *sums54, double *A72, double *b12);
+
+/* ---- DeviceArray complex math over arrays -------------------------------------------------- */
+/* Experiments/test_CSFD/main.cpp:18-86 over arrays: which 0 mul 1 div 2 exp 3 sin 4 pow(.,3);
+ * our 0 = *_raw, 1 = *_our. */
+int xs_csfd_array_op(int which, int our, const float *a, const float *b, float *out, long n, void *stream);
+/* f1(x, y) = (x + y)^2 in dual-complex arithmetic (test_CSFD/main.cpp:8-11) */
+int xs_dcsfd_f1(const float *x, const float *y, float *out, long n, void *stream);
+/* elementwise complex<float> (dual = 0) / d_complex<float> (dual = 1) operator tables
+ * (cuda_complex.hpp:100-881, cuda_double_complex.hpp:137-260); op codes listed in DESIGN.md */
+int xs_complex_table(int dual, int op, const float *a, const float *b, float *out, long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,28 @@ _SIGS = {
                                            _vp, _vp, _vp, _sz, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "xs_integrate_scaled": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float,
                                       _vp, _vp, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp]),
+    "xs_tsdf_reduce_workspace_bytes": (_sz, []),
+    "xs_compute_local_tsdf_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
+                                                _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "xs_compute_local_tsdf_loss": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
+                                             _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "xs_bilateral_filter": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "xs_pyr_down": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "xs_create_vmap": (C.c_int, [_f32p, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "xs_create_nmap": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp]),
+    "xs_resize_vmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "xs_resize_nmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "xs_raycast": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
+                             C.c_int, C.c_int, _vp, _vp]),
+    "xs_icp_workspace_bytes": (_sz, []),
+    "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
+                                    C.c_float, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "xs_estimate_combined": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
+                                       C.c_float, _vp, _vp, _f64p, _f64p, C.POINTER(C.c_longlong), _vp]),
+    "xs_icp_unpack": (None, [_f64p, _f64p, _f64p]),
+    "xs_csfd_array_op": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
+    "xs_dcsfd_f1": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
+    "xs_complex_table": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
 }
 
 
@@ -121,3 +143,113 @@ def integrate_scaled(depth_scaled, scaled_step, rows, cols, intr, max_weight, re
     check(_lib.xs_integrate_scaled(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), max_weight,
                                    r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
                                    _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _stream(stream)))
+
+
+def tsdf_reduce_workspace_bytes():
+    return _lib.xs_tsdf_reduce_workspace_bytes()
+
+
+def compute_local_tsdf_hessian(depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, gt, workspace, out4,
+                               volumes=None, z0=0, z1=None, stream=None):
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c, 36), _fa(tv2c, 12)
+    z1 = int(r[2]) if z1 is None else z1
+    vols = [_ptr(v) for v in volumes] if volumes else [None] * 4
+    check(_lib.xs_compute_local_tsdf_hessian(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p),
+                                             voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist, _ptr(gt), vols[0],
+                                             vols[1], vols[2], vols[3], z0, z1, _ptr(workspace), _ptr(out4), _stream(stream)))
+
+
+def compute_local_tsdf_loss(depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, gt, workspace, out2,
+                            volumes=None, z0=0, z1=None, stream=None):
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c, 9), _fa(tv2c, 3)
+    z1 = int(r[2]) if z1 is None else z1
+    vols = [_ptr(v) for v in volumes] if volumes else [None] * 2
+    check(_lib.xs_compute_local_tsdf_loss(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p),
+                                          voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist, _ptr(gt), vols[0],
+                                          vols[1], z0, z1, _ptr(workspace), _ptr(out2), _stream(stream)))
+
+
+def bilateral_filter(src, src_step, rows, cols, dst, dst_step, stream=None):
+    check(_lib.xs_bilateral_filter(_ptr(src), src_step, rows, cols, _ptr(dst), dst_step, _stream(stream)))
+
+
+def pyr_down(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
+    check(_lib.xs_pyr_down(_ptr(src), src_step, src_rows, src_cols, _ptr(dst), dst_step, _stream(stream)))
+
+
+def create_vmap(intr, depth, depth_step, rows, cols, vmap, vmap_step, stream=None):
+    k = _fa(intr, 4)
+    check(_lib.xs_create_vmap(k.ctypes.data_as(_f32p), _ptr(depth), depth_step, rows, cols, _ptr(vmap), vmap_step, _stream(stream)))
+
+
+def create_nmap(vmap, nmap, map_step, rows, cols, stream=None):
+    check(_lib.xs_create_nmap(_ptr(vmap), _ptr(nmap), map_step, rows, cols, _stream(stream)))
+
+
+def resize_vmap(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
+    check(_lib.xs_resize_vmap(_ptr(src), src_step, src_rows, src_cols, _ptr(dst), dst_step, _stream(stream)))
+
+
+def resize_nmap(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
+    check(_lib.xs_resize_nmap(_ptr(src), src_step, src_rows, src_cols, _ptr(dst), dst_step, _stream(stream)))
+
+
+def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols,
+            hits=None, stream=None):
+    r = _ia(res, 3)
+    k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
+                          vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
+
+
+def icp_workspace_bytes():
+    return _lib.xs_icp_workspace_bytes()
+
+
+def icp_accumulate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
+                   distThres, angleThres, workspace, sums, y0=0, y1=None, stream=None):
+    a, b, c, d, k = _fa(Rcurr, 18), _fa(tcurr, 6), _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    y1 = rows if y1 is None else y1
+    check(_lib.xs_icp_accumulate(P(a), P(b), _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
+                                 map_step, rows, cols, distThres, angleThres, y0, y1, _ptr(workspace), _ptr(sums), _stream(stream)))
+
+
+def estimate_combined(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
+                      distThres, angleThres, workspace, sums, stream=None):
+    """Returns (A[72], b[12], inliers) on the host after synchronising, like estimateCombined."""
+    a, b, c, d, k = _fa(Rcurr, 18), _fa(tcurr, 6), _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    A = np.zeros(72, np.float64)
+    bb = np.zeros(12, np.float64)
+    inl = C.c_longlong(0)
+    check(_lib.xs_estimate_combined(P(a), P(b), _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
+                                    map_step, rows, cols, distThres, angleThres, _ptr(workspace), _ptr(sums), A.ctypes.data_as(_f64p),
+                                    bb.ctypes.data_as(_f64p), C.byref(inl), _stream(stream)))
+    return A, bb, inl.value
+
+
+def icp_unpack(sums54):
+    s = np.ascontiguousarray(sums54, dtype=np.float64)
+    A = np.zeros(72, np.float64)
+    b = np.zeros(12, np.float64)
+    _lib.xs_icp_unpack(s.ctypes.data_as(_f64p), A.ctypes.data_as(_f64p), b.ctypes.data_as(_f64p))
+    return A, b
+
+
+CSFD_OPS = {"mul": 0, "div": 1, "exp": 2, "sin": 3, "pow": 4}
+
+
+def csfd_array_op(name, variant, a, b, out, n, stream=None):
+    check(_lib.xs_csfd_array_op(CSFD_OPS[name], 1 if variant == "our" else 0, _ptr(a), _ptr(b), _ptr(out), n, _stream(stream)))
+
+
+def dcsfd_f1(x, y, out, n, stream=None):
+    check(_lib.xs_dcsfd_f1(_ptr(x), _ptr(y), _ptr(out), n, _stream(stream)))
+
+
+def complex_table(dual, op, a, b, out, n, stream=None):
+    check(_lib.xs_complex_table(1 if dual else 0, op, _ptr(a), _ptr(b), _ptr(out), n, _stream(stream)))

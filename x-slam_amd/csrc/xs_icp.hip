@@ -1,0 +1,224 @@
+// xs_icp.hip — ICP point-to-plane normal equations for gfx950.  Replaces
+// XKinectFusion/src/ICP.cu:166-281 (Combined: search_newton + operator()), :5-118 (LDS tree
+// reductions), :120-164 (TranformReduction second kernel) and :365-429 (estimateCombined).
+//
+// Reference shape: one pixel per thread, 27 complex products each pushed through an LDS tree
+// (27 x 2 barriers + 8 steps), 518 KB of per-block partials, and a second 27-block launch to
+// add them up; the tree's tail relies on 32-wide warp-synchronous execution (ICP.cu:40-65).
+// Here: each lane owns a strip of pixels and keeps the 27 complex sums (54 doubles) in
+// registers — products in complex float, accumulation in double, as the reference
+// (ICP.cu:273-274).  A wave folds its 64 lanes with cross-lane shuffles, the four waves of a
+// workgroup meet once in LDS, and the workgroup writes one 54-double partial.  The last
+// workgroup to arrive (agent-scope ticket) adds the partials in index order, so the result is
+// deterministic and there is no second launch.
+#include "xs_device.h"
+#include "../../include/xslam_amd.h"
+
+using namespace xs;
+
+struct IcpArgs {
+    MatS33 Rcurr; cfloat3 tcurr;
+    const cfloat *vmap_curr; const cfloat *nmap_curr;
+    MatS33 Rprev_inv; cfloat3 tprev;
+    Intr intr;
+    const cfloat *vmap_g_prev; const cfloat *nmap_g_prev;
+    size_t mstep;
+    float distThres, angleThres;
+    int cols, rows;
+    int y0, y1;             // pixel rows this launch covers (row sharding across GPUs)
+    double *partials;       // [gridDim.x][56]
+    unsigned *ticket;       // zeroed before the launch
+    double *out;            // 54 sums (27 x re,im) + [54] = inlier count
+};
+
+namespace {
+// ICP.cu:196-244
+__device__ __forceinline__ bool search(const IcpArgs &a, int x, int y, cfloat3 &n, cfloat3 &d, cfloat3 &s) {
+    cfloat3 ncurr;
+    ncurr.x = row_ptr(a.nmap_curr, a.mstep, y)[x];
+    if (isnan(ncurr.x.re)) return false;
+    ncurr.y = row_ptr(a.nmap_curr, a.mstep, y + a.rows)[x];
+    ncurr.z = row_ptr(a.nmap_curr, a.mstep, y + 2 * a.rows)[x];
+    cfloat3 vcurr;
+    vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
+    vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
+    vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
+    const cfloat3 vcurr_g = a.Rcurr * vcurr + a.tcurr;
+    const cfloat3 vcp = a.Rprev_inv * (vcurr_g - a.tprev);
+    const float cpx = vcp.x.re, cpy = vcp.y.re, cpz = vcp.z.re;
+    const int ux = __float2int_rn(cpx * a.intr.fx / cpz + a.intr.cx);
+    const int uy = __float2int_rn(cpy * a.intr.fy / cpz + a.intr.cy);
+    if (ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || cpz < 0) return false;
+    cfloat3 nprev_g;
+    nprev_g.x = row_ptr(a.nmap_g_prev, a.mstep, uy)[ux];
+    if (isnan(nprev_g.x.re)) return false;
+    nprev_g.y = row_ptr(a.nmap_g_prev, a.mstep, uy + a.rows)[ux];
+    nprev_g.z = row_ptr(a.nmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    cfloat3 vprev_g;
+    vprev_g.x = row_ptr(a.vmap_g_prev, a.mstep, uy)[ux];
+    vprev_g.y = row_ptr(a.vmap_g_prev, a.mstep, uy + a.rows)[ux];
+    vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    const cfloat dist = norm(vprev_g - vcurr_g);
+    if (dist.re > a.distThres) return false;
+    const cfloat3 ncurr_g = a.Rcurr * ncurr;
+    const cfloat sine = norm(cross(ncurr_g, nprev_g));
+    if (sine.re >= a.angleThres) return false;
+    n = nprev_g; d = vprev_g; s = vcurr_g;
+    return true;
+}
+constexpr int NS = 54;      // 27 complex sums
+constexpr int NP = 56;      // partial record: 54 sums + count + pad
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    double cnt = 0.0;
+    // 64 consecutive columns per wave; workgroups stride over (row, column-tile) pairs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (a.cols + 63) / 64;
+    const int ntiles = tiles_x * (a.y1 - a.y0);
+    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+        const int y = a.y0 + t / tiles_x;
+        const int x = (t % tiles_x) * 64 + lane;
+        if (x >= a.cols) continue;
+        cfloat3 n, d, s;
+        if (!search(a, x, y, n, d, s)) continue;
+        cfloat row[7];
+        const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
+        row[0] = cr.x; row[1] = cr.y; row[2] = cr.z;
+        row[3] = n.x; row[4] = n.y; row[5] = n.z;
+        row[6] = dot(n, d - s);
+        int shift = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 7; ++j) {
+                const cfloat p = row[i] * row[j];
+                acc[2 * shift] += (double)p.re;
+                acc[2 * shift + 1] += (double)p.im;
+                ++shift;
+            }
+        cnt += 1.0;
+    }
+    // wave fold, then one LDS exchange across the 4 waves
+    __shared__ double smem[4][NP];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double v = wave_sum_f64(acc[k]);
+        if (lane == 0) smem[wave][k] = v;
+    }
+    {
+        const double v = wave_sum_f64(cnt);
+        if (lane == 0) smem[wave][NS] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS + 1) {
+        const double v = ((smem[0][threadIdx.x] + smem[1][threadIdx.x]) + smem[2][threadIdx.x]) + smem[3][threadIdx.x];
+        // write-through store so the last workgroup reads it from memory, not a stale cache
+        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NP + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // publish: every storing wave drains its stores, the workgroup meets, one lane takes a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned s_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < NS + 1) {
+        double sum = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b)
+            sum += __hip_atomic_load(&a.partials[(size_t)b * NP + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.out[threadIdx.x] = sum;
+    }
+}
+
+static void ld_mat(const float *p, MatS33 &m) {
+    for (int r = 0; r < 3; ++r) {
+        m.data[r].x = cfloat(p[r * 6 + 0], p[r * 6 + 1]);
+        m.data[r].y = cfloat(p[r * 6 + 2], p[r * 6 + 3]);
+        m.data[r].z = cfloat(p[r * 6 + 4], p[r * 6 + 5]);
+    }
+}
+static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
+
+enum { XS_ICP_MAX_BLOCKS = 512 };
+
+extern "C" size_t xs_icp_workspace_bytes(void) { return (size_t)XS_ICP_MAX_BLOCKS * NP * sizeof(double) + 256; }
+
+/* estimateCombined(const MatS33& Rcurr, const devComplex3& tcurr, const MapArr& vmap_curr,
+ *     const MapArr& nmap_curr, const MatS33& Rprev_inv, const devComplex3& tprev, const Intr&,
+ *     const MapArr& vmap_g_prev, const MapArr& nmap_g_prev, float distThres, float angleThres,
+ *     DeviceArray2D<devComplexICP>& gbuf, DeviceArray<devComplexICP>& mbuf,
+ *     hostComplexICP* A, hostComplexICP* b)                 ICP.h:24-31, ICP.cu:365-429
+ * Device half: enqueue the reduction; sums_dev receives 55 doubles = the 27 complex<double>
+ * sums in the reference's mbuf order (ICP.cu:266-280) followed by the inlier count.
+ * workspace: xs_icp_workspace_bytes() bytes of device memory (replaces gbuf).  [y0, y1): pixel
+ * rows covered (0, rows for one GPU).  No synchronisation, no download. */
+extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                                 const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                                 const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
+                                 int y0, int y1, void *workspace, double *sums_dev, void *stream) {
+    if (!Rcurr18 || !tcurr6 || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
+        !workspace || !sums_dev)
+        return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate: null pointer");
+    if (y0 < 0 || y1 > rows || y1 < y0) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate: bad row range");
+    IcpArgs a;
+    ld_mat(Rcurr18, a.Rcurr); ld_vec(tcurr6, a.tcurr); ld_mat(Rprev_inv18, a.Rprev_inv); ld_vec(tprev6, a.tprev);
+    a.vmap_curr = (const cfloat *)vmap_curr; a.nmap_curr = (const cfloat *)nmap_curr;
+    a.vmap_g_prev = (const cfloat *)vmap_g_prev; a.nmap_g_prev = (const cfloat *)nmap_g_prev;
+    a.mstep = map_step; a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.distThres = distThres; a.angleThres = angleThres; a.cols = cols; a.rows = rows; a.y0 = y0; a.y1 = y1;
+    a.ticket = (unsigned *)workspace;
+    a.partials = (double *)((char *)workspace + 256);
+    a.out = sums_dev;
+    const int tiles = div_up(cols, 64) * (y1 - y0);
+    int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
+    if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    XS_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_icp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* Host half of estimateCombined (ICP.cu:414-428): synchronise the stream, download the 27
+ * sums and unpack them into the symmetric 6x6 A (A[i*6+j] = A[j*6+i]) and b, both as
+ * complex<double> (re, im) pairs.  inliers may be NULL. */
+extern "C" int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                                    const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                                    const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
+                                    void *workspace, double *sums_dev, double *A72_host, double *b12_host, long long *inliers,
+                                    void *stream) {
+    int rc = xs_icp_accumulate(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step,
+                               rows, cols, distThres, angleThres, 0, rows, workspace, sums_dev, stream);
+    if (rc) return rc;
+    double host[55];
+    XS_CHECK(hipMemcpyAsync(host, sums_dev, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    XS_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    xs_icp_unpack(host, A72_host, b12_host);
+    if (inliers) *inliers = (long long)host[54];
+    return 0;
+}
+
+/* ICP.cu:419-428 on the host: 27 (re, im) sums -> symmetric A[36] and b[6], complex<double> */
+extern "C" void xs_icp_unpack(const double *sums54, double *A72, double *b12) {
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const double re = sums54[2 * shift], im = sums54[2 * shift + 1];
+            ++shift;
+            if (j == 6) { b12[2 * i] = re; b12[2 * i + 1] = im; }
+            else {
+                A72[2 * (j * 6 + i)] = re; A72[2 * (j * 6 + i) + 1] = im;
+                A72[2 * (i * 6 + j)] = re; A72[2 * (i * 6 + j) + 1] = im;
+            }
+        }
+}

@@ -1,0 +1,214 @@
+// xs_map.hip — depth / vertex / normal map preparation for gfx950.  Replaces
+// XKinectFusion/src/Map.cu: bilateralKernel (:155-199, launcher :262-271), pyrDownKernel
+// (:202-230, :274-283), computeVmapKernel (:8-29, :73-86), computeNmapKernel (:32-70, :89-102),
+// resizeMapKernel<normalize> (:105-152, :233-259).
+//
+// Maps are complex (re, im) float pairs; a vertex / normal map is three stacked planes of
+// rows x cols (x rows, then y, then z).  Invalid pixels carry the NaN sentinel in the x plane
+// only (Map.cu:27,42,69,126).  All kernels put 64 consecutive columns on a wave so every row
+// access is one coalesced segment (512 B of complex per wave-row).
+#include "xs_device.h"
+#include "../../include/xslam_amd.h"
+
+using namespace xs;
+
+namespace {
+constexpr float kSigmaColor = 30.f;   // mm, Map.cu:4
+constexpr float kSigmaSpace = 4.5f;   // px, Map.cu:5
+constexpr int BR = 6, BD = 2 * BR + 1;  // 13x13 window (Map.cu:169-170)
+constexpr int BTX = 64, BTY = 4;        // block = 4 waves, one image row each
+}  // namespace
+
+// The 13x13 window of every pixel of a 64x4 block is staged once in LDS as u16 (76 x 16 tile,
+// 2.4 KB), so the 169 taps per pixel are LDS reads instead of 169 global loads.  The taps are
+// accumulated in the reference's order (rows outer, columns inner): float sums are order
+// dependent and the result is rounded to an integer millimetre.
+__global__ void __launch_bounds__(BTX *BTY) k_bilateral(const uint16_t *src, size_t sstep, int rows, int cols, cfloat *dst, size_t dstep,
+                                                        float sigma_space2_inv_half, float sigma_color2_inv_half) {
+    __shared__ uint16_t tile[BTY + 2 * BR][BTX + 2 * BR + 4];
+    const int bx = blockIdx.x * BTX, by = blockIdx.y * BTY;
+    const int tid = threadIdx.y * BTX + threadIdx.x;
+    for (int i = tid; i < (BTY + 2 * BR) * (BTX + 2 * BR); i += BTX * BTY) {
+        int ty = i / (BTX + 2 * BR), tx = i % (BTX + 2 * BR);
+        int gy = by + ty - BR, gx = bx + tx - BR;
+        uint16_t v = 0;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = row_ptr(src, sstep, gy)[gx];
+        tile[ty][tx] = v;
+    }
+    __syncthreads();
+    const int x = bx + threadIdx.x, y = by + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const int value = tile[threadIdx.y + BR][threadIdx.x + BR];
+    const int tx = min(x - BD / 2 + BD, cols - 1);  // exclusive; the last column/row is never read (Map.cu:172-179)
+    const int ty = min(y - BD / 2 + BD, rows - 1);
+    float sum1 = 0, sum2 = 0;
+    for (int cy = max(y - BD / 2, 0); cy < ty; ++cy) {
+        for (int cx = max(x - BD / 2, 0); cx < tx; ++cx) {
+            const int tmp = tile[cy - by + BR][cx - bx + BR];
+            const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+            const float color2 = (float)((value - tmp) * (value - tmp));
+            const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+            sum1 += tmp * weight;
+            sum2 += weight;
+        }
+    }
+    int round = __float2int_rn(sum1 / sum2);
+    if (round > 5000 || round < 200) round = 0;
+    round = max(0, min(round, 32767));
+    row_ptr(dst, dstep, y)[x] = cfloat(__int2float_rd(round), 0.f);
+}
+
+/* bilateralFilter(const DeviceArray2D<ushort>& src, MapArr& dst)   Map.h:16-22, Map.cu:262-271 */
+extern "C" int xs_bilateral_filter(const uint16_t *src, size_t src_step, int rows, int cols, float *dst, size_t dst_step, void *stream) {
+    if (!src || !dst) return xs_set_error(hipErrorInvalidValue, "xs_bilateral_filter: null pointer");
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 block(BTX, BTY), grid(div_up(cols, BTX), div_up(rows, BTY));
+    hipLaunchKernelGGL(k_bilateral, grid, block, 0, (hipStream_t)stream, src, src_step, rows, cols, (cfloat *)dst, dst_step,
+                       0.5f / (kSigmaSpace * kSigmaSpace), 0.5f / (kSigmaColor * kSigmaColor));
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pyr_down(const cfloat *src, size_t sstep, int srows, int scols, cfloat *dst, size_t dstep,
+                                                  int drows, int dcols, float sigma_color) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dcols || y >= drows) return;
+    const int D = 5;
+    const int center = __float2int_rn(row_ptr(src, sstep, 2 * y)[2 * x].re);
+    const int tx = min(2 * x - D / 2 + D, scols - 1);
+    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    int sum = 0, count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const int val = __float2int_rn(row_ptr(src, sstep, cy)[cx].re);
+            if (abs(val - center) < 3 * sigma_color) { sum += val; ++count; }
+        }
+    row_ptr(dst, dstep, y)[x] = cfloat(__int2float_rd(sum / count), 0.f);  // integer division (Map.cu:228)
+}
+
+/* pyrDown(const MapArr& src, MapArr& dst)   Map.h:24-29, Map.cu:274-283; dst is (rows/2) x (cols/2) */
+extern "C" int xs_pyr_down(const float *src, size_t src_step, int src_rows, int src_cols, float *dst, size_t dst_step, void *stream) {
+    if (!src || !dst) return xs_set_error(hipErrorInvalidValue, "xs_pyr_down: null pointer");
+    int drows = src_rows / 2, dcols = src_cols / 2;
+    if (drows <= 0 || dcols <= 0) return 0;
+    dim3 block(64, 4), grid(div_up(dcols, 64), div_up(drows, 4));
+    hipLaunchKernelGGL(k_pyr_down, grid, block, 0, (hipStream_t)stream, (const cfloat *)src, src_step, src_rows, src_cols, (cfloat *)dst,
+                       dst_step, drows, dcols, kSigmaColor);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vmap(const cfloat *depth, size_t dstep, int rows, int cols, cfloat *vmap, size_t mstep, float fx_inv,
+                                              float fy_inv, float cx, float cy) {
+    const int u = threadIdx.x + blockIdx.x * blockDim.x;
+    const int v = threadIdx.y + blockIdx.y * blockDim.y;
+    if (u >= cols || v >= rows) return;
+    cfloat z = row_ptr(depth, dstep, v)[u];
+    z /= 1000.f;
+    if (z.re != 0) {
+        const cfloat vx = z * (float(u) - cx) * fx_inv;
+        const cfloat vy = z * (float(v) - cy) * fy_inv;
+        row_ptr(vmap, mstep, v)[u] = vx;
+        row_ptr(vmap, mstep, v + rows)[u] = vy;
+        row_ptr(vmap, mstep, v + rows * 2)[u] = z;
+    } else
+        row_ptr(vmap, mstep, v)[u] = cfloat(qnan_f(), 0.f);
+}
+
+/* createVMap(const Intr&, const MapArr& depth, MapArr& vmap)   Map.h:31-37, Map.cu:73-86 */
+extern "C" int xs_create_vmap(const float *intr4, const float *depth, size_t depth_step, int rows, int cols, float *vmap, size_t vmap_step,
+                              void *stream) {
+    if (!intr4 || !depth || !vmap) return xs_set_error(hipErrorInvalidValue, "xs_create_vmap: null pointer");
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
+    hipLaunchKernelGGL(k_vmap, grid, block, 0, (hipStream_t)stream, (const cfloat *)depth, depth_step, rows, cols, (cfloat *)vmap, vmap_step,
+                       1.f / intr4[0], 1.f / intr4[1], intr4[2], intr4[3]);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_nmap(int rows, int cols, const cfloat *vmap, cfloat *nmap, size_t mstep) {
+    const int u = threadIdx.x + blockIdx.x * blockDim.x;
+    const int v = threadIdx.y + blockIdx.y * blockDim.y;
+    if (u >= cols || v >= rows) return;
+    if (u == cols - 1 || v == rows - 1) { row_ptr(nmap, mstep, v)[u] = cfloat(qnan_f(), 0.f); return; }
+    cfloat3 v00, v01, v10;
+    v00.x = row_ptr(vmap, mstep, v)[u];
+    v01.x = row_ptr(vmap, mstep, v)[u + 1];
+    v10.x = row_ptr(vmap, mstep, v + 1)[u];
+    if (!isnan(v00.x.re) && !isnan(v01.x.re) && !isnan(v10.x.re)) {
+        v00.y = row_ptr(vmap, mstep, v + rows)[u];
+        v01.y = row_ptr(vmap, mstep, v + rows)[u + 1];
+        v10.y = row_ptr(vmap, mstep, v + 1 + rows)[u];
+        v00.z = row_ptr(vmap, mstep, v + 2 * rows)[u];
+        v01.z = row_ptr(vmap, mstep, v + 2 * rows)[u + 1];
+        v10.z = row_ptr(vmap, mstep, v + 1 + 2 * rows)[u];
+        const cfloat3 r = normalized(cross(v01 - v00, v10 - v00));
+        row_ptr(nmap, mstep, v)[u] = r.x;
+        row_ptr(nmap, mstep, v + rows)[u] = r.y;
+        row_ptr(nmap, mstep, v + 2 * rows)[u] = r.z;
+    } else
+        row_ptr(nmap, mstep, v)[u] = cfloat(qnan_f(), 0.f);
+}
+
+/* createNMap(const MapArr& vmap, MapArr& nmap)   Map.h:39-44, Map.cu:89-102; rows = map rows / 3 */
+extern "C" int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, int rows, int cols, void *stream) {
+    if (!vmap || !nmap) return xs_set_error(hipErrorInvalidValue, "xs_create_nmap: null pointer");
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
+    hipLaunchKernelGGL(k_nmap, grid, block, 0, (hipStream_t)stream, rows, cols, (const cfloat *)vmap, (cfloat *)nmap, map_step);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+template <bool NORMALIZE>
+__global__ void __launch_bounds__(256) k_resize(int drows, int dcols, int srows, const cfloat *in, size_t istep, cfloat *out, size_t ostep) {
+    const int x = threadIdx.x + blockIdx.x * blockDim.x;
+    const int y = threadIdx.y + blockIdx.y * blockDim.y;
+    if (x >= dcols || y >= drows) return;
+    const int xs_ = x * 2, ys = y * 2;
+    const cfloat x00 = row_ptr(in, istep, ys)[xs_], x01 = row_ptr(in, istep, ys)[xs_ + 1];
+    const cfloat x10 = row_ptr(in, istep, ys + 1)[xs_], x11 = row_ptr(in, istep, ys + 1)[xs_ + 1];
+    if (isnan(x00.re) || isnan(x01.re) || isnan(x10.re) || isnan(x11.re)) {
+        row_ptr(out, ostep, y)[x] = cfloat(qnan_f(), 0.f);
+        return;
+    }
+    cfloat3 n;
+    n.x = (x00 + x01 + x10 + x11) / 4.0f;
+    const cfloat y00 = row_ptr(in, istep, ys + srows)[xs_], y01 = row_ptr(in, istep, ys + srows)[xs_ + 1];
+    const cfloat y10 = row_ptr(in, istep, ys + srows + 1)[xs_], y11 = row_ptr(in, istep, ys + srows + 1)[xs_ + 1];
+    n.y = (y00 + y01 + y10 + y11) / 4.0f;
+    const cfloat z00 = row_ptr(in, istep, ys + 2 * srows)[xs_], z01 = row_ptr(in, istep, ys + 2 * srows)[xs_ + 1];
+    const cfloat z10 = row_ptr(in, istep, ys + 2 * srows + 1)[xs_], z11 = row_ptr(in, istep, ys + 2 * srows + 1)[xs_ + 1];
+    n.z = (z00 + z01 + z10 + z11) / 4.0f;
+    if (NORMALIZE) n = normalized(n);
+    row_ptr(out, ostep, y)[x] = n.x;
+    row_ptr(out, ostep, y + drows)[x] = n.y;
+    row_ptr(out, ostep, y + 2 * drows)[x] = n.z;
+}
+
+static int resize_map(bool normalize, const float *in, size_t istep, int srows, int scols, float *out, size_t ostep, void *stream) {
+    if (!in || !out) return xs_set_error(hipErrorInvalidValue, "xs_resize_map: null pointer");
+    int drows = srows / 2, dcols = scols / 2;
+    if (drows <= 0 || dcols <= 0) return 0;
+    dim3 block(64, 4), grid(div_up(dcols, 64), div_up(drows, 4));
+    if (normalize)
+        hipLaunchKernelGGL(k_resize<true>, grid, block, 0, (hipStream_t)stream, drows, dcols, srows, (const cfloat *)in, istep, (cfloat *)out, ostep);
+    else
+        hipLaunchKernelGGL(k_resize<false>, grid, block, 0, (hipStream_t)stream, drows, dcols, srows, (const cfloat *)in, istep, (cfloat *)out, ostep);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+/* resizeVMap / resizeNMap(const MapArr& input, MapArr& output)   Map.h:46-54, Map.cu:233-259
+ * src_rows = rows of ONE plane of the input.  The reference synchronises here (:248). */
+extern "C" int xs_resize_vmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream) {
+    return resize_map(false, in, in_step, src_rows, src_cols, out, out_step, stream);
+}
+extern "C" int xs_resize_nmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream) {
+    return resize_map(true, in, in_step, src_rows, src_cols, out, out_step, stream);
+}

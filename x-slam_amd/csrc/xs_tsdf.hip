@@ -223,3 +223,248 @@ extern "C" int xs_integrate_tsdf_volume(const uint16_t *depth, size_t depth_step
     return xs_integrate_scaled(depth_scaled, scaled_step, rows, cols, intr4, max_weight, res, voxel_size, Rv2c18, tv2c6, tranc_dist, value,
                                weight, grad, vol_step, threshold, z0, z1, updated_dev, stream);
 }
+
+// ==========================================================================================
+// Dual-complex Hessian kernel and its real-valued twin.  Replaces TsdfFusion.cu:204-283
+// (ComputeLocalTsdfHessianKernel) + :286-331 (ComputeLocalTsdf_hessian) and :335-410 + :412-447
+// (ComputeLocalTsdfLossKernel / ComputeLocalTsdf_loss).
+//
+// The reference writes four N^3 scratch volumes (value / grad / hessian / count) and then runs
+// four thrust::reduce passes over them: five full-volume passes.  Here the per-voxel terms are
+// folded on chip — lane registers, wave shuffles, one LDS exchange, one record per workgroup,
+// and the last workgroup adds the records in index order — so the only N^3 traffic is the 4 B
+// per voxel of the dense ground-truth TSDF (algorithmic bytes 4*N^3 + 2*W*H).  Sums are kept
+// in double and rounded once; thrust's float tree order is unspecified in the reference.
+struct HessArgs {
+    const float *depth; size_t dstep; int drows, dcols;
+    int X, Y, Z, z0, z1, zchunk;
+    float voxel_size, tranc_dist, tranc_dist_inv;
+    Intr intr;
+    const float *gt;      // dense, unpitched: index z*Y*X + y*X + x, storage starts at z0
+    double *partials;     // [blocks][8]
+    unsigned *ticket;
+    double *out;          // hessian: {loss, grad, hessian, count}; loss: {loss, count}
+    float *real_out, *grad_out, *hess_out; int *count_out;  // optional per-voxel volumes (same indexing as gt)
+};
+struct HessPoseD { MatD33 R; dcfloat3 t; };
+struct HessPoseF { float R[9]; float t[3]; };
+
+template <int NV>
+__device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *partials, unsigned *ticket, double *out) {
+    __shared__ double sm[4][NV];
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_sum_f64(v[k]);
+        if (lane == 0) sm[wave][k] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        const double s = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
+        __hip_atomic_store(&partials[(size_t)bid * 8 + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == nblocks - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (s_last) {
+        // 64 lanes stride over the records, then a wave fold: fixed association, deterministic
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                double s = 0.0;
+                for (unsigned b = lane; b < nblocks; b += 64)
+                    s += __hip_atomic_load(&partials[(size_t)b * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s = wave_sum_f64(s);
+                if (lane == 0) out[k] = s;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const HessPoseD P) {
+    const int x = threadIdx.x + blockIdx.x * 64;
+    const int y = threadIdx.y + blockIdx.y * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (x < a.X && y < a.Y) {
+        const int zb = a.z0 + blockIdx.z * a.zchunk, ze = min(zb + a.zchunk, a.z1);
+        const dcfloat vgx((float(x) + 0.5f) * a.voxel_size), vgy((float(y) + 0.5f) * a.voxel_size);
+        for (int z = zb; z < ze; ++z) {
+            const size_t index = (size_t)(z - a.z0) * a.Y * a.X + (size_t)y * a.X + x;
+            const float gt = a.gt[index];
+            if (gt == 0 || fabsf(gt) > 0.95) continue;
+            const dcfloat gt_tsdf(gt);
+            const dcfloat vgz((float(z) + 0.5f) * a.voxel_size);
+            dcfloat3 v_g; v_g.x = vgx; v_g.y = vgy; v_g.z = vgz;
+            dcfloat3 v_c;
+            v_c.x = dot(P.R.data[0], v_g) + P.t.x;
+            v_c.y = dot(P.R.data[1], v_g) + P.t.y;
+            v_c.z = dot(P.R.data[2], v_g) + P.t.z;
+            const dcfloat inv_z = dcfloat(1.0f) / v_c.z;
+            if (inv_z.value() < 0) continue;
+            const dcfloat image_x = v_c.x * inv_z * a.intr.fx + a.intr.cx;
+            const dcfloat image_y = v_c.y * inv_z * a.intr.fy + a.intr.cy;
+            const int coo_x = __float2int_rd(image_x.value() - 0.5f), coo_y = __float2int_rd(image_y.value() - 0.5f);
+            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
+            const int near_x = __float2int_rn(image_x.value()), near_y = __float2int_rn(image_y.value());
+            dcfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x]);
+            const dcfloat d00(row_ptr(a.depth, a.dstep, coo_y)[coo_x]), d10(row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1]);
+            const dcfloat d01(row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x]), d11(row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1]);
+            if (d00.value() != 0.0f && d01.value() != 0.0f && d10.value() != 0.0f && d11.value() != 0.0f) {  // :248-251, threshold unused
+                const dcfloat one(1.0f);
+                const dcfloat fa = image_x - dcfloat(float(coo_x) + 0.5f);
+                const dcfloat fb = image_y - dcfloat(float(coo_y) + 0.5f);
+                Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+            }
+            if (Dp.value() > 5 || Dp.value() < 0.2) continue;
+            const dcfloat xl = (image_x - a.intr.cx) / a.intr.fx;
+            const dcfloat yl = (image_y - a.intr.cy) / a.intr.fy;
+            dcfloat3 v_c_1; v_c_1.x = Dp * xl; v_c_1.y = Dp * yl; v_c_1.z = Dp;
+            const dcfloat distance = norm(v_c_1) - norm(v_c);
+            const dcfloat gt_distance = gt_tsdf * a.tranc_dist;
+            const dcfloat error = (distance - gt_distance) * a.tranc_dist_inv;
+            if (fabsf(error.value()) > 1) continue;
+            const dcfloat loss = error * error;
+            if (a.real_out) {
+                a.real_out[index] = loss.value(); a.grad_out[index] = loss.grad();
+                a.hess_out[index] = loss.hessian(); a.count_out[index] = 1;
+            }
+            acc[0] += loss.value(); acc[1] += loss.grad(); acc[2] += loss.hessian(); acc[3] += 1.0;
+        }
+    }
+    block_fold_and_finish<4>(acc, a.partials, a.ticket, a.out);
+}
+
+__global__ void __launch_bounds__(256) k_tsdf_loss(const HessArgs a, const HessPoseF P) {
+    const int x = threadIdx.x + blockIdx.x * 64;
+    const int y = threadIdx.y + blockIdx.y * 4;
+    double acc[2] = {0.0, 0.0};
+    if (x < a.X && y < a.Y) {
+        const int zb = a.z0 + blockIdx.z * a.zchunk, ze = min(zb + a.zchunk, a.z1);
+        const float vgx = (float(x) + 0.5f) * a.voxel_size, vgy = (float(y) + 0.5f) * a.voxel_size;
+        for (int z = zb; z < ze; ++z) {
+            const size_t index = (size_t)(z - a.z0) * a.Y * a.X + (size_t)y * a.X + x;
+            const float gt_tsdf = a.gt[index];
+            if (gt_tsdf == 0 || fabsf(gt_tsdf) > 0.95) continue;
+            const float vgz = (float(z) + 0.5f) * a.voxel_size;
+            const float vcx = (P.R[0] * vgx + P.R[1] * vgy + P.R[2] * vgz) + P.t[0];
+            const float vcy = (P.R[3] * vgx + P.R[4] * vgy + P.R[5] * vgz) + P.t[1];
+            const float vcz = (P.R[6] * vgx + P.R[7] * vgy + P.R[8] * vgz) + P.t[2];
+            const float inv_z = 1.0f / vcz;
+            if (inv_z < 0) continue;
+            const float image_x = vcx * inv_z * a.intr.fx + a.intr.cx;
+            const float image_y = vcy * inv_z * a.intr.fy + a.intr.cy;
+            const int coo_x = __float2int_rd(image_x - 0.5f), coo_y = __float2int_rd(image_y - 0.5f);
+            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
+            const int near_x = __float2int_rn(image_x), near_y = __float2int_rn(image_y);
+            float Dp = row_ptr(a.depth, a.dstep, near_y)[near_x];
+            const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x], d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
+            const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x], d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+            if (d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+                const float one = 1.0f;
+                const float fa = image_x - (float(coo_x) + 0.5f), fb = image_y - (float(coo_y) + 0.5f);
+                Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+            }
+            if (Dp > 5 || Dp < 0.2) continue;
+            const float xl = (image_x - a.intr.cx) / a.intr.fx, yl = (image_y - a.intr.cy) / a.intr.fy;
+            const float v1x = Dp * xl, v1y = Dp * yl, v1z = Dp;
+            const float distance = sqrtf(v1x * v1x + v1y * v1y + v1z * v1z) - sqrtf(vcx * vcx + vcy * vcy + vcz * vcz);
+            const float gt_distance = gt_tsdf * a.tranc_dist;
+            const float error = (distance - gt_distance) * a.tranc_dist_inv;
+            if (fabsf(error) > 1) continue;
+            const float loss = error * error;
+            if (a.real_out) { a.real_out[index] = loss; a.count_out[index] = 1; }
+            acc[0] += loss; acc[1] += 1.0;
+        }
+    }
+    block_fold_and_finish<2>(acc, a.partials, a.ticket, a.out);
+}
+
+enum { XS_TSDF_REDUCE_MAX_BLOCKS = 65536 };
+extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_REDUCE_MAX_BLOCKS * 8 * sizeof(double) + 256; }
+
+static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
+                       float voxel_size, float tranc_dist, const float *gt, int z0, int z1, void *workspace, double *out_dev, dim3 &grid,
+                       void *stream) {
+    if (!depth_scaled || !intr4 || !res || !gt || !workspace || !out_dev) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: null pointer");
+    if (z0 < 0 || z1 > res[2] || z1 <= z0) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: bad slab");
+    a.depth = depth_scaled; a.dstep = scaled_step; a.drows = rows; a.dcols = cols;
+    a.X = res[0]; a.Y = res[1]; a.Z = res[2]; a.z0 = z0; a.z1 = z1;
+    a.voxel_size = voxel_size; a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist;
+    a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.gt = gt; a.ticket = (unsigned *)workspace; a.partials = (double *)((char *)workspace + 256); a.out = out_dev;
+    int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
+    while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
+    a.zchunk = div_up(nz, zsplit);
+    grid = dim3(gx, gy, div_up(nz, a.zchunk));
+    if ((long long)grid.x * grid.y * grid.z > XS_TSDF_REDUCE_MAX_BLOCKS) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: volume too large for the reduce workspace");
+    XS_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
+    return 0;
+}
+
+/* float4 ComputeLocalTsdf_hessian(const PtrStepSz<ushort>& depth, const Intr&, DeviceArray2D<float>& depthScaled,
+ *     const int3& res, float voxel_size, const MatD33& Rv2c, const devDComplex3& tv2c, float tranc_dist,
+ *     float threshold, float k, thrustDvec<float>& gt, real, grad, hessian, thrustDvec<int>& count)
+ *                                                        TsdfFusion.h:55-60, TsdfFusion.cu:286-331
+ * depth_scaled: output of xs_scale_depth.  Rv2c36 / tv2c12: MatD33 / devDComplex3 as groups of
+ * (re.re, re.im, im.re, im.im).  gt: dense unpitched TSDF of the slab [z0, z1).  out4_dev: 4
+ * doubles {loss, grad, hessian, count} (the reference returns them narrowed to float4).  The
+ * four per-voxel volumes are optional (all four or none).  threshold and k are unused by the
+ * reference kernel.  No synchronisation. */
+extern "C" int xs_compute_local_tsdf_hessian(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4,
+                                             const int *res, float voxel_size, const float *Rv2c36, const float *tv2c12,
+                                             float tranc_dist, const float *gt, float *real_out, float *grad_out, float *hess_out,
+                                             int *count_out, int z0, int z1, void *workspace, double *out4_dev, void *stream) {
+    HessArgs a; dim3 grid;
+    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out4_dev, grid, stream);
+    if (rc) return rc;
+    if (!Rv2c36 || !tv2c12) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_hessian: null pose");
+    const bool all = real_out && grad_out && hess_out && count_out, none = !real_out && !grad_out && !hess_out && !count_out;
+    if (!all && !none) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_hessian: pass all four volumes or none");
+    a.real_out = real_out; a.grad_out = grad_out; a.hess_out = hess_out; a.count_out = count_out;
+    HessPoseD P;
+    for (int r = 0; r < 3; ++r) {
+        const float *p = Rv2c36 + r * 12;
+        P.R.data[r].x = dcfloat(p[0], p[1], p[2], p[3]);
+        P.R.data[r].y = dcfloat(p[4], p[5], p[6], p[7]);
+        P.R.data[r].z = dcfloat(p[8], p[9], p[10], p[11]);
+    }
+    P.t.x = dcfloat(tv2c12[0], tv2c12[1], tv2c12[2], tv2c12[3]);
+    P.t.y = dcfloat(tv2c12[4], tv2c12[5], tv2c12[6], tv2c12[7]);
+    P.t.z = dcfloat(tv2c12[8], tv2c12[9], tv2c12[10], tv2c12[11]);
+    hipLaunchKernelGGL(k_tsdf_hessian, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* float2 ComputeLocalTsdf_loss(..., const Mat33& Rv2c, const float3& tv2c, ..., gt, real, count)
+ *                                                        TsdfFusion.h:48-52, TsdfFusion.cu:412-447
+ * out2_dev: {loss, count} as doubles. */
+extern "C" int xs_compute_local_tsdf_loss(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4,
+                                          const int *res, float voxel_size, const float *Rv2c9, const float *tv2c3, float tranc_dist,
+                                          const float *gt, float *real_out, int *count_out, int z0, int z1, void *workspace,
+                                          double *out2_dev, void *stream) {
+    HessArgs a; dim3 grid;
+    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out2_dev, grid, stream);
+    if (rc) return rc;
+    if (!Rv2c9 || !tv2c3) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_loss: null pose");
+    if ((real_out == nullptr) != (count_out == nullptr)) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_loss: pass both volumes or none");
+    a.real_out = real_out; a.grad_out = nullptr; a.hess_out = nullptr; a.count_out = count_out;
+    HessPoseF P;
+    for (int i = 0; i < 9; ++i) P.R[i] = Rv2c9[i];
+    for (int i = 0; i < 3; ++i) P.t[i] = tv2c3[i];
+    hipLaunchKernelGGL(k_tsdf_loss, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
