@@ -1,0 +1,64 @@
+/* xslam_amd_pipeline.h — C ABI of the host orchestrator (libxslam_host.so): the C++ class
+ * KinectFusionReconstruction (x-slam_amd/host/, mirroring
+ * XKinectFusion/include/KinectFusionReconstruction.h:19-174) behind an opaque handle, for
+ * callers that are not C++ (bench.py, the parity tests).  Config is the reference's flat YAML
+ * (Experiments/test_xkinect_fusion/configs/ICL_traj2.yaml) passed as text, plus the optional
+ * keys csfd_seed_row / csfd_seed_col / csfd_seed_h.
+ * 4x4 complex matrices cross as 32 floats, row-major (re, im) pairs.  Errors inside the
+ * pipeline print and exit(-1), as the reference's cudaSafeCall does (Common/include/cx.h:124-130).
+ */
+#ifndef XSLAM_AMD_PIPELINE_H
+#define XSLAM_AMD_PIPELINE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t (as void*) every later call enqueues on; NULL = default stream */
+void xs_kf_set_stream(void *stream);
+/* KinectFusionReconstruction() + SetYamlParameters(config)     KinectFusionReconstruction.cpp:4-73
+ * returns NULL (and prints) on a missing key */
+void *xs_kf_create(const char *yaml_text);
+void xs_kf_destroy(void *kf);
+/* gt_poses (camera-to-world) for flag_use_gtPose: n matrices of 32 floats   .h:36, .cpp:239-247 */
+void xs_kf_set_gt_poses(void *kf, int n, const float *c2w32);
+/* ProcessFrame(const DeviceArray2D<ushort>& depth_frame_d)     .cpp:147-159
+ * depth_dev: u16 millimetres resident in device memory, row pitch step_bytes.  Returns 1, or 0
+ * when the alignment failed (frame_id is then not advanced, as in the reference). */
+int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes);
+/* the reference demo's upload + ProcessFrame (main.cpp:50-58): host buffer, dense rows */
+int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host);
+void xs_kf_synchronize(void *kf);
+
+int xs_kf_frame_id(void *kf);
+int xs_kf_num_poses(void *kf);                                   /* world2camera_record.size() */
+void xs_kf_get_world2camera(void *kf, int idx, float *out32);    /* idx < 0 counts from the back */
+float xs_kf_tranc_dist(void *kf);
+long long xs_kf_last_updated_voxels(void *kf);                   /* U of the last integrate */
+long long xs_kf_last_raycast_hits(void *kf);
+/* per ICP iteration of the last frame: 54 sums (27 x re, im) + inlier count; returns #doubles */
+int xs_kf_icp_log(void *kf, double *out, int capacity);
+
+/* dense host copies (X*Y*Z each; any pointer may be NULL)   TsdfVolume.cpp:64-77 */
+int xs_kf_download_volume(void *kf, float *value, int *weight, float *grad);
+/* which: 0 depths_curr 1 vmaps_curr 2 nmaps_curr 3 vmaps_g_prev 4 nmaps_g_prev; out: planes x
+ * rows x cols x (re, im), dense */
+int xs_kf_download_map(void *kf, int which, int level, float *out);
+/* device pointers + pitch of the live arrays: which 0 value 1 weight 2 grad */
+void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes);
+
+/* per-stage HIP-event timing: 0 surface 1 icp 2 scale 3 integrate 4 raycast 5 resize */
+void xs_kf_set_profiling(void *kf, int on);
+void xs_kf_stage_times(void *kf, double *ms6, long long *calls6);
+void xs_kf_reset_stage_times(void *kf);
+
+/* volume checkpoint (value + grad + weight + poses)   cf. saveTSDFVolume, .cpp:438-447 */
+int xs_kf_save_checkpoint(void *kf, const char *path);
+int xs_kf_load_checkpoint(void *kf, const char *path);
+int xs_kf_save_tsdf_volume(void *kf, const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

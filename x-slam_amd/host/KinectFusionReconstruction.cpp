@@ -1,0 +1,418 @@
+// KinectFusionReconstruction.cpp — per-frame pipeline on one MI355X; follows the control flow
+// of XKinectFusion/src/KinectFusionReconstruction.cpp:9-332 (cited per method) over the
+// launcher shim.  One stream, no per-frame allocation, synchronisation only where the host
+// needs a result (the 6x6 normal equations of each ICP iteration).
+#include "KinectFusionReconstruction.h"
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+using namespace xs_host;
+
+KinectFusionReconstruction::KinectFusionReconstruction() {
+    depth_width = 0;
+    depth_height = 0;
+    for (int s = 0; s < ST_COUNT; ++s) {
+        hipSafeCall(hipEventCreate(&ev_[s][0]));
+        hipSafeCall(hipEventCreate(&ev_[s][1]));
+        ev_used_[s] = false;
+    }
+}
+
+KinectFusionReconstruction::~KinectFusionReconstruction() {
+    if (tsdf_volume_d_ptr) ReleaseBuffers();
+    for (int s = 0; s < ST_COUNT; ++s) {
+        (void)hipEventDestroy(ev_[s][0]);
+        (void)hipEventDestroy(ev_[s][1]);
+    }
+}
+
+// reference :9-73
+void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
+    this->config = config_;
+    const int resolutionX = config.as<int>("tsdf_size_x");
+    const int resolutionY = config.as<int>("tsdf_size_y");
+    const int resolutionZ = config.as<int>("tsdf_size_z");
+    volume_resolution = Vector3i(resolutionX, resolutionY, resolutionZ);
+    voxel_size = config.as<float>("tsdf_voxel_size");
+    max_integration_weight = config.as<int>("max_integration_weight");
+    const float thres_range = config.as<float>("thres_range");
+
+    csfd_seed_row = config.as<int>("csfd_seed_row", -1);
+    csfd_seed_col = config.as<int>("csfd_seed_col", -1);
+    csfd_seed_h = config.as<float>("csfd_seed_h", (float)H_);
+
+    world2camera = Matrix4cf::Identity();
+    if (csfd_seed_row >= 0 && csfd_seed_row < 4 && csfd_seed_col >= 0 && csfd_seed_col < 4)
+        world2camera(csfd_seed_row, csfd_seed_col).imag(csfd_seed_h);  // the line the reference leaves commented (:22)
+    world2camera_record.clear();
+    world2camera_record.reserve(10000);
+    world2camera_record.push_back(world2camera);
+    world2volume = Matrix4cf::Identity();
+    const float init_x = config.as<float>("init_x"), init_y = config.as<float>("init_y"), init_z = config.as<float>("init_z");
+    const float r_x = config.as<float>("r_x") / 180.0f * float(M_PI);
+    const float r_y = config.as<float>("r_y") / 180.0f * float(M_PI);
+    const float r_z = config.as<float>("r_z") / 180.0f * float(M_PI);
+    // Rx * Ry * Rz as rotation matrices (the reference multiplies real AngleAxisf objects, i.e.
+    // quaternions; identical for the shipped r_x = r_y = r_z = 0)
+    const Matrix3cf rotation = (angle_axis(hostComplex(r_x, 0.f), 0) * angle_axis(hostComplex(r_y, 0.f), 1)) * angle_axis(hostComplex(r_z, 0.f), 2);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) world2volume(i, j) = hostComplex(rotation(i, j).real(), 0.f);
+    world2volume(0, 3) = hostComplex(init_x, 0.f);
+    world2volume(1, 3) = hostComplex(init_y, 0.f);
+    world2volume(2, 3) = hostComplex(init_z, 0.f);
+
+    depth_width = config.as<int>("depth_width");
+    depth_height = config.as<int>("depth_height");
+    kinect_intrinsic.fx = config.as<float>("fx");
+    kinect_intrinsic.fy = config.as<float>("fy");
+    kinect_intrinsic.cx = config.as<float>("cx");
+    kinect_intrinsic.cy = config.as<float>("cy");
+
+    num_levels = config.as<int>("num_levels");
+    if (num_levels > 3) {
+        std::cout << "sorry, the max supported multi-level = 3" << "\n";
+        num_levels = 3;
+    }
+    const int iters[] = {5, 4, 3};
+    std::copy(iters, iters + num_levels, icp_iterations);
+
+    distThres = config.as<float>("distThres");
+    angleThres = float(sin(config.as<float>("angleThres") / 180.f * M_PI));
+
+    biInterpolate_threshold = config.as<float>("biInterpolate_threshold");
+    trunc_logistic_k = config.as<float>("trunc_logistic_k", 0.f);
+
+    AllocateBuffers();
+    tsdf_volume_d_ptr = new TsdfVolume(volume_resolution, voxel_size, thres_range);
+
+    use_gtPose = config.as<bool>("flag_use_gtPose", false);
+    gt_poses.resize(0);
+    frame_id = 0;
+    frame_step = config.as<int>("frame_step", 1);
+}
+
+// reference :75-106 (the unused newTSDF_volume, jacobi and hessian buffers are not allocated)
+void KinectFusionReconstruction::AllocateBuffers() {
+    depths_curr_d.resize(num_levels);
+    vmaps_curr_d.resize(num_levels);
+    nmaps_curr_d.resize(num_levels);
+    vmaps_g_prev_d.resize(num_levels);
+    nmaps_g_prev_d.resize(num_levels);
+    for (int i = 0; i < num_levels; ++i) {
+        const int pyr_rows = depth_height >> i, pyr_cols = depth_width >> i;
+        depths_curr_d[i].create(pyr_rows, pyr_cols);
+        vmaps_curr_d[i].create(pyr_rows * 3, pyr_cols);
+        nmaps_curr_d[i].create(pyr_rows * 3, pyr_cols);
+        vmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
+        nmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
+    }
+    depthRawScaled_d.create(depth_height, depth_width);
+    counters_.create(2);
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), current_stream()));
+}
+
+// reference :108-123
+void KinectFusionReconstruction::ReleaseBuffers() {
+    for (int i = 0; i < (int)depths_curr_d.size(); ++i) {
+        depths_curr_d[i].release();
+        vmaps_curr_d[i].release();
+        nmaps_curr_d[i].release();
+        vmaps_g_prev_d[i].release();
+        nmaps_g_prev_d[i].release();
+    }
+    g_buf.release();
+    sum_buf.release();
+    depthRawScaled_d.release();
+    delete tsdf_volume_d_ptr;
+    tsdf_volume_d_ptr = nullptr;
+}
+
+// reference :125-145
+int KinectFusionReconstruction::SmoothDepthFrame(MapArr &dst_d, const DeviceArray2D<ushort> &src_d) {
+    if (src_d.rows() <= 0 || src_d.cols() <= 0) {
+        std::cout << "error: KinectFusionReconstruction::SmoothDepthFrame, input map is empty" << std::endl;
+        return 0;
+    }
+    if (dst_d.rows() != src_d.rows() || dst_d.cols() != src_d.cols()) {
+        dst_d.release();
+        dst_d.create(src_d.rows(), src_d.cols());
+    }
+    bilateralFilter(src_d, dst_d);
+    return 1;
+}
+
+// reference :147-159.  On a failed alignment the reference returns without advancing frame_id,
+// and its demo retries the same frame forever; the status is returned
+// the same way here and the caller decides.
+int KinectFusionReconstruction::ProcessFrame(const DeviceArray2D<ushort> &depth_frame_d) {
+    const int align_return = AlignDepthToReconstruction(depth_frame_d, false);
+    if (frame_id > 0 && !align_return) {
+        std::cout << "Frame align failed!" << std::endl;
+        return 0;
+    }
+    IntegrateFrame(depth_frame_d);
+    frame_id += frame_step;
+    if (profiling) collect_stage_times();
+    return 1;
+}
+
+// reference :161-175
+int KinectFusionReconstruction::AlignDepthToReconstruction(const DeviceArray2D<ushort> &depth_frame_d, bool /*use_LM*/) {
+    SurfaceMeasure(depth_frame_d);
+    if (use_gtPose) return 1;
+    Matrix4cf c2w_prev = inverse(world2camera_record.back());
+    Matrix3frm Rprev = GetRotation(c2w_prev);
+    Vector3cf tprev = GetTranslation(c2w_prev);
+    Matrix3frm Rprev_inv = inverse(Rprev);
+    Matrix3frm Rcurr = Rprev;
+    Vector3cf tcurr = tprev;
+    return PoseEstimate(Rcurr, tcurr, Rprev_inv, tprev);
+}
+
+// reference :177-235
+int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, Matrix3frm Rprev_inv, Vector3cf tprev) {
+    icp_log.clear();
+    if (frame_id == 0) return 0;
+    Matrix4cf c2w_prev = inverse(world2camera_record.back());
+    Matrix4cf c2w_curr = c2w_prev;
+    auto &device_Rprev_inv = device_cast<MatS33>(Rprev_inv);
+    auto &device_tprev = device_cast<devComplex3>(tprev);
+    stage_begin(ST_ICP);
+    for (int level_index = num_levels - 1; level_index >= 0; --level_index) {
+        MapArr &vmap_curr = vmaps_curr_d[level_index];
+        MapArr &nmap_curr = nmaps_curr_d[level_index];
+        MapArr &vmap_g_prev = vmaps_g_prev_d[level_index];
+        MapArr &nmap_g_prev = nmaps_g_prev_d[level_index];
+        const int iter_num = icp_iterations[level_index];
+        for (int iter = 0; iter < iter_num; ++iter) {
+            auto &device_Rcurr = device_cast<MatS33>(Rcurr);
+            auto &device_tcurr = device_cast<devComplex3>(tcurr);
+            hostComplexICP A[36], b[6];
+            long long inliers = 0;
+            estimateCombined(device_Rcurr, device_tcurr, vmap_curr, nmap_curr, device_Rprev_inv, device_tprev, kinect_intrinsic(level_index),
+                             vmap_g_prev, nmap_g_prev, distThres, angleThres, g_buf, sum_buf, A, b, &inliers);
+            {   // diagnostics: re-pack the 27 sums in launch order
+                int shift = 0;
+                for (int i = 0; i < 6; ++i)
+                    for (int j = i; j < 7; ++j, ++shift) {
+                        const hostComplexICP v = (j == 6) ? b[i] : A[i * 6 + j];
+                        icp_log.push_back(v.real());
+                        icp_log.push_back(v.imag());
+                    }
+                icp_log.push_back((double)inliers);
+            }
+            const double det = real_determinant6(A);
+            if (fabs(det) < 1e-15 || std::isnan(det)) {
+                if (std::isnan(det)) std::cout << "qnan det" << std::endl;
+                else std::cout << "eps det: " << fabs(det) << std::endl;
+                stage_end(ST_ICP);
+                return 0;
+            }
+            hostComplexICP sol[6];
+            llt_solve6(A, b, sol);
+            hostComplex result[6];
+            for (int i = 0; i < 6; ++i) result[i] = hostComplex((float)sol[i].real(), (float)sol[i].imag());
+            const hostComplex alpha = result[0], beta = result[1], gamma = result[2];
+            const Matrix3cf Rinc = (angle_axis(gamma, 2) * angle_axis(beta, 1)) * angle_axis(alpha, 0);
+            Vector3cf tinc; tinc[0] = result[3]; tinc[1] = result[4]; tinc[2] = result[5];
+            Vector3cf rt = Rinc * tcurr;
+            for (int i = 0; i < 3; ++i) tcurr[i] = rt[i] + tinc[i];
+            Rcurr = Rinc * Rcurr;
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) c2w_curr(i, j) = Rcurr(i, j);
+                c2w_curr(i, 3) = tcurr[i];
+            }
+            c2w_curr(3, 3) = hostComplex(1.f, 0.f);
+        }
+    }
+    stage_end(ST_ICP);
+    world2camera = inverse(c2w_curr);
+    world2camera_record.push_back(world2camera);
+    return 1;
+}
+
+// reference :237-278
+int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d) {
+    if (use_gtPose) {
+        Matrix4cf c2w = gt_poses[frame_id];
+        world2camera = inverse(c2w);
+        world2camera_record.back() = world2camera;
+    }
+    Matrix4cf c2w = inverse(world2camera_record.back());
+    Matrix4cf c2v = world2volume * c2w;
+    Matrix4cf v2c = inverse(c2v);
+    Vector3cf tc2v = GetTranslation(c2v);
+    auto &device_tc2v = device_cast<devComplex3>(tc2v);
+    Matrix3frm Rv2c = GetRotation(v2c);
+    auto &device_Rv2c = device_cast<MatS33>(Rv2c);
+    Vector3cf tv2c = GetTranslation(v2c);
+    auto &device_tv2c = device_cast<devComplex3>(tv2c);
+    (void)device_tc2v;
+
+    int3 volume_res;
+    volume_res.x = volume_resolution.x();
+    volume_res.y = volume_resolution.y();
+    volume_res.z = volume_resolution.z();
+    hipStream_t st = current_stream();
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), st));
+    // integrateTsdfVolume (TsdfFusion.cu:173-201), its two launches timed separately
+    const int res[3] = {volume_res.x, volume_res.y, volume_res.z};
+    DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
+    DeviceArray2D<int> weight = tsdf_volume_d_ptr->weight();
+    stage_begin(ST_SCALE);
+    check_rc(xs_scale_depth(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                            depthRawScaled_d.step(), st), "scaleDepth");
+    stage_end(ST_SCALE);
+    stage_begin(ST_INTEGRATE);
+    check_rc(xs_integrate_scaled(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
+                                 &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re, &device_tv2c.x.re,
+                                 tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(), weight.ptr(), grad.ptr(), value.step(),
+                                 biInterpolate_threshold, 0, res[2], counters_.ptr(), st), "integrateTsdfVolume");
+    stage_end(ST_INTEGRATE);
+
+    stage_begin(ST_RAYCAST);
+    CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
+    stage_end(ST_RAYCAST);
+    stage_begin(ST_RESIZE);
+    for (int i = 1; i < num_levels; ++i) {
+        resizeVMap(vmaps_g_prev_d[i - 1], vmaps_g_prev_d[i], false);
+        resizeNMap(nmaps_g_prev_d[i - 1], nmaps_g_prev_d[i], false);
+    }
+    stage_end(ST_RESIZE);
+    return 1;
+}
+
+// reference :280-299
+void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &depth_frame_d) {
+    if (depth_width <= 0 || depth_height <= 0) {
+        std::cout << "error::KinectFusionReconstruction, not created yet" << std::endl;
+        return;
+    }
+    stage_begin(ST_SURFACE);
+    SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
+    for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
+    for (int i = 0; i < num_levels; ++i) {
+        createVMap(kinect_intrinsic(i), depths_curr_d[i], vmaps_curr_d[i]);  // camera frame, +z forward
+        createNMap(vmaps_curr_d[i], nmaps_curr_d[i]);
+    }
+    stage_end(ST_SURFACE);
+}
+
+// reference :302-332
+int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &normal_g_d) {
+    Matrix4cf c2w = inverse(world2camera);
+    Matrix4cf c2v = world2volume * c2w;
+    Matrix4cf v2w = inverse(world2volume);
+    Matrix3frm Rc2v = GetRotation(c2v);
+    Vector3cf tc2v = GetTranslation(c2v);
+    Matrix3frm Rv2w = GetRotation(v2w);
+    Vector3cf tv2w = GetTranslation(v2w);
+    auto &device_Rc2v = device_cast<MatS33>(Rc2v);
+    auto &device_tc2v = device_cast<devComplex3>(tc2v);
+    auto &device_Rv2w = device_cast<MatS33>(Rv2w);
+    auto &device_tv2w = device_cast<devComplex3>(tv2w);
+    int3 volume_res;
+    volume_res.x = volume_resolution.x();
+    volume_res.y = volume_resolution.y();
+    volume_res.z = volume_resolution.z();
+    raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
+            voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1);
+    return 0;
+}
+
+void KinectFusionReconstruction::synchronize() { hipSafeCall(hipStreamSynchronize(current_stream())); }
+
+long long KinectFusionReconstruction::lastUpdatedVoxels() {
+    unsigned long long h[2];
+    counters_.download(h);
+    return (long long)h[0];
+}
+long long KinectFusionReconstruction::lastRaycastHits() {
+    unsigned long long h[2];
+    counters_.download(h);
+    return (long long)h[1];
+}
+
+// ---- volume checkpoint --------------------------------------------------------------------
+// reference :438-447 writes raw float32 values; here X*Y*Z of them (the reference's count uses
+// res[2] twice)
+void KinectFusionReconstruction::saveTSDFVolume(const std::string &tsdf_filename) {
+    std::vector<float> tsdf;
+    tsdf_volume_d_ptr->downloadTSDFWithoutGrad(tsdf);
+    std::ofstream f(tsdf_filename, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(tsdf.data()), (std::streamsize)(tsdf.size() * sizeof(float)));
+}
+namespace {
+struct CkptHeader { char magic[8]; int res[3]; float voxel_size, tranc_dist; int frame_id; int n_poses; };
+}
+void KinectFusionReconstruction::saveCheckpoint(const std::string &filename) {
+    std::vector<float> v, g;
+    std::vector<int> w;
+    tsdf_volume_d_ptr->downloadTSDFWithGrad(v, g);
+    tsdf_volume_d_ptr->downloadWeight(w);
+    CkptHeader h{};
+    std::snprintf(h.magic, sizeof(h.magic), "XSTSDF1");
+    for (int i = 0; i < 3; ++i) h.res[i] = volume_resolution[i];
+    h.voxel_size = voxel_size; h.tranc_dist = tsdf_volume_d_ptr->getTsdfTruncDist(); h.frame_id = frame_id;
+    h.n_poses = (int)world2camera_record.size();
+    std::ofstream f(filename, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(&h), sizeof(h));
+    f.write(reinterpret_cast<const char *>(world2camera_record.data()), (std::streamsize)(h.n_poses * sizeof(Matrix4cf)));
+    f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * 4));
+    f.write(reinterpret_cast<const char *>(g.data()), (std::streamsize)(g.size() * 4));
+    f.write(reinterpret_cast<const char *>(w.data()), (std::streamsize)(w.size() * 4));
+}
+bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) return false;
+    CkptHeader h{};
+    f.read(reinterpret_cast<char *>(&h), sizeof(h));
+    if (std::string(h.magic) != "XSTSDF1") return false;
+    for (int i = 0; i < 3; ++i) if (h.res[i] != volume_resolution[i]) return false;
+    world2camera_record.resize(h.n_poses);
+    f.read(reinterpret_cast<char *>(world2camera_record.data()), (std::streamsize)(h.n_poses * sizeof(Matrix4cf)));
+    world2camera = world2camera_record.back();
+    frame_id = h.frame_id;
+    const size_t n = (size_t)h.res[0] * h.res[1] * h.res[2];
+    std::vector<float> v(n), g(n);
+    std::vector<int> w(n);
+    f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * 4));
+    f.read(reinterpret_cast<char *>(g.data()), (std::streamsize)(n * 4));
+    f.read(reinterpret_cast<char *>(w.data()), (std::streamsize)(n * 4));
+    if (!f) return false;
+    const int X = h.res[0], rows = h.res[1] * h.res[2];
+    tsdf_volume_d_ptr->value().upload(v.data(), X * 4, rows, X);
+    tsdf_volume_d_ptr->grad().upload(g.data(), X * 4, rows, X);
+    tsdf_volume_d_ptr->weight().upload(w.data(), X * 4, rows, X);
+    // previous-frame maps are derived state: regenerate them from the restored volume and pose
+    CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
+    for (int i = 1; i < num_levels; ++i) {
+        resizeVMap(vmaps_g_prev_d[i - 1], vmaps_g_prev_d[i], false);
+        resizeNMap(nmaps_g_prev_d[i - 1], nmaps_g_prev_d[i], false);
+    }
+    synchronize();
+    return true;
+}
+
+// ---- per-stage HIP event timing (on the stream the kernels are launched on) -----------------
+void KinectFusionReconstruction::stage_begin(int st) {
+    if (!profiling) return;
+    hipSafeCall(hipEventRecord(ev_[st][0], current_stream()));
+}
+void KinectFusionReconstruction::stage_end(int st) {
+    if (!profiling) return;
+    hipSafeCall(hipEventRecord(ev_[st][1], current_stream()));
+    ev_used_[st] = true;
+}
+void KinectFusionReconstruction::collect_stage_times() {
+    synchronize();
+    for (int s = 0; s < ST_COUNT; ++s) {
+        if (!ev_used_[s]) continue;
+        float ms = 0.f;
+        hipSafeCall(hipEventElapsedTime(&ms, ev_[s][0], ev_[s][1]));
+        stage_ms[s] += ms;
+        stage_calls[s] += 1;
+        ev_used_[s] = false;
+    }
+}

@@ -1,0 +1,106 @@
+// KinectFusionReconstruction.h — host orchestrator of the XKinectFusion CSFD pipeline on one
+// MI355X.  Same class name, public fields and method names as the reference
+// (XKinectFusion/include/KinectFusionReconstruction.h:19-174), so a caller of the reference's
+// class (Experiments/test_xkinect_fusion/main.cpp:38-58) drives this one the same way:
+//     KinectFusionReconstruction kinfu;  kinfu.SetYamlParameters(config);
+//     kinfu.ProcessFrame(depth_frame_d);  kinfu.world2camera_record.back();
+// Host algebra comes from host_algebra.hpp (no Eigen), config from flat_yaml.hpp (no yaml-cpp).
+//
+// Additions: the CSFD seed is a parameter (keys csfd_seed_row / csfd_seed_col / csfd_seed_h; the
+// reference has the seed line commented out, KinectFusionReconstruction.cpp:22); per-stage HIP
+// event timing; counters of updated voxels and raycast hits; volume checkpoint save / load.
+#pragma once
+#include "TsdfVolume.h"
+#include "flat_yaml.hpp"
+#include <string>
+#include <vector>
+
+class KinectFusionReconstruction {
+public:
+    typedef xs_host::Matrix3cf Matrix3frm;  // row-major complex 3x3
+    typedef xs_host::Matrix4cf Matrix4cf;
+    typedef xs_host::Vector3cf Vector3cf;
+    enum Stage { ST_SURFACE = 0, ST_ICP, ST_SCALE, ST_INTEGRATE, ST_RAYCAST, ST_RESIZE, ST_COUNT };
+
+    xs_host::FlatYaml config;
+    int num_levels = 3;
+    Matrix4cf world2camera;
+    Matrix4cf world2volume;
+    std::vector<Matrix4cf> world2camera_record;
+    int frame_id = 0;
+    int frame_step = 1;
+    std::vector<Matrix4cf> gt_poses{};  // camera-to-world; complex so a CSFD seed can ride on a given pose
+
+    Intr kinect_intrinsic;
+    int depth_width = 0, depth_height = 0;
+
+    Vector3i volume_resolution;
+    float voxel_size{};
+    TsdfVolume *tsdf_volume_d_ptr = nullptr;
+    int max_integration_weight = 0;
+
+    int icp_iterations[3]{};
+    float distThres{};
+    float angleThres{};
+    DeviceArray2D<devComplexICP> g_buf;  // kept for signature compatibility; unused by the fused reduction
+    DeviceArray<devComplexICP> sum_buf;
+
+    float trunc_logistic_k = 0.f;
+    float biInterpolate_threshold{0.005f};
+
+    std::vector<DeviceArray2D<devComplex>> depths_curr_d, vmaps_curr_d, nmaps_curr_d, vmaps_g_prev_d, nmaps_g_prev_d;
+    DeviceArray2D<float> depthRawScaled_d;
+
+    bool use_gtPose = false;
+
+    // CSFD seed: i*h on world2camera(row, col); row < 0 disables
+    int csfd_seed_row = -1, csfd_seed_col = -1;
+    float csfd_seed_h = 1e-7f;
+
+    // instrumentation
+    bool profiling = false;
+    double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    long long stage_calls[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> icp_log;  // per ICP iteration of the last frame: 54 sums + inliers
+
+    KinectFusionReconstruction();
+    ~KinectFusionReconstruction();
+
+    int getFrame() const { return frame_id; }
+    int getVolumeSize() const { return volume_resolution[0] * volume_resolution[1] * volume_resolution[2]; }
+    Matrix4cf getCamera2Volume() { return world2volume * xs_host::inverse(world2camera); }
+
+    void AllocateBuffers();
+    void ReleaseBuffers();
+    void SetYamlParameters(const xs_host::FlatYaml &config_);
+    int ProcessFrame(const DeviceArray2D<ushort> &depth_frame_d);
+    void SurfaceMeasure(const DeviceArray2D<ushort> &depth_frame_d);
+    int PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, Matrix3frm Rprev_inv, Vector3cf tprev);
+    int AlignDepthToReconstruction(const DeviceArray2D<ushort> &depth_frame_d, bool use_LM = false);
+    int IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d);
+    static int SmoothDepthFrame(MapArr &dst_d, const DeviceArray2D<ushort> &src_d);
+    int CalculatePointCloud(MapArr &xyz_g_d, MapArr &normal_g_d);
+
+    static inline Vector3cf GetTranslation(Matrix4cf &trans_mat) { return xs_host::GetTranslation(trans_mat); }
+    static inline Matrix3frm GetRotation(Matrix4cf &trans_mat) { return xs_host::GetRotation(trans_mat); }
+
+    // volume checkpoint: raw float32 value (+ grad, + int32 weight), X*Y*Z each, dense
+    // (the reference's saveTSDFVolume writes value only and res[0]*res[2]*res[2] floats,
+    // KinectFusionReconstruction.cpp:438-447)
+    void saveTSDFVolume(const std::string &tsdf_filename);
+    void saveCheckpoint(const std::string &filename);
+    bool loadCheckpoint(const std::string &filename);
+
+    // counters of the last frame (synchronise the stream)
+    long long lastUpdatedVoxels();
+    long long lastRaycastHits();
+    void synchronize();
+
+private:
+    DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits
+    hipEvent_t ev_[ST_COUNT + 1][2];
+    bool ev_used_[ST_COUNT];
+    void stage_begin(int st);
+    void stage_end(int st);
+    void collect_stage_times();
+};

@@ -1,0 +1,107 @@
+// xs_pipeline_capi.cpp — C ABI over KinectFusionReconstruction (include/xslam_amd_pipeline.h).
+#include "../../include/xslam_amd_pipeline.h"
+#include "KinectFusionReconstruction.h"
+#include <cstring>
+#include <exception>
+
+typedef KinectFusionReconstruction KF;
+using xs_host::Matrix4cf;
+
+extern "C" {
+
+void xs_kf_set_stream(void *stream) { xs_host::current_stream() = (hipStream_t)stream; }
+
+void *xs_kf_create(const char *yaml_text) {
+    try {
+        KF *k = new KF();
+        k->SetYamlParameters(xs_host::FlatYaml::Load(yaml_text ? yaml_text : ""));
+        return k;
+    } catch (const std::exception &e) {
+        printf("xs_kf_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void xs_kf_destroy(void *kf) { delete (KF *)kf; }
+
+void xs_kf_set_gt_poses(void *kf, int n, const float *c2w32) {
+    KF *k = (KF *)kf;
+    k->gt_poses.resize(n);
+    for (int i = 0; i < n; ++i) std::memcpy(&k->gt_poses[i], c2w32 + 32 * i, 32 * sizeof(float));
+}
+
+int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) {
+    KF *k = (KF *)kf;
+    DeviceArray2D<ushort> view(k->depth_height, k->depth_width, (void *)depth_dev, step_bytes);  // borrowed, not counted
+    return k->ProcessFrame(view);
+}
+int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host) {
+    KF *k = (KF *)kf;
+    static thread_local DeviceArray2D<ushort> frame;
+    frame.upload(depth_host, k->depth_width * sizeof(ushort), k->depth_height, k->depth_width);
+    return k->ProcessFrame(frame);
+}
+void xs_kf_synchronize(void *kf) { ((KF *)kf)->synchronize(); }
+
+int xs_kf_frame_id(void *kf) { return ((KF *)kf)->frame_id; }
+int xs_kf_num_poses(void *kf) { return (int)((KF *)kf)->world2camera_record.size(); }
+void xs_kf_get_world2camera(void *kf, int idx, float *out32) {
+    KF *k = (KF *)kf;
+    if (idx < 0) idx += (int)k->world2camera_record.size();
+    std::memcpy(out32, &k->world2camera_record[idx], 32 * sizeof(float));
+}
+float xs_kf_tranc_dist(void *kf) { return ((KF *)kf)->tsdf_volume_d_ptr->getTsdfTruncDist(); }
+long long xs_kf_last_updated_voxels(void *kf) { return ((KF *)kf)->lastUpdatedVoxels(); }
+long long xs_kf_last_raycast_hits(void *kf) { return ((KF *)kf)->lastRaycastHits(); }
+int xs_kf_icp_log(void *kf, double *out, int capacity) {
+    KF *k = (KF *)kf;
+    const int n = (int)k->icp_log.size();
+    if (out && capacity >= n && n) std::memcpy(out, k->icp_log.data(), n * sizeof(double));
+    return n;
+}
+
+int xs_kf_download_volume(void *kf, float *value, int *weight, float *grad) {
+    KF *k = (KF *)kf;
+    const int X = k->volume_resolution[0];
+    if (value) k->tsdf_volume_d_ptr->value().download(value, X * sizeof(float));
+    if (weight) k->tsdf_volume_d_ptr->weight().download(weight, X * sizeof(int));
+    if (grad) k->tsdf_volume_d_ptr->grad().download(grad, X * sizeof(float));
+    return 0;
+}
+int xs_kf_download_map(void *kf, int which, int level, float *out) {
+    KF *k = (KF *)kf;
+    if (level < 0 || level >= k->num_levels) return -1;
+    MapArr *m = nullptr;
+    switch (which) {
+        case 0: m = &k->depths_curr_d[level]; break;
+        case 1: m = &k->vmaps_curr_d[level]; break;
+        case 2: m = &k->nmaps_curr_d[level]; break;
+        case 3: m = &k->vmaps_g_prev_d[level]; break;
+        case 4: m = &k->nmaps_g_prev_d[level]; break;
+        default: return -1;
+    }
+    m->download(out, m->cols() * sizeof(devComplex));
+    return 0;
+}
+void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes) {
+    KF *k = (KF *)kf;
+    if (which == 1) { auto a = k->tsdf_volume_d_ptr->weight(); if (step_bytes) *step_bytes = a.step(); return a.ptr(); }
+    auto a = which == 0 ? k->tsdf_volume_d_ptr->value() : k->tsdf_volume_d_ptr->grad();
+    if (step_bytes) *step_bytes = a.step();
+    return a.ptr();
+}
+
+void xs_kf_set_profiling(void *kf, int on) { ((KF *)kf)->profiling = on != 0; }
+void xs_kf_stage_times(void *kf, double *ms6, long long *calls6) {
+    KF *k = (KF *)kf;
+    for (int i = 0; i < KF::ST_COUNT; ++i) { if (ms6) ms6[i] = k->stage_ms[i]; if (calls6) calls6[i] = k->stage_calls[i]; }
+}
+void xs_kf_reset_stage_times(void *kf) {
+    KF *k = (KF *)kf;
+    for (int i = 0; i < KF::ST_COUNT; ++i) { k->stage_ms[i] = 0; k->stage_calls[i] = 0; }
+}
+
+int xs_kf_save_checkpoint(void *kf, const char *path) { ((KF *)kf)->saveCheckpoint(path); return 0; }
+int xs_kf_load_checkpoint(void *kf, const char *path) { return ((KF *)kf)->loadCheckpoint(path) ? 0 : -1; }
+int xs_kf_save_tsdf_volume(void *kf, const char *path) { ((KF *)kf)->saveTSDFVolume(path); return 0; }
+
+}  // extern "C"

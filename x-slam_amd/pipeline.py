@@ -1,0 +1,176 @@
+"""ctypes binding of the host orchestrator's C ABI (include/xslam_amd_pipeline.h,
+libxslam_host.so built from x-slam_amd/host/).  The orchestrator itself is C++
+(KinectFusionReconstruction, mirroring the reference class); this module only lets Python
+callers — bench.py and the parity tests — drive it.  No CPU fallback: a missing library is an
+ImportError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi  # loads libxslam_hip.so first (libxslam_host.so links against it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxslam_host.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: run __graft_entry__.build() (make -C x-slam_amd/host). There is no CPU fallback.")
+_lib = C.CDLL(LIB_PATH)
+
+_vp, _sz = C.c_void_p, C.c_size_t
+_f32p, _f64p, _i32p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+_SIGS = {
+    "xs_kf_set_stream": (None, [_vp]),
+    "xs_kf_create": (_vp, [C.c_char_p]),
+    "xs_kf_destroy": (None, [_vp]),
+    "xs_kf_set_gt_poses": (None, [_vp, C.c_int, _f32p]),
+    "xs_kf_process_frame": (C.c_int, [_vp, _vp, _sz]),
+    "xs_kf_process_frame_host": (C.c_int, [_vp, _vp]),
+    "xs_kf_synchronize": (None, [_vp]),
+    "xs_kf_frame_id": (C.c_int, [_vp]),
+    "xs_kf_num_poses": (C.c_int, [_vp]),
+    "xs_kf_get_world2camera": (None, [_vp, C.c_int, _f32p]),
+    "xs_kf_tranc_dist": (C.c_float, [_vp]),
+    "xs_kf_last_updated_voxels": (C.c_longlong, [_vp]),
+    "xs_kf_last_raycast_hits": (C.c_longlong, [_vp]),
+    "xs_kf_icp_log": (C.c_int, [_vp, _f64p, C.c_int]),
+    "xs_kf_download_volume": (C.c_int, [_vp, _f32p, _i32p, _f32p]),
+    "xs_kf_download_map": (C.c_int, [_vp, C.c_int, C.c_int, _f32p]),
+    "xs_kf_volume_ptr": (_vp, [_vp, C.c_int, C.POINTER(_sz)]),
+    "xs_kf_set_profiling": (None, [_vp, C.c_int]),
+    "xs_kf_stage_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
+    "xs_kf_reset_stage_times": (None, [_vp]),
+    "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
+    "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
+    "xs_kf_save_tsdf_volume": (C.c_int, [_vp, C.c_char_p]),
+}
+for _n, (_r, _a) in _SIGS.items():
+    _f = getattr(_lib, _n)
+    _f.restype, _f.argtypes = _r, _a
+
+STAGES = ("surface", "icp", "scale", "integrate", "raycast", "resize")
+MAPS = {"depths_curr": 0, "vmaps_curr": 1, "nmaps_curr": 2, "vmaps_g_prev": 3, "nmaps_g_prev": 4}
+
+
+def yaml_text(params: dict) -> str:
+    """Flat YAML in the reference's format (ICL_traj2.yaml) from a dict of its keys."""
+    out = []
+    for k, v in params.items():
+        if isinstance(v, bool):
+            v = "true" if v else "false"
+        elif isinstance(v, float):
+            v = repr(float(np.float32(v))) if abs(v) < 1e-3 and v != 0 else repr(v)
+        out.append(f"{k}: {v}")
+    return "\n".join(out) + "\n"
+
+
+def set_stream(stream):
+    _lib.xs_kf_set_stream(None if stream is None else (stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)))
+
+
+class KinectFusion:
+    """Handle to a C++ KinectFusionReconstruction."""
+
+    def __init__(self, params, gt_poses=None):
+        text = params if isinstance(params, str) else yaml_text(params)
+        self.cfg = {}
+        for line in text.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                self.cfg[k.strip()] = v.split("#")[0].strip()
+        self.h = _lib.xs_kf_create(text.encode())
+        if not self.h:
+            raise ValueError("xs_kf_create failed (missing config key?)")
+        self.res = [int(self.cfg[f"tsdf_size_{a}"]) for a in "xyz"]
+        self.width, self.height = int(self.cfg["depth_width"]), int(self.cfg["depth_height"])
+        if gt_poses is not None:
+            g = np.ascontiguousarray(gt_poses, dtype=np.float32).reshape(-1, 32)
+            _lib.xs_kf_set_gt_poses(self.h, g.shape[0], g.ctypes.data_as(_f32p))
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.xs_kf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process_frame(self, depth_dev, step_bytes=None):
+        """depth_dev: torch int16/uint16 CUDA tensor [H, W] (u16 millimetres) or a raw device address."""
+        ptr = depth_dev if isinstance(depth_dev, int) else depth_dev.data_ptr()
+        step = step_bytes if step_bytes is not None else self.width * 2
+        return _lib.xs_kf_process_frame(self.h, ptr, step)
+
+    def process_frame_host(self, depth_u16):
+        d = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        return _lib.xs_kf_process_frame_host(self.h, d.ctypes.data)
+
+    def synchronize(self):
+        _lib.xs_kf_synchronize(self.h)
+
+    @property
+    def frame_id(self):
+        return _lib.xs_kf_frame_id(self.h)
+
+    def num_poses(self):
+        return _lib.xs_kf_num_poses(self.h)
+
+    def world2camera(self, idx=-1):
+        out = np.zeros(32, np.float32)
+        _lib.xs_kf_get_world2camera(self.h, idx, out.ctypes.data_as(_f32p))
+        return out.reshape(4, 4, 2)
+
+    def tranc_dist(self):
+        return _lib.xs_kf_tranc_dist(self.h)
+
+    def last_U(self):
+        return _lib.xs_kf_last_updated_voxels(self.h)
+
+    def last_hits(self):
+        return _lib.xs_kf_last_raycast_hits(self.h)
+
+    def icp_log(self):
+        n = _lib.xs_kf_icp_log(self.h, None, 0)
+        out = np.zeros(n, np.float64)
+        if n:
+            _lib.xs_kf_icp_log(self.h, out.ctypes.data_as(_f64p), n)
+        return out.reshape(-1, 55)
+
+    def volume(self):
+        n = self.res[0] * self.res[1] * self.res[2]
+        v, w, g = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        _lib.xs_kf_download_volume(self.h, v.ctypes.data_as(_f32p), w.ctypes.data_as(_i32p), g.ctypes.data_as(_f32p))
+        return v, w, g
+
+    def map(self, which, level):
+        rows, cols = self.height >> level, self.width >> level
+        planes = 1 if which == "depths_curr" else 3
+        out = np.zeros((planes * rows, cols, 2), np.float32)
+        rc = _lib.xs_kf_download_map(self.h, MAPS[which], level, out.ctypes.data_as(_f32p))
+        assert rc == 0
+        return out
+
+    def volume_ptr(self, which):
+        step = _sz(0)
+        p = _lib.xs_kf_volume_ptr(self.h, {"value": 0, "weight": 1, "grad": 2}[which], C.byref(step))
+        return p, step.value
+
+    def set_profiling(self, on=True):
+        _lib.xs_kf_set_profiling(self.h, 1 if on else 0)
+
+    def stage_times(self):
+        ms = np.zeros(6, np.float64)
+        calls = (C.c_longlong * 6)()
+        _lib.xs_kf_stage_times(self.h, ms.ctypes.data_as(_f64p), calls)
+        return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(STAGES)}
+
+    def reset_stage_times(self):
+        _lib.xs_kf_reset_stage_times(self.h)
+
+    def save_checkpoint(self, path):
+        _lib.xs_kf_save_checkpoint(self.h, path.encode())
+
+    def load_checkpoint(self, path):
+        return _lib.xs_kf_load_checkpoint(self.h, path.encode()) == 0
+
+    def save_tsdf_volume(self, path):
+        _lib.xs_kf_save_tsdf_volume(self.h, path.encode())
