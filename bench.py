@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of first-order-CSFD XKinectFusion (BASELINE.json metric) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512]
+
+A step = ProcessFrame of one synthetic 640x480 depth frame (scene S1)
+into the TSDF volume: surface measure -> 12 ICP iterations -> integrate -> raycast -> map
+pyramid, all in complex float with the CSFD seed i*1e-7 on world2camera(0,3).  Depth frames
+are resident in HBM before the timed region.  One JSON line on rank 0 with the contract's
+fields plus
+  roofline     : the TSDF-integrate kernel — algorithmic bytes 24*U + 2*W*H per launch (U = voxels
+                 written, counted by the kernel) / its mean duration from HIP events recorded on
+                 the launch stream inside the timed region; peak = 8 TB/s HBM3E
+  cpu_baseline : the CPU oracle (oracle/, a port — not the product path) timed on this host's
+                 cores on a bounded sample of the same workload
+  stages_ms, integrate_s2 : extra context (per-stage mean ms; the frustum-filling scene S2 on
+                 which integrate is HBM-bound)
+N > 1 (launched by torch.distributed.run, one rank per GPU): the volume is sharded by z-slab,
+ICP rows by rank, and the 6x6 / 6x1 normal equations are all-reduced over RCCL (see
+x-slam_amd/sharded.py); max-over-ranks timing, "scaling": "strong" (one frame stream, fixed
+total work).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+W, H = 640, 480
+
+
+def cpu_baseline(synth, size, budget_s=20.0):
+    """Oracle pipeline (CPU restatement, OpenMP over all host cores) on the first frames of the
+    same stream.  Reported beside the GPU number; not a target."""
+    from oracle import oracle as orc
+    orc.build(ref=False)
+    o = orc.Oracle()
+    kf = orc.OracleKinFu(o, orc.params_from_dict(synth.s1_params(size)))
+    frames, t_used, k = 0, 0.0, 0
+    kf.process_frame(synth.s1_frame(0))  # frame 0 has no ICP: not timed
+    while t_used < budget_s and k < 30:
+        k += 1
+        d = synth.s1_frame(k)
+        t0 = time.perf_counter()
+        ok = kf.process_frame(d)
+        t_used += time.perf_counter() - t0
+        frames += 1
+        if not ok:
+            break
+    cores = o._num_threads()
+    kf.close()
+    return {"value": round(frames / t_used, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle pipeline, scene S1 {size}^3, frames 1..{frames} ({t_used:.1f} s), OpenMP x{cores}"}
+
+
+def integrate_s2_probe(torch, capi, synth, size=512, reps=20):
+    """Scene S2 (frustum-filling placement): the configuration on which integrate is
+    HBM-bound.  Times the integrate kernel alone with HIP events."""
+    prm = synth.s2_params(size)
+    n = size
+    res = [n, n, n]
+    vs = np.float32(prm["tsdf_voxel_size"])
+    trunc = float(max(np.float32(vs * np.float32(3.0)), np.float32(np.float32(2.1) * vs)))
+    value = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+    weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+    grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+    capi.init_volume(value, weight, grad, n * 4, res)
+    depth = torch.from_numpy(synth.render_s2().view(np.int16)).cuda()
+    scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    capi.scale_depth(depth, W * 2, H, W, scaled, W * 4)
+    # v2c for c2v = translate(2.56, 2.56, 0.05): identity rotation, seed on t_x
+    R = np.zeros((3, 3, 2), np.float32)
+    R[[0, 1, 2], [0, 1, 2], 0] = 1
+    t = np.zeros((3, 2), np.float32)
+    t[:, 0] = [-prm["init_x"], -prm["init_y"], -prm["init_z"]]
+    t[0, 1] = 1e-7
+    intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream()
+    args = (scaled, W * 4, H, W, intr, 100, res, float(vs), R, t, trunc, value, weight, grad, n * 4)
+    capi.integrate_scaled(*args, updated=counter, stream=s)
+    torch.cuda.synchronize()
+    U = int(counter.item())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(reps):
+        capi.integrate_scaled(*args, stream=s)
+    e1.record(s)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 24.0 * U + 2.0 * W * H
+    return {"scene": f"S2 {size}^3", "U": U, "U_frac": round(U / n ** 3, 4), "ms": round(ms, 4),
+            "achieved_GBs": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-s2", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    synth = importlib.import_module("x-slam_amd.synth")
+    capi = importlib.import_module("x-slam_amd.capi")
+    pl = importlib.import_module("x-slam_amd.pipeline")
+
+    K, Wm, N = a.steps, a.warmup, a.size
+    T = 300
+    nframes = K + Wm
+    # frame 0 initialises the map (no ICP); the stream then follows the S1 trajectory
+    frames_np = [synth.s1_frame(k % T) for k in range(min(nframes + 1, T))]
+    dev_frames = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames_np]
+    stream = torch.cuda.current_stream()
+    pl.set_stream(stream)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+        sharded = importlib.import_module("x-slam_amd.sharded")
+        runner = sharded.ShardedKinectFusion(synth.s1_params(N), rank, world, dist)
+    else:
+        dist = None
+        runner = pl.KinectFusion(synth.s1_params(N))
+
+    def frame(i):
+        return dev_frames[i % len(dev_frames)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ok = runner.process_frame(frame(0))
+    assert ok == 1
+    for i in range(1, Wm + 1):
+        assert runner.process_frame(frame(i)) == 1, "tracking lost during warm-up"
+    runner.set_profiling(True)
+    runner.reset_stage_times()
+    usum = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(Wm + 1, Wm + 1 + K):
+        assert runner.process_frame(frame(i)) == 1, "tracking lost"
+    barrier()
+    dt = time.perf_counter() - t0
+    usum = runner.cumulative_counters()[0]
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ut = torch.tensor([usum], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ut)
+        usum = int(ut.item())
+    st = runner.stage_times()
+    fps = K / dt
+    U = usum / K
+    int_ms = st["integrate"][0] / max(st["integrate"][1], 1)
+    nbytes = 24.0 * U + 2.0 * W * H
+    if world > 1:
+        nbytes = nbytes / world  # per launch: each rank's kernel covers its own slab
+    out = {
+        "metric": "fps XKinectFusion 512^3 TSDF 640x480 CSFD", "value": round(fps, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1000.0 * dt / K, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32 (complex<f32> CSFD)", "data": "synthetic",
+        "config": {"workload": f"XKinectFusion scene S1 (plane+sphere, ICL intrinsics), {N}^3 TSDF, 640x480, first-order CSFD seed "
+                               f"i*1e-7 on world2camera(0,3), 3 pyramid levels x (5,4,3) ICP iterations",
+                   "volume": f"{N}^3", "voxel_size_m": round(7.68 / N, 6), "frames_resident_in_hbm": True,
+                   "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + ICP row shards, RCCL all-reduce of the 6x6|6x1 normal equations"},
+        "roofline": {"kernel": "k_integrate (TSDF integrate)", "bound": "hbm", "achieved": round(nbytes / int_ms / 1e6, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / int_ms / 1e6 / HBM_PEAK_GBS, 5), "traffic": None,
+                     "algorithmic_bytes_per_launch": round(nbytes), "U_per_frame": round(U, 1), "kernel_ms": round(int_ms, 5)},
+        "stages_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in st.items()},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_s2:
+            runner.close()
+            out["integrate_s2"] = integrate_s2_probe(torch, capi, synth, 512)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(synth, N)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

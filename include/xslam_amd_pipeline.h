@@ -51,6 +51,8 @@ void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes);
 /* per-stage HIP-event timing: 0 surface 1 icp 2 scale 3 integrate 4 raycast 5 resize */
 void xs_kf_set_profiling(void *kf, int on);
 void xs_kf_stage_times(void *kf, double *ms6, long long *calls6);
+/* voxels written / raycast hits summed over the frames processed with profiling on */
+void xs_kf_cumulative_counters(void *kf, long long *updated, long long *hits);
 void xs_kf_reset_stage_times(void *kf);
 
 /* volume checkpoint (value + grad + weight + poses)   cf. saveTSDFVolume, .cpp:438-447 */

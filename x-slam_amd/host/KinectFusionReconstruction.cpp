@@ -18,9 +18,11 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
         hipSafeCall(hipEventCreate(&ev_[s][1]));
         ev_used_[s] = false;
     }
+    hipSafeCall(hipHostMalloc((void **)&pinned_counters_, 2 * sizeof(unsigned long long)));
 }
 
 KinectFusionReconstruction::~KinectFusionReconstruction() {
+    if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (tsdf_volume_d_ptr) ReleaseBuffers();
     for (int s = 0; s < ST_COUNT; ++s) {
         (void)hipEventDestroy(ev_[s][0]);
@@ -406,7 +408,10 @@ void KinectFusionReconstruction::stage_end(int st) {
     ev_used_[st] = true;
 }
 void KinectFusionReconstruction::collect_stage_times() {
+    hipSafeCall(hipMemcpyAsync(pinned_counters_, counters_.ptr(), 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, current_stream()));
     synchronize();
+    cum_updated += (long long)pinned_counters_[0];
+    cum_hits += (long long)pinned_counters_[1];
     for (int s = 0; s < ST_COUNT; ++s) {
         if (!ev_used_[s]) continue;
         float ms = 0.f;

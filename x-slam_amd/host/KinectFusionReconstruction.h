@@ -62,6 +62,7 @@ public:
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0, 0};
     long long stage_calls[ST_COUNT] = {0, 0, 0, 0, 0, 0};
     std::vector<double> icp_log;  // per ICP iteration of the last frame: 54 sums + inliers
+    long long cum_updated = 0, cum_hits = 0;  // summed over profiled frames (read back with the stage times)
 
     KinectFusionReconstruction();
     ~KinectFusionReconstruction();
@@ -98,6 +99,7 @@ public:
 
 private:
     DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits
+    unsigned long long *pinned_counters_ = nullptr;
     hipEvent_t ev_[ST_COUNT + 1][2];
     bool ev_used_[ST_COUNT];
     void stage_begin(int st);

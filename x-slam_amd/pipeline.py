@@ -39,6 +39,7 @@ _SIGS = {
     "xs_kf_set_profiling": (None, [_vp, C.c_int]),
     "xs_kf_stage_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_reset_stage_times": (None, [_vp]),
+    "xs_kf_cumulative_counters": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_save_tsdf_volume": (C.c_int, [_vp, C.c_char_p]),
@@ -162,6 +163,11 @@ class KinectFusion:
         calls = (C.c_longlong * 6)()
         _lib.xs_kf_stage_times(self.h, ms.ctypes.data_as(_f64p), calls)
         return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(STAGES)}
+
+    def cumulative_counters(self):
+        u, h = C.c_longlong(0), C.c_longlong(0)
+        _lib.xs_kf_cumulative_counters(self.h, C.byref(u), C.byref(h))
+        return u.value, h.value
 
     def reset_stage_times(self):
         _lib.xs_kf_reset_stage_times(self.h)
