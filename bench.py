@@ -74,7 +74,9 @@ def integrate_s2_probe(torch, capi, synth, size=512, reps=20):
     capi.init_volume(value, weight, grad, n * 4, res)
     depth = torch.from_numpy(synth.render_s2().view(np.int16)).cuda()
     scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
-    capi.scale_depth(depth, W * 2, H, W, scaled, W * 4)
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
     # v2c for c2v = translate(2.56, 2.56, 0.05): identity rotation, seed on t_x
     R = np.zeros((3, 3, 2), np.float32)
     R[[0, 1, 2], [0, 1, 2], 0] = 1
@@ -85,13 +87,13 @@ def integrate_s2_probe(torch, capi, synth, size=512, reps=20):
     counter = torch.zeros(1, dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
     args = (scaled, W * 4, H, W, intr, 100, res, float(vs), R, t, trunc, value, weight, grad, n * 4)
-    capi.integrate_scaled(*args, updated=counter, stream=s)
+    capi.integrate_scaled(*args, updated=counter, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
     U = int(counter.item())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(reps):
-        capi.integrate_scaled(*args, stream=s)
+        capi.integrate_scaled(*args, depth_max=dmax, workspace=ws, stream=s)
     e1.record(s)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

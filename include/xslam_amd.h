@@ -41,6 +41,10 @@ int xs_init_volume(float *value, int *weight, float *grad, size_t step_bytes, co
 /* scaleDepthKernal launch inside integrateTsdfVolume        TsdfFusion.cu:68-82, :182-187
  * u16 millimetres -> float metres, 0 outside [200, 5000]. */
 int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step, void *stream);
+/* Same, and max_dev (a device float the caller zeroed beforehand) receives the largest valid
+ * depth of the frame, for xs_integrate_scaled's far clipping. */
+int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
+                       float *max_dev, void *stream);
 
 /* integrateTsdfVolume(const PtrStepSz<ushort>& depth, const Intr&, int max_weight, const int3& res,
  *     float voxel_size, const MatS33& Rv2c, const devComplex3& tv2c, const devComplex3& tc2v,
@@ -55,11 +59,17 @@ int xs_integrate_tsdf_volume(const uint16_t *depth, size_t depth_step, int rows,
                              const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                              float *value, int *weight, float *grad, size_t vol_step, float *depth_scaled, size_t scaled_step,
                              float threshold, int z0, int z1, unsigned long long *updated_dev, void *stream);
-/* Same, from an already scaled depth image (tsdfFusionKernal alone, TsdfFusion.cu:85-171). */
+/* Same, from an already scaled depth image (tsdfFusionKernal alone, TsdfFusion.cu:85-171).
+ * depth_max_dev: optional device float = largest valid depth of the frame (xs_scale_depth_max);
+ * lets a column stop behind the farthest surface.  NULL = walk the whole frustum. */
 int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                         const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
                         int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
-                        unsigned long long *updated_dev, void *stream);
+                        unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, void *stream);
+/* Device workspace for xs_integrate_scaled's brick work list, for a slab of nz planes.  With a
+ * workspace the kernel first lists the 64x4x8-voxel bricks that can intersect the frustum and
+ * then spreads them over all CUs; without one (NULL) each column walks its own clipped range. */
+size_t xs_integrate_workspace_bytes(const int *res, int nz);
 
 /* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */
 size_t xs_tsdf_reduce_workspace_bytes(void);
@@ -107,6 +117,8 @@ int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, cons
 
 /* ---- ICP normal equations ----------------------------------------------------------------- */
 size_t xs_icp_workspace_bytes(void);
+/* zero the workspace's arrival ticket once after allocation; every launch leaves it zero */
+int xs_icp_workspace_init(void *workspace, void *stream);
 /* Device half of estimateCombined (ICP.h:24-31, ICP.cu:166-281 + 120-164): sums_dev receives 55
  * doubles — the 27 complex<double> sums in the reference's mbuf order, then the inlier count.
  * workspace replaces gbuf.  [y0, y1): pixel rows covered.  No synchronisation. */

@@ -21,7 +21,7 @@ def dev():
     return torch, capi
 
 
-def run_gpu(torch, capi, prm, frames, res, pitch_elems=None, threshold=0.0, slabs=1, max_weight=None, depth_fn=None):
+def run_gpu(torch, capi, prm, frames, res, pitch_elems=None, threshold=0.0, slabs=1, max_weight=None, depth_fn=None, far_clip=False, bricks=False):
     X, Y, Z = res
     pitch = (pitch_elems or X)
     step = pitch * 4
@@ -42,10 +42,19 @@ def run_gpu(torch, capi, prm, frames, res, pitch_elems=None, threshold=0.0, slab
         for s in range(slabs):
             z0, z1 = bounds[s], bounds[s + 1]
             off = z0 * Y
-            capi.integrate_tsdf_volume(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, intr_of(prm), mw, res,
-                                       prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm),
-                                       value[off:], weight[off:], grad[off:], step, scaled, synth.WIDTH * 4,
-                                       threshold=threshold, z0=z0, z1=z1, updated=counter)
+            if far_clip or bricks:  # the orchestrator's path: frame depth maximum -> far clip; brick work list
+                dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+                capi.scale_depth_max(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, scaled, synth.WIDTH * 4, dmax)
+                ws = torch.zeros(capi.integrate_workspace_bytes(res, z1 - z0), dtype=torch.uint8, device="cuda") if bricks else None
+                capi.integrate_scaled(scaled, synth.WIDTH * 4, synth.HEIGHT, synth.WIDTH, intr_of(prm), mw, res, prm["tsdf_voxel_size"],
+                                      T["Rv2c"], T["tv2c"], tranc_dist(prm), value[off:], weight[off:], grad[off:], step,
+                                      threshold=threshold, z0=z0, z1=z1, updated=counter, depth_max=dmax if far_clip else None,
+                                      workspace=ws)
+            else:
+                capi.integrate_tsdf_volume(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, intr_of(prm), mw, res,
+                                           prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm),
+                                           value[off:], weight[off:], grad[off:], step, scaled, synth.WIDTH * 4,
+                                           threshold=threshold, z0=z0, z1=z1, updated=counter)
         torch.cuda.synchronize()
         counts.append(int(counter.item()))
     v = value[:, :X].contiguous().cpu().numpy().reshape(-1)
@@ -90,6 +99,62 @@ def test_integrate_s1_three_frames(dev, oracle, n):
     compare(run_gpu(torch, capi, prm, [0, 1, 2], res), run_cpu(oracle, prm, [0, 1, 2], res))
 
 
+@pytest.mark.parametrize("n,threshold", [(96, 0.0), (128, 0.02)])
+def test_integrate_far_clip_changes_nothing(dev, oracle, n, threshold):
+    """Column clipping against the frame's largest depth skips only voxels the reference would
+    not write: identical volumes with and without it, and both equal to the oracle."""
+    torch, capi = dev
+    prm = synth.s1_params(n, threshold=threshold)
+    res = [n, n, n]
+    a = run_gpu(torch, capi, prm, [0, 5, 9], res, threshold=threshold)
+    for kw in (dict(far_clip=True), dict(bricks=True), dict(far_clip=True, bricks=True), dict(far_clip=True, bricks=True, slabs=3)):
+        b = run_gpu(torch, capi, prm, [0, 5, 9], res, threshold=threshold, **kw)
+        for u, v in zip(a[:3], b[:3]):
+            assert np.array_equal(u, v), kw
+        assert a[3] == b[3], kw
+    compare(b, run_cpu(oracle, prm, [0, 5, 9], res, threshold=threshold))
+
+
+def test_integrate_rotated_and_inside_out_views(dev, oracle):
+    """Column clipping under strong rotations (every sign of the half-space slopes), a camera
+    outside the volume and a view from the far side."""
+    torch, capi = dev
+    n = 96
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    rng = np.random.default_rng(3)
+    d = synth.s1_frame(0)
+    ds = oracle.scale_depth(d)
+    depth = torch.from_numpy(d.astype(np.int16)).cuda()
+    scaled = torch.empty((synth.HEIGHT, synth.WIDTH), dtype=torch.float32, device="cuda")
+    for trial in range(8):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = rng.uniform(0.2, 3.0)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        tv = rng.uniform(-2.0, 9.0, 3)  # camera position in the volume frame, sometimes outside
+        v2c = np.eye(4); v2c[:3, :3] = Rm.T; v2c[:3, 3] = -Rm.T @ tv
+        R = np.zeros((3, 3, 2), np.float32); R[..., 0] = v2c[:3, :3]; R[..., 1] = rng.normal(size=(3, 3)) * 1e-7
+        t = np.zeros((3, 2), np.float32); t[:, 0] = v2c[:3, 3]; t[:, 1] = rng.normal(size=3) * 1e-7
+        value = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+        weight = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
+        grad = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+        dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        capi.scale_depth_max(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, scaled, synth.WIDTH * 4, dmax)
+        ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda") if trial % 2 else None
+        capi.integrate_scaled(scaled, synth.WIDTH * 4, synth.HEIGHT, synth.WIDTH, intr_of(prm), 100, res, prm["tsdf_voxel_size"], R, t,
+                              tranc_dist(prm), value, weight, grad, n * 4, updated=counter, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        assert abs(float(dmax.item()) - float(ds.max())) == 0.0
+        v, w, g = oracle.new_volume(res)
+        U = oracle.integrate(ds, v, w, g, res, tranc_dist(prm), 100, R, t, intr_of(prm), prm["tsdf_voxel_size"])
+        gpu = (value.cpu().numpy().reshape(-1), weight.cpu().numpy().reshape(-1), grad.cpu().numpy().reshape(-1), [int(counter.item())])
+        assert mismatch_fraction(gpu[1], w) <= FLIP_BUDGET and mismatch_fraction(gpu[0], v) <= FLIP_BUDGET, trial
+        assert mismatch_fraction(gpu[2], g) <= FLIP_BUDGET, trial
+        assert abs(gpu[3][0] - U) <= max(2, 1e-4 * U)
+
+
 def test_integrate_bilinear_branch(dev, oracle):
     torch, capi = dev
     prm = synth.s1_params(96, threshold=0.02)
@@ -106,7 +171,9 @@ def test_integrate_ragged_pitched_volume(dev, oracle):
     torch, capi = dev
     prm = synth.s1_params(128)
     res = [100, 70, 90]
-    compare(run_gpu(torch, capi, prm, [0, 2], res, pitch_elems=128), run_cpu(oracle, prm, [0, 2], res))
+    cpu = run_cpu(oracle, prm, [0, 2], res)
+    compare(run_gpu(torch, capi, prm, [0, 2], res, pitch_elems=128), cpu)
+    compare(run_gpu(torch, capi, prm, [0, 2], res, pitch_elems=128, far_clip=True, bricks=True), cpu)
 
 
 @pytest.mark.parametrize("slabs", [2, 3, 8])
@@ -159,12 +226,12 @@ def test_integrate_size_independent_properties_512(dev):
     n = 512
     prm = synth.s1_params(n)
     res = [n, n, n]
-    v, w, g, c = run_gpu(torch, capi, prm, [0], res)
+    v, w, g, c = run_gpu(torch, capi, prm, [0], res, far_clip=True, bricks=True)
     assert int(w.sum()) == c[0]
     assert abs(c[0] - 1930365) <= 200  # reference kernel, same scene
     assert not v[w == 0].any() and not g[w == 0].any()
     assert np.all(np.abs(v[w > 0]) <= 1.0 + 1e-6)
-    v2, w2, g2, c2 = run_gpu(torch, capi, prm, [0, 0], res)
+    v2, w2, g2, c2 = run_gpu(torch, capi, prm, [0, 0], res, far_clip=True, bricks=True)
     assert c2[1] == c2[0]
     assert np.array_equal(w2, 2 * w)
     free = v == 1.0

@@ -42,7 +42,9 @@ _SIGS = {
     "xs_integrate_tsdf_volume": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float,
                                            _vp, _vp, _vp, _sz, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "xs_integrate_scaled": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float,
-                                      _vp, _vp, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp]),
+                                      _vp, _vp, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
+    "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "xs_tsdf_reduce_workspace_bytes": (_sz, []),
     "xs_compute_local_tsdf_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
                                                 _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -57,6 +59,7 @@ _SIGS = {
     "xs_raycast": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
                              C.c_int, C.c_int, _vp, _vp]),
     "xs_icp_workspace_bytes": (_sz, []),
+    "xs_icp_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                     C.c_float, C.c_int, C.c_int, _vp, _vp, _vp]),
     "xs_estimate_combined": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -135,14 +138,24 @@ def integrate_tsdf_volume(depth, depth_step, rows, cols, intr, max_weight, res, 
                                         threshold, z0, z1, _ptr(updated), _stream(stream)))
 
 
+def scale_depth_max(depth, depth_step, rows, cols, scaled, scaled_step, max_dev, stream=None):
+    check(_lib.xs_scale_depth_max(_ptr(depth), depth_step, rows, cols, _ptr(scaled), scaled_step, _ptr(max_dev), _stream(stream)))
+
+
 def integrate_scaled(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight,
-                     grad, vol_step, threshold=0.0, z0=0, z1=None, updated=None, stream=None):
+                     grad, vol_step, threshold=0.0, z0=0, z1=None, updated=None, depth_max=None, workspace=None, stream=None):
     r = _ia(res, 3)
     k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
     z1 = int(r[2]) if z1 is None else z1
     check(_lib.xs_integrate_scaled(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), max_weight,
                                    r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
-                                   _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _stream(stream)))
+                                   _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _ptr(depth_max),
+                                   _ptr(workspace), _stream(stream)))
+
+
+def integrate_workspace_bytes(res, nz=None):
+    r = _ia(res, 3)
+    return _lib.xs_integrate_workspace_bytes(r.ctypes.data_as(_i32p), int(r[2]) if nz is None else nz)
 
 
 def tsdf_reduce_workspace_bytes():
@@ -207,6 +220,10 @@ def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, gr
 
 def icp_workspace_bytes():
     return _lib.xs_icp_workspace_bytes()
+
+
+def icp_workspace_init(workspace, stream=None):
+    check(_lib.xs_icp_workspace_init(_ptr(workspace), _stream(stream)))
 
 
 def icp_accumulate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,

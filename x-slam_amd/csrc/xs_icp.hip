@@ -128,15 +128,34 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == gridDim.x - 1) ? 1u : 0u;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // the ticket re-arms itself: the next launch on this stream starts from zero
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (s_last && threadIdx.x < NS + 1) {
-        double sum = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b)
-            sum += __hip_atomic_load(&a.partials[(size_t)b * NP + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.out[threadIdx.x] = sum;
+    if (s_last) {
+        // after the acquire (this CU's L1 invalidated) + barrier, plain loads see every record.
+        // Column c = lane, records strided over the 4 waves, 8 independent loads in flight; the
+        // four wave sums are then added in wave order — a fixed association, so deterministic.
+        const int c = lane;
+        double s = 0.0;
+        if (c < NS + 1) {
+            const double *p = a.partials + c;
+            unsigned b = wave;
+            for (; b + 28 < gridDim.x; b += 32) {
+                const double v0 = p[(size_t)(b + 0) * NP], v1 = p[(size_t)(b + 4) * NP], v2 = p[(size_t)(b + 8) * NP], v3 = p[(size_t)(b + 12) * NP];
+                const double v4 = p[(size_t)(b + 16) * NP], v5 = p[(size_t)(b + 20) * NP], v6 = p[(size_t)(b + 24) * NP], v7 = p[(size_t)(b + 28) * NP];
+                s += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+            }
+            for (; b < gridDim.x; b += 4) s += p[(size_t)b * NP];
+        }
+        __syncthreads();
+        if (c < NS + 1) smem[wave][c] = s;
+        __syncthreads();
+        if (threadIdx.x < NS + 1) a.out[threadIdx.x] = ((smem[0][threadIdx.x] + smem[1][threadIdx.x]) + smem[2][threadIdx.x]) + smem[3][threadIdx.x];
     }
 }
 
@@ -149,9 +168,15 @@ static void ld_mat(const float *p, MatS33 &m) {
 }
 static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
 
-enum { XS_ICP_MAX_BLOCKS = 512 };
+enum { XS_ICP_MAX_BLOCKS = 256 };  // one workgroup per CU
 
 extern "C" size_t xs_icp_workspace_bytes(void) { return (size_t)XS_ICP_MAX_BLOCKS * NP * sizeof(double) + 256; }
+/* zero the arrival ticket once after allocating the workspace (launches re-arm it themselves) */
+extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
+    if (!workspace) return xs_set_error(hipErrorInvalidValue, "xs_icp_workspace_init: null pointer");
+    XS_CHECK(hipMemsetAsync(workspace, 0, 256, (hipStream_t)stream));
+    return 0;
+}
 
 /* estimateCombined(const MatS33& Rcurr, const devComplex3& tcurr, const MapArr& vmap_curr,
  *     const MapArr& nmap_curr, const MatS33& Rprev_inv, const devComplex3& tprev, const Intr&,
@@ -183,7 +208,7 @@ extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, cons
     int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
     if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    XS_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
+    // the ticket word must be zero on first use (xs_icp_workspace_init); every launch leaves it zero
     hipLaunchKernelGGL(k_icp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
@@ -200,8 +225,10 @@ extern "C" int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, c
     int rc = xs_icp_accumulate(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step,
                                rows, cols, distThres, angleThres, 0, rows, workspace, sums_dev, stream);
     if (rc) return rc;
-    double host[55];
-    XS_CHECK(hipMemcpyAsync(host, sums_dev, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    // pinned staging: a pageable destination would bounce through the runtime's own staging buffer
+    static thread_local double *host = nullptr;
+    if (!host) XS_CHECK(hipHostMalloc((void **)&host, 64 * sizeof(double)));
+    XS_CHECK(hipMemcpyAsync(host, sums_dev, 55 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     XS_CHECK(hipStreamSynchronize((hipStream_t)stream));
     xs_icp_unpack(host, A72_host, b12_host);
     if (inliers) *inliers = (long long)host[54];

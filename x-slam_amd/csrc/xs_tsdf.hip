@@ -53,113 +53,285 @@ extern "C" int xs_init_volume(float *value, int *weight, float *grad, size_t ste
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_scale_depth(const uint16_t *depth, size_t dstep, int rows, int cols, float *scaled, size_t sstep) {
-    int x = threadIdx.x + blockIdx.x * blockDim.x;
-    int y = threadIdx.y + blockIdx.y * blockDim.y;
-    if (x >= cols || y >= rows) return;
-    int Dp = row_ptr(depth, dstep, y)[x];
-    float r = 0.f;
-    if (!(Dp > 5000 || Dp < 200)) r = float(Dp) / 1000.f;  // metres
-    row_ptr(scaled, sstep, y)[x] = r;
+__global__ void __launch_bounds__(256) k_scale_depth(const uint16_t *depth, size_t dstep, int rows, int cols, float *scaled, size_t sstep,
+                                                     unsigned *max_bits) {
+    // few, fat workgroups (grid-stride over pixels) so the optional maximum costs one atomic per
+    // workgroup instead of one per wave
+    const int n = rows * cols;
+    unsigned b = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / cols, x = i - y * cols;
+        const int Dp = row_ptr(depth, dstep, y)[x];
+        float r = 0.f;
+        if (!(Dp > 5000 || Dp < 200)) r = float(Dp) / 1000.f;  // metres
+        row_ptr(scaled, sstep, y)[x] = r;
+        b = max(b, __float_as_uint(r));  // non-negative floats order like their bit patterns
+    }
+    if (max_bits) {
+        __shared__ unsigned sm[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) b = max(b, (unsigned)__shfl_down((int)b, off, 64));
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            b = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+            if (b) atomicMax(max_bits, b);
+        }
+    }
 }
 
-extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step, void *stream) {
+/* max_dev: optional device float that receives max(scaled) via atomicMax on its bits; the caller
+ * zeroes it before the launch (used by integrate to stop walking behind the farthest surface) */
+extern "C" int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
+                                  float *max_dev, void *stream) {
     if (!depth || !scaled) return xs_set_error(hipErrorInvalidValue, "xs_scale_depth: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
-    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
-    hipLaunchKernelGGL(k_scale_depth, grid, block, 0, (hipStream_t)stream, depth, depth_step, rows, cols, scaled, scaled_step);
+    int blocks = div_up(rows * cols, 256 * 16);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_scale_depth, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, depth_step, rows, cols, scaled, scaled_step, (unsigned *)max_dev);
     XS_CHECK(hipGetLastError());
     return 0;
 }
+extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step, void *stream) {
+    return xs_scale_depth_max(depth, depth_step, rows, cols, scaled, scaled_step, nullptr, stream);
+}
 
 // ------------------------------------------------------------------------------------------
+// Brick geometry: 64 (x) x 4 (y) x 8 (z) voxels = one 256-thread workgroup, lane = x, so every
+// volume access of a wave is one 256-byte row segment.
+enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
+
 struct IntegrateArgs {
     const float *depth; size_t dstep; int drows, dcols;
     float *value; int *weight; float *grad; size_t vstep;
     int X, Y, Z;        // full resolution
     int z0, z1;         // slab owned by this launch; storage starts at z0
-    int zchunk;         // z range per blockIdx.z
+    int zchunk;         // z range per blockIdx.z (column-walk kernel)
     float tranc_dist, tranc_dist_inv; int max_weight;
     MatS33 R; cfloat3 t;
     Intr intr; float voxel_size, threshold;
     unsigned long long *updated;  // optional device counter
+    const float *depth_max;       // optional: largest valid depth of the frame (device)
+    int *brick_list; unsigned *brick_count;  // work list of the two-phase path
+    int bricks_x, bricks_y, bricks_z;
 };
 
+namespace {
+// Half-spaces of the (padded) view frustum in the volume's voxel-index space.  Along any
+// direction the camera-frame position is affine in the voxel index (real parts), so each side
+// of the image window, the camera plane and the far limit is alpha + bx*i + by*j + bz*k >= -slack
+// with (i, j, k) = voxel index + 0.5.  The window is the reference's in-image test
+// (TsdfFusion.cu:123-124) padded by three pixels, the slack is 2e-3 of the term magnitudes:
+// voxels outside provably fail the exact tests; voxels inside still take them.
+struct Frustum {
+    float alpha[6], bx[6], by[6], bz[6], slack[6];
+    int n;
+};
+__device__ __forceinline__ Frustum make_frustum(const IntegrateArgs &a) {
+    Frustum f;
+    const float vs = a.voxel_size, fx = a.intr.fx, fy = a.intr.fy;
+    const float ul = (1.5f - a.intr.cx) - 2.f, uh = ((a.dcols - 0.5f) - a.intr.cx + 1.0f) + 2.f;
+    const float vl = (1.5f - a.intr.cy) - 2.f, vh = ((a.drows - 0.5f) - a.intr.cy + 1.0f) + 2.f;
+    // camera coordinates (real parts): p_r = t_r + vs * (R_r0*i + R_r1*j + R_r2*k)
+    float T[3], M[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T[r] = (r == 0 ? a.t.x.re : r == 1 ? a.t.y.re : a.t.z.re);
+        M[r][0] = a.R.data[r].x.re * vs; M[r][1] = a.R.data[r].y.re * vs; M[r][2] = a.R.data[r].z.re * vs;
+    }
+    const float ext = (float)max(a.X, max(a.Y, a.Z));
+    float mag[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) mag[r] = fabsf(T[r]) + (fabsf(M[r][0]) + fabsf(M[r][1]) + fabsf(M[r][2])) * ext;
+    const float rel = 2e-3f;
+    int n = 0;
+    auto plane = [&](float cxk, float cyk, float czk, float c0, float sl) {  // cxk*px' + cyk*py' + czk*c + c0 >= 0
+        f.alpha[n] = cxk * T[0] + cyk * T[1] + czk * T[2] + c0;
+        f.bx[n] = cxk * M[0][0] + cyk * M[1][0] + czk * M[2][0];
+        f.by[n] = cxk * M[0][1] + cyk * M[1][1] + czk * M[2][1];
+        f.bz[n] = cxk * M[0][2] + cyk * M[1][2] + czk * M[2][2];
+        f.slack[n] = sl;
+        ++n;
+    };
+    plane(0.f, 0.f, 1.f, 0.f, rel * mag[2]);                                        // c >= 0
+    plane(fx, 0.f, -ul, 0.f, rel * (fabsf(fx) * mag[0] + fabsf(ul) * mag[2]));      // fx*X >= ul*c
+    plane(-fx, 0.f, uh, 0.f, rel * (fabsf(fx) * mag[0] + fabsf(uh) * mag[2]));      // fx*X <= uh*c
+    plane(0.f, fy, -vl, 0.f, rel * (fabsf(fy) * mag[1] + fabsf(vl) * mag[2]));      // fy*Y >= vl*c
+    plane(0.f, -fy, vh, 0.f, rel * (fabsf(fy) * mag[1] + fabsf(vh) * mag[2]));      // fy*Y <= vh*c
+    if (a.depth_max) {
+        // behind the farthest surface by more than the truncation band nothing is written:
+        // v_c_1 = Dp*(xl, yl, 1) lies on the voxel's own ray, so sdf = (Dp - c) * |v_c|/c with
+        // |v_c|/c >= 1 and Dp <= Dmax; c > Dmax + trunc therefore gives sdf < -trunc
+        const float cfar = *a.depth_max * 1.0001f + 1.05f * a.tranc_dist;
+        plane(0.f, 0.f, -1.f, cfar, rel * mag[2]);                                  // c <= cfar
+    }
+    f.n = n;
+    return f;
+}
+// Intersect {k : alpha + beta*k >= -slack} with [lo, hi]
+__device__ __forceinline__ void clip_halfspace(float alpha, float beta, float slack, float &lo, float &hi) {
+    const float av = alpha + slack;
+    if (fabsf(beta) <= 1e-12f * (fabsf(alpha) + slack)) {
+        if (av < 0.f) { lo = 1.f; hi = 0.f; }
+        return;
+    }
+    const float root = -av * __frcp_rn(beta);  // approximate: the caller pads the interval
+    if (beta > 0.f) lo = fmaxf(lo, root); else hi = fminf(hi, root);
+}
+// z interval [zb, ze) of column (x, y) that can pass the tests, padded by two voxels
+__device__ __forceinline__ void clip_column(const Frustum &f, int x, int y, int &zb, int &ze) {
+    float lo = (float)zb, hi = (float)ze;
+    const float i = x + 0.5f, j = y + 0.5f;
+    for (int p = 0; p < f.n; ++p) clip_halfspace(f.alpha[p] + f.bx[p] * i + f.by[p] * j, f.bz[p], f.slack[p], lo, hi);
+    zb = max(zb, (int)floorf(lo - 0.5f) - 2);
+    ze = min(ze, (int)ceilf(hi - 0.5f) + 3);
+}
+// can any voxel of the index box [x0,x1) x [y0,y1) x [z0,z1) pass?  (all corners outside one
+// half-space => no)
+__device__ __forceinline__ bool box_may_pass(const Frustum &f, int x0, int x1, int y0, int y1, int z0, int z1) {
+    const float xa = x0 + 0.5f, xb = x1 - 0.5f, ya = y0 + 0.5f, yb = y1 - 0.5f, za = z0 + 0.5f, zb = z1 - 0.5f;
+    for (int p = 0; p < f.n; ++p) {
+        // maximum of the affine form over the box: pick the favourable end per axis
+        const float m = f.alpha[p] + (f.bx[p] > 0 ? f.bx[p] * xb : f.bx[p] * xa) + (f.by[p] > 0 ? f.by[p] * yb : f.by[p] * ya) +
+                        (f.bz[p] > 0 ? f.bz[p] * zb : f.bz[p] * za);
+        if (m < -f.slack[p] * 1.5f) return false;
+    }
+    return true;
+}
+
+// The reference's per-voxel body (TsdfFusion.cu:110-168) for z in [zb, ze) of column (x, y).
+template <bool BILINEAR>
+__device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x, int y, int zb, int ze) {
+    unsigned n_upd = 0;
+    const float vgx = (x + 0.5f) * a.voxel_size;
+    const float vgy = (y + 0.5f) * a.voxel_size;
+    // z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy); v_g has zero imaginary
+    // part, so each complex product is (re*vg, im*vg)
+    cfloat base[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
+    const float fx = a.intr.fx, fy = a.intr.fy, cx = a.intr.cx, cy = a.intr.cy;
+    // conservative image window in un-divided form (one pixel of slack on each side)
+    const float ulo = 1.5f - cx, uhi = (a.dcols - 0.5f) - cx + 1.0f;
+    const float vlo = 1.5f - cy, vhi = (a.drows - 0.5f) - cy + 1.0f;
+    const size_t row = (size_t)(zb - a.z0) * a.Y + y;
+    float *pos = row_ptr(a.value, a.vstep, 0) + row * (a.vstep / 4) + x;
+    int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
+    float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
+    const size_t zstride = (size_t)a.Y * (a.vstep / 4);
+    for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
+        const float vgz = (z + 0.5f) * a.voxel_size;
+        cfloat3 v_c;
+        v_c.x = (base[0] + a.R.data[0].z * vgz) + a.t.x;
+        v_c.y = (base[1] + a.R.data[1].z * vgz) + a.t.y;
+        v_c.z = (base[2] + a.R.data[2].z * vgz) + a.t.z;
+        const float c = v_c.z.re;
+        if (c < 0) continue;  // Re(1/v_c.z) < 0
+        const cfloat px = v_c.x * fx, py = v_c.y * fy;
+        // early reject before the divides: |true image coordinate - (px/c + cx)| << 1 pixel
+        if (c > 0) {
+            if (px.re < ulo * c || px.re > uhi * c) continue;
+            if (py.re < vlo * c || py.re > vhi * c) continue;
+        }
+        const cfloat inv_z = 1.0f / v_c.z;
+        const cfloat image_x = px * inv_z + cx;
+        const cfloat image_y = py * inv_z + cy;
+        const int coo_x = __float2int_rd(image_x.re - 0.5f);
+        const int coo_y = __float2int_rd(image_y.re - 0.5f);
+        if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
+        const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
+        cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
+        if (BILINEAR) {
+            const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
+            const float d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
+            const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x];
+            const float d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+            const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
+            const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
+            if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+                const cfloat one(1.0f, 0.0f);
+                const cfloat fa = image_x - cfloat(coo_x + 0.5f, 0.0f);
+                const cfloat fb = image_y - cfloat(coo_y + 0.5f, 0.0f);
+                Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+            }
+        }
+        if (!(Dp.re > 0)) continue;  // the update needs Re Dp > 0 (TsdfFusion.cu:150); skip the norms early
+        const cfloat xl = (image_x - cx) / fx;
+        const cfloat yl = (image_y - cy) / fy;
+        const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
+        const cfloat sdf = norm(v_c_1) - norm(v_c);
+        if (sdf.re >= -a.tranc_dist) {
+            cfloat tsdf = sdf * a.tranc_dist_inv;
+            if (sdf.re > a.tranc_dist) tsdf = cfloat(1.0f, 0.0f);
+            const cfloat tsdf_prev(*pos, *gpos);
+            const int weight_prev = *wpos;
+            const cfloat tsdf_new = (tsdf_prev * __int2float_rn(weight_prev) + 1.0f * tsdf) / __int2float_rn(weight_prev + 1);
+            *pos = tsdf_new.re;
+            *wpos = min(weight_prev + 1, a.max_weight);
+            *gpos = tsdf_new.im;
+            ++n_upd;
+        }
+    }
+    return n_upd;
+}
+}  // namespace
+
+// ---- path 1: column walk (no workspace): thread (x, y) walks its clipped z interval ---------
 template <bool BILINEAR>
 __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
     const int x = threadIdx.x + blockIdx.x * 64;
     const int y = threadIdx.y + blockIdx.y * 4;
     unsigned n_upd = 0;
     if (x < a.X && y < a.Y) {
-        const float vgx = (x + 0.5f) * a.voxel_size;
-        const float vgy = (y + 0.5f) * a.voxel_size;
-        // z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy); v_g has zero
-        // imaginary part, so each complex product is (re*vg, im*vg)
-        cfloat base[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
-        const float fx = a.intr.fx, fy = a.intr.fy, cx = a.intr.cx, cy = a.intr.cy;
-        // conservative image window in un-divided form (one pixel of slack on each side)
-        const float ulo = 1.5f - cx, uhi = (a.dcols - 0.5f) - cx + 1.0f;
-        const float vlo = 1.5f - cy, vhi = (a.drows - 0.5f) - cy + 1.0f;
         int zb = a.z0 + blockIdx.z * a.zchunk;
         int ze = min(zb + a.zchunk, a.z1);
-        size_t row = (size_t)(zb - a.z0) * a.Y + y;
-        float *pos = row_ptr(a.value, a.vstep, 0) + row * (a.vstep / 4) + x;
-        int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
-        float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
-        const size_t zstride = (size_t)a.Y * (a.vstep / 4);
-        for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
-            const float vgz = (z + 0.5f) * a.voxel_size;
-            cfloat3 v_c;
-            v_c.x = (base[0] + a.R.data[0].z * vgz) + a.t.x;
-            v_c.y = (base[1] + a.R.data[1].z * vgz) + a.t.y;
-            v_c.z = (base[2] + a.R.data[2].z * vgz) + a.t.z;
-            const float c = v_c.z.re;
-            if (c < 0) continue;  // Re(1/v_c.z) < 0
-            const cfloat px = v_c.x * fx, py = v_c.y * fy;
-            // early reject: |true image coordinate - (px/c + cx)| << 1 pixel
-            if (c > 0) {
-                if (px.re < ulo * c || px.re > uhi * c) continue;
-                if (py.re < vlo * c || py.re > vhi * c) continue;
-            }
-            const cfloat inv_z = 1.0f / v_c.z;
-            const cfloat image_x = px * inv_z + cx;
-            const cfloat image_y = py * inv_z + cy;
-            const int coo_x = __float2int_rd(image_x.re - 0.5f);
-            const int coo_y = __float2int_rd(image_y.re - 0.5f);
-            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
-            const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
-            cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
-            if (BILINEAR) {
-                const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
-                const float d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
-                const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x];
-                const float d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
-                const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
-                const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
-                if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
-                    const cfloat one(1.0f, 0.0f);
-                    const cfloat fa = image_x - cfloat(coo_x + 0.5f, 0.0f);
-                    const cfloat fb = image_y - cfloat(coo_y + 0.5f, 0.0f);
-                    Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
-                }
-            }
-            const cfloat xl = (image_x - cx) / fx;
-            const cfloat yl = (image_y - cy) / fy;
-            const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
-            const cfloat sdf = norm(v_c_1) - norm(v_c);
-            if (Dp.re > 0 && sdf.re >= -a.tranc_dist) {
-                cfloat tsdf = sdf * a.tranc_dist_inv;
-                if (sdf.re > a.tranc_dist) tsdf = cfloat(1.0f, 0.0f);
-                const cfloat tsdf_prev(*pos, *gpos);
-                const int weight_prev = *wpos;
-                const cfloat tsdf_new = (tsdf_prev * __int2float_rn(weight_prev) + 1.0f * tsdf) / __int2float_rn(weight_prev + 1);
-                *pos = tsdf_new.re;
-                *wpos = min(weight_prev + 1, a.max_weight);
-                *gpos = tsdf_new.im;
-                ++n_upd;
-            }
+        const Frustum f = make_frustum(a);
+        clip_column(f, x, y, zb, ze);
+        if (zb < ze) n_upd = integrate_span<BILINEAR>(a, x, y, zb, ze);
+    }
+    if (a.updated) {
+        unsigned s = wave_sum_u32(n_upd);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.updated, (unsigned long long)s);
+    }
+}
+
+// ---- path 2: brick work list ------------------------------------------------------------------
+// Phase A: one thread per brick tests it against the padded frustum (and the far limit) and
+// appends survivors to a list — a wave ballots, one atomic per wave.  Phase B: resident
+// workgroups stride over the list; each handles one 64x4x8 brick.  The voxels that can be
+// written (a few % of an ICL-like volume) are thereby spread over every CU instead of being
+// concentrated in the few columns that cross the frustum.
+__global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) {
+    const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = false;
+    if (b < nb) {
+        const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
+        const int x0 = bx * BRICK_X, y0 = by * BRICK_Y, z0 = a.z0 + bz * BRICK_Z;
+        const Frustum f = make_frustum(a);
+        active = box_may_pass(f, x0, min(x0 + BRICK_X, a.X), y0, min(y0 + BRICK_Y, a.Y), z0, min(z0 + BRICK_Z, a.z1));
+    }
+    const unsigned long long m = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0 && m) base = atomicAdd(a.brick_count, (unsigned)__popcll(m));
+    base = __shfl((int)base, 0, 64);
+    if (active) a.brick_list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+
+template <bool BILINEAR>
+__global__ void __launch_bounds__(256) k_integrate_bricks(const IntegrateArgs a) {
+    const unsigned count = *a.brick_count;
+    unsigned n_upd = 0;
+    const Frustum f = make_frustum(a);
+    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+        const int b = a.brick_list[e];
+        const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
+        const int x = bx * BRICK_X + threadIdx.x, y = by * BRICK_Y + threadIdx.y;
+        if (x < a.X && y < a.Y) {
+            int zb = a.z0 + bz * BRICK_Z, ze = min(zb + BRICK_Z, a.z1);
+            clip_column(f, x, y, zb, ze);
+            if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
         }
     }
     if (a.updated) {
@@ -177,10 +349,17 @@ static void load_mat(const float *p, MatS33 &m) {
 }
 static void load_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
 
+/* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
+extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
+    if (!res || nz <= 0) return 0;
+    const size_t nb = (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, BRICK_Z);
+    return 256 + nb * sizeof(int);
+}
+
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                                    float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
-                                   unsigned long long *updated_dev, void *stream) {
+                                   unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, void *stream) {
     if (!depth_scaled || !intr4 || !res || !Rv2c18 || !tv2c6 || !value || !weight || !grad)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: null pointer");
     if (z0 < 0 || z1 > res[2] || z1 < z0 || (vol_step % 4) != 0 || vol_step < (size_t)res[0] * 4)
@@ -193,19 +372,35 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
     a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist; a.max_weight = max_weight;
     load_mat(Rv2c18, a.R); load_vec(tv2c6, a.t);
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
-    a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev;
-    // enough workgroups to fill 256 CUs several times over: split z so that grid >= ~4096 blocks
+    a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev; a.depth_max = depth_max_dev;
+    a.brick_list = nullptr; a.brick_count = nullptr;
+    const int nz = z1 - z0;
+    a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, BRICK_Z);
+    a.zchunk = nz;
+    hipStream_t st = (hipStream_t)stream;
     dim3 block(64, 4);
-    int gx = div_up(a.X, 64), gy = div_up(a.Y, 4);
-    int nz = z1 - z0;
-    int zsplit = 1;
-    while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
-    a.zchunk = div_up(nz, zsplit);
-    dim3 grid(gx, gy, div_up(nz, a.zchunk));
-    if (threshold > 0.0f)
-        hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, (hipStream_t)stream, a);
+    if (workspace) {
+        a.brick_count = (unsigned *)workspace;
+        a.brick_list = (int *)((char *)workspace + 256);
+        const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
+        XS_CHECK(hipMemsetAsync(a.brick_count, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+        // resident workgroups stride over the list: 256 CUs x 8
+        const int g = nb < 2048 ? nb : 2048;
+        if (threshold > 0.0f)
+            hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
+        else
+            hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
+    } else {
+        int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
+        while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
+        a.zchunk = div_up(nz, zsplit);
+        dim3 grid(gx, gy, div_up(nz, a.zchunk));
+        if (threshold > 0.0f)
+            hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, st, a);
+    }
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -221,7 +416,7 @@ extern "C" int xs_integrate_tsdf_volume(const uint16_t *depth, size_t depth_step
     int rc = xs_scale_depth(depth, depth_step, rows, cols, depth_scaled, scaled_step, stream);
     if (rc) return rc;
     return xs_integrate_scaled(depth_scaled, scaled_step, rows, cols, intr4, max_weight, res, voxel_size, Rv2c18, tv2c6, tranc_dist, value,
-                               weight, grad, vol_step, threshold, z0, z1, updated_dev, stream);
+                               weight, grad, vol_step, threshold, z0, z1, updated_dev, nullptr, nullptr, stream);
 }
 
 // ==========================================================================================

@@ -110,8 +110,12 @@ void KinectFusionReconstruction::AllocateBuffers() {
         nmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
     }
     depthRawScaled_d.create(depth_height, depth_width);
-    counters_.create(2);
-    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), current_stream()));
+    {
+        const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
+        integrate_ws_.create(xs_integrate_workspace_bytes(res, res[2]));
+    }
+    counters_.create(3);  // [0] updated voxels, [1] raycast hits, [2] bits of the frame's largest valid depth
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 3 * sizeof(unsigned long long), current_stream()));
 }
 
 // reference :108-123
@@ -257,20 +261,21 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     hipStream_t st = current_stream();
-    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), st));
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 3 * sizeof(unsigned long long), st));
+    float *depth_max_dev = reinterpret_cast<float *>(counters_.ptr() + 2);
     // integrateTsdfVolume (TsdfFusion.cu:173-201), its two launches timed separately
     const int res[3] = {volume_res.x, volume_res.y, volume_res.z};
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
     DeviceArray2D<int> weight = tsdf_volume_d_ptr->weight();
     stage_begin(ST_SCALE);
-    check_rc(xs_scale_depth(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
-                            depthRawScaled_d.step(), st), "scaleDepth");
+    check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                                depthRawScaled_d.step(), depth_max_dev, st), "scaleDepth");
     stage_end(ST_SCALE);
     stage_begin(ST_INTEGRATE);
     check_rc(xs_integrate_scaled(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
                                  &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re, &device_tv2c.x.re,
                                  tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(), weight.ptr(), grad.ptr(), value.step(),
-                                 biInterpolate_threshold, 0, res[2], counters_.ptr(), st), "integrateTsdfVolume");
+                                 biInterpolate_threshold, 0, res[2], counters_.ptr(), depth_max_dev, integrate_ws_.ptr(), st), "integrateTsdfVolume");
     stage_end(ST_INTEGRATE);
 
     stage_begin(ST_RAYCAST);
@@ -326,12 +331,12 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
 void KinectFusionReconstruction::synchronize() { hipSafeCall(hipStreamSynchronize(current_stream())); }
 
 long long KinectFusionReconstruction::lastUpdatedVoxels() {
-    unsigned long long h[2];
+    unsigned long long h[3];
     counters_.download(h);
     return (long long)h[0];
 }
 long long KinectFusionReconstruction::lastRaycastHits() {
-    unsigned long long h[2];
+    unsigned long long h[3];
     counters_.download(h);
     return (long long)h[1];
 }

@@ -98,7 +98,8 @@ public:
     void synchronize();
 
 private:
-    DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits
+    DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits, [2] frame depth max (float bits)
+    DeviceArray<unsigned char> integrate_ws_;  // brick work list of the integrate kernel
     unsigned long long *pinned_counters_ = nullptr;
     hipEvent_t ev_[ST_COUNT + 1][2];
     bool ev_used_[ST_COUNT];

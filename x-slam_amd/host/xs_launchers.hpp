@@ -57,7 +57,13 @@ struct Scratch {
     DeviceArray<unsigned char> icp_ws, reduce_ws;
     DeviceArray<double> sums;
     static Scratch &get() { static Scratch s; return s; }
-    void *icp() { if (icp_ws.size() != xs_icp_workspace_bytes()) icp_ws.create(xs_icp_workspace_bytes()); return icp_ws.ptr(); }
+    void *icp() {
+        if (icp_ws.size() != xs_icp_workspace_bytes()) {
+            icp_ws.create(xs_icp_workspace_bytes());
+            check_rc(xs_icp_workspace_init(icp_ws.ptr(), current_stream()), "icp workspace");
+        }
+        return icp_ws.ptr();
+    }
     void *reduce() { if (reduce_ws.size() != xs_tsdf_reduce_workspace_bytes()) reduce_ws.create(xs_tsdf_reduce_workspace_bytes()); return reduce_ws.ptr(); }
     double *sum_buf() { if (sums.size() != 64) sums.create(64); return sums.ptr(); }
 };
