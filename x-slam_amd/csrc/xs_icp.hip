@@ -102,16 +102,30 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
             }
         cnt += 1.0;
     }
-    // wave fold, then one LDS exchange across the 4 waves
+    // Fold the 256 lanes of the workgroup: every lane parks its 55 values (54 sums + count) in an
+    // LDS tile [wave][value][lane] (rows padded to 65 doubles: conflict-free both ways), then four
+    // threads per value each add one wave's 64 entries in lane order and the four results are
+    // added in wave order — fixed association, no cross-lane shuffles (55 dependent 6-step
+    // ds_bpermute chains cost ~20 us here).  Two passes of 28 values keep the tile at 58 KB.
+    __shared__ double tile[4][28][65];
     __shared__ double smem[4][NP];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const double v = wave_sum_f64(acc[k]);
-        if (lane == 0) smem[wave][k] = v;
-    }
-    {
-        const double v = wave_sum_f64(cnt);
-        if (lane == 0) smem[wave][NS] = v;
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 28; ++kk) {
+            const int k = half * 28 + kk;
+            if (k < NS) tile[wave][kk][lane] = acc[k];
+            else if (k == NS) tile[wave][kk][lane] = cnt;
+        }
+        __syncthreads();
+        const int kk = threadIdx.x >> 2, q = threadIdx.x & 3;
+        if (kk < 28 && half * 28 + kk <= NS) {
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) sacc += tile[q][kk][i];
+            smem[q][half * 28 + kk] = sacc;
+        }
     }
     __syncthreads();
     if (threadIdx.x < NS + 1) {

@@ -16,6 +16,7 @@
 // (u*fx vs c*(bound)), before the two IEEE divides; anything within a pixel of the border
 // takes the exact path.  Only voxels that pass the reference's predicate touch memory.
 #include "xs_device.h"
+#include <algorithm>
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
@@ -101,7 +102,21 @@ extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows
 // volume access of a wave is one 256-byte row segment.
 enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
 
+// Half-spaces of the (padded) view frustum in the volume's voxel-index space, built on the
+// host and passed as kernel arguments (wave-uniform: they live in scalar registers).  Along any
+// direction the camera-frame position is affine in the voxel index (real parts), so each side
+// of the image window, the camera plane and the far limit is
+//     alpha + bx*i + by*j + bz*k >= -slack,   (i, j, k) = voxel index + 0.5.
+// The window is the reference's in-image test (TsdfFusion.cu:123-124) padded by three pixels,
+// the slack is 2e-3 of the term magnitudes: voxels outside provably fail the exact tests;
+// voxels inside still take them.  Plane 5 is the far limit c <= cfar; cfar comes from the
+// frame's largest depth on the device (alpha[5] holds everything but cfar).
+struct Frustum {
+    float alpha[6], bx[6], by[6], bz[6], slack[6];
+};
+
 struct IntegrateArgs {
+    Frustum fr;
     const float *depth; size_t dstep; int drows, dcols;
     float *value; int *weight; float *grad; size_t vstep;
     int X, Y, Z;        // full resolution
@@ -117,55 +132,15 @@ struct IntegrateArgs {
 };
 
 namespace {
-// Half-spaces of the (padded) view frustum in the volume's voxel-index space.  Along any
-// direction the camera-frame position is affine in the voxel index (real parts), so each side
-// of the image window, the camera plane and the far limit is alpha + bx*i + by*j + bz*k >= -slack
-// with (i, j, k) = voxel index + 0.5.  The window is the reference's in-image test
-// (TsdfFusion.cu:123-124) padded by three pixels, the slack is 2e-3 of the term magnitudes:
-// voxels outside provably fail the exact tests; voxels inside still take them.
-struct Frustum {
-    float alpha[6], bx[6], by[6], bz[6], slack[6];
-    int n;
-};
-__device__ __forceinline__ Frustum make_frustum(const IntegrateArgs &a) {
-    Frustum f;
-    const float vs = a.voxel_size, fx = a.intr.fx, fy = a.intr.fy;
-    const float ul = (1.5f - a.intr.cx) - 2.f, uh = ((a.dcols - 0.5f) - a.intr.cx + 1.0f) + 2.f;
-    const float vl = (1.5f - a.intr.cy) - 2.f, vh = ((a.drows - 0.5f) - a.intr.cy + 1.0f) + 2.f;
-    // camera coordinates (real parts): p_r = t_r + vs * (R_r0*i + R_r1*j + R_r2*k)
-    float T[3], M[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        T[r] = (r == 0 ? a.t.x.re : r == 1 ? a.t.y.re : a.t.z.re);
-        M[r][0] = a.R.data[r].x.re * vs; M[r][1] = a.R.data[r].y.re * vs; M[r][2] = a.R.data[r].z.re * vs;
-    }
-    const float ext = (float)max(a.X, max(a.Y, a.Z));
-    float mag[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) mag[r] = fabsf(T[r]) + (fabsf(M[r][0]) + fabsf(M[r][1]) + fabsf(M[r][2])) * ext;
-    const float rel = 2e-3f;
-    int n = 0;
-    auto plane = [&](float cxk, float cyk, float czk, float c0, float sl) {  // cxk*px' + cyk*py' + czk*c + c0 >= 0
-        f.alpha[n] = cxk * T[0] + cyk * T[1] + czk * T[2] + c0;
-        f.bx[n] = cxk * M[0][0] + cyk * M[1][0] + czk * M[2][0];
-        f.by[n] = cxk * M[0][1] + cyk * M[1][1] + czk * M[2][1];
-        f.bz[n] = cxk * M[0][2] + cyk * M[1][2] + czk * M[2][2];
-        f.slack[n] = sl;
-        ++n;
-    };
-    plane(0.f, 0.f, 1.f, 0.f, rel * mag[2]);                                        // c >= 0
-    plane(fx, 0.f, -ul, 0.f, rel * (fabsf(fx) * mag[0] + fabsf(ul) * mag[2]));      // fx*X >= ul*c
-    plane(-fx, 0.f, uh, 0.f, rel * (fabsf(fx) * mag[0] + fabsf(uh) * mag[2]));      // fx*X <= uh*c
-    plane(0.f, fy, -vl, 0.f, rel * (fabsf(fy) * mag[1] + fabsf(vl) * mag[2]));      // fy*Y >= vl*c
-    plane(0.f, -fy, vh, 0.f, rel * (fabsf(fy) * mag[1] + fabsf(vh) * mag[2]));      // fy*Y <= vh*c
-    if (a.depth_max) {
-        // behind the farthest surface by more than the truncation band nothing is written:
-        // v_c_1 = Dp*(xl, yl, 1) lies on the voxel's own ray, so sdf = (Dp - c) * |v_c|/c with
-        // |v_c|/c >= 1 and Dp <= Dmax; c > Dmax + trunc therefore gives sdf < -trunc
-        const float cfar = *a.depth_max * 1.0001f + 1.05f * a.tranc_dist;
-        plane(0.f, 0.f, -1.f, cfar, rel * mag[2]);                                  // c <= cfar
-    }
-    f.n = n;
+// device side of the frustum: add the far limit (see struct Frustum).  Behind the farthest
+// surface by more than the truncation band nothing is written: v_c_1 = Dp*(xl, yl, 1) lies on
+// the voxel's own ray, so sdf = (Dp - c) * |v_c|/c with |v_c|/c >= 1 and Dp <= Dmax; c > Dmax +
+// trunc therefore gives sdf < -trunc.  Without a frame maximum the valid-depth gate of
+// scaleDepth (5 m, TsdfFusion.cu:77) bounds Dp.
+__device__ __forceinline__ Frustum device_frustum(const IntegrateArgs &a) {
+    Frustum f = a.fr;
+    const float dmax = a.depth_max ? *a.depth_max : 5.0f;
+    f.alpha[5] += dmax * 1.0001f + 1.05f * a.tranc_dist;
     return f;
 }
 // Intersect {k : alpha + beta*k >= -slack} with [lo, hi]
@@ -182,7 +157,8 @@ __device__ __forceinline__ void clip_halfspace(float alpha, float beta, float sl
 __device__ __forceinline__ void clip_column(const Frustum &f, int x, int y, int &zb, int &ze) {
     float lo = (float)zb, hi = (float)ze;
     const float i = x + 0.5f, j = y + 0.5f;
-    for (int p = 0; p < f.n; ++p) clip_halfspace(f.alpha[p] + f.bx[p] * i + f.by[p] * j, f.bz[p], f.slack[p], lo, hi);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) clip_halfspace(f.alpha[p] + f.bx[p] * i + f.by[p] * j, f.bz[p], f.slack[p], lo, hi);
     zb = max(zb, (int)floorf(lo - 0.5f) - 2);
     ze = min(ze, (int)ceilf(hi - 0.5f) + 3);
 }
@@ -190,7 +166,8 @@ __device__ __forceinline__ void clip_column(const Frustum &f, int x, int y, int 
 // half-space => no)
 __device__ __forceinline__ bool box_may_pass(const Frustum &f, int x0, int x1, int y0, int y1, int z0, int z1) {
     const float xa = x0 + 0.5f, xb = x1 - 0.5f, ya = y0 + 0.5f, yb = y1 - 0.5f, za = z0 + 0.5f, zb = z1 - 0.5f;
-    for (int p = 0; p < f.n; ++p) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
         // maximum of the affine form over the box: pick the favourable end per axis
         const float m = f.alpha[p] + (f.bx[p] > 0 ? f.bx[p] * xb : f.bx[p] * xa) + (f.by[p] > 0 ? f.by[p] * yb : f.by[p] * ya) +
                         (f.bz[p] > 0 ? f.bz[p] * zb : f.bz[p] * za);
@@ -285,7 +262,7 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
     if (x < a.X && y < a.Y) {
         int zb = a.z0 + blockIdx.z * a.zchunk;
         int ze = min(zb + a.zchunk, a.z1);
-        const Frustum f = make_frustum(a);
+        const Frustum f = device_frustum(a);
         clip_column(f, x, y, zb, ze);
         if (zb < ze) n_upd = integrate_span<BILINEAR>(a, x, y, zb, ze);
     }
@@ -308,7 +285,7 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     if (b < nb) {
         const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
         const int x0 = bx * BRICK_X, y0 = by * BRICK_Y, z0 = a.z0 + bz * BRICK_Z;
-        const Frustum f = make_frustum(a);
+        const Frustum f = device_frustum(a);
         active = box_may_pass(f, x0, min(x0 + BRICK_X, a.X), y0, min(y0 + BRICK_Y, a.Y), z0, min(z0 + BRICK_Z, a.z1));
     }
     const unsigned long long m = __ballot(active);
@@ -323,7 +300,7 @@ template <bool BILINEAR>
 __global__ void __launch_bounds__(256) k_integrate_bricks(const IntegrateArgs a) {
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
-    const Frustum f = make_frustum(a);
+    const Frustum f = device_frustum(a);
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
         const int b = a.brick_list[e];
         const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
@@ -348,6 +325,37 @@ static void load_mat(const float *p, MatS33 &m) {
     }
 }
 static void load_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
+
+
+static void set_plane(Frustum &f, int P, const float T[3], const float M[3][3], float cxk, float cyk, float czk, float sl) {
+    f.alpha[P] = cxk * T[0] + cyk * T[1] + czk * T[2];  // cxk*X + cyk*Y + czk*c >= -sl
+    f.bx[P] = cxk * M[0][0] + cyk * M[1][0] + czk * M[2][0];
+    f.by[P] = cxk * M[0][1] + cyk * M[1][1] + czk * M[2][1];
+    f.bz[P] = cxk * M[0][2] + cyk * M[1][2] + czk * M[2][2];
+    f.slack[P] = sl;
+}
+static void host_frustum(IntegrateArgs &a) {
+    Frustum &f = a.fr;
+    const float vs = a.voxel_size, fx = a.intr.fx, fy = a.intr.fy;
+    const float ul = (1.5f - a.intr.cx) - 2.f, uh = ((a.dcols - 0.5f) - a.intr.cx + 1.0f) + 2.f;
+    const float vl = (1.5f - a.intr.cy) - 2.f, vh = ((a.drows - 0.5f) - a.intr.cy + 1.0f) + 2.f;
+    // camera coordinates (real parts): p_r = t_r + vs * (R_r0*i + R_r1*j + R_r2*k)
+    const float T[3] = {a.t.x.re, a.t.y.re, a.t.z.re};
+    const float M[3][3] = {{a.R.data[0].x.re * vs, a.R.data[0].y.re * vs, a.R.data[0].z.re * vs},
+                           {a.R.data[1].x.re * vs, a.R.data[1].y.re * vs, a.R.data[1].z.re * vs},
+                           {a.R.data[2].x.re * vs, a.R.data[2].y.re * vs, a.R.data[2].z.re * vs}};
+    const float ext = (float)std::max(a.X, std::max(a.Y, a.Z));
+    const float mag0 = fabsf(T[0]) + (fabsf(M[0][0]) + fabsf(M[0][1]) + fabsf(M[0][2])) * ext;
+    const float mag1 = fabsf(T[1]) + (fabsf(M[1][0]) + fabsf(M[1][1]) + fabsf(M[1][2])) * ext;
+    const float mag2 = fabsf(T[2]) + (fabsf(M[2][0]) + fabsf(M[2][1]) + fabsf(M[2][2])) * ext;
+    const float rel = 2e-3f;
+    set_plane(f, 0, T, M, 0.f, 0.f, 1.f, rel * mag2);                                      // c >= 0
+    set_plane(f, 1, T, M, fx, 0.f, -ul, rel * (fabsf(fx) * mag0 + fabsf(ul) * mag2));      // fx*X >= ul*c
+    set_plane(f, 2, T, M, -fx, 0.f, uh, rel * (fabsf(fx) * mag0 + fabsf(uh) * mag2));      // fx*X <= uh*c
+    set_plane(f, 3, T, M, 0.f, fy, -vl, rel * (fabsf(fy) * mag1 + fabsf(vl) * mag2));      // fy*Y >= vl*c
+    set_plane(f, 4, T, M, 0.f, -fy, vh, rel * (fabsf(fy) * mag1 + fabsf(vh) * mag2));      // fy*Y <= vh*c
+    set_plane(f, 5, T, M, 0.f, 0.f, -1.f, rel * mag2);                                     // c <= cfar (cfar added on the device)
+}
 
 /* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
@@ -374,6 +382,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev; a.depth_max = depth_max_dev;
     a.brick_list = nullptr; a.brick_count = nullptr;
+    host_frustum(a);
     const int nz = z1 - z0;
     a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, BRICK_Z);
     a.zchunk = nz;
