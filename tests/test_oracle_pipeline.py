@@ -1,0 +1,103 @@
+"""CPU-only: the oracle's kernel / pipeline restatement against the committed fixtures
+(generated with the reference's own complex class, oracle/_ref) and against the counts the
+survey recorded from the reference kernel bodies."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from helpers import intr_of, s1_transforms, synth, tranc_dist
+
+
+def test_oracle_pipeline_matches_ref_fixture_n64(oracle):
+    """oc::cplx<float> (restatement) vs ::complex<float> (reference header) through the whole
+    pipeline: same libm, no contraction on either side -> identical."""
+    from oracle.oracle import OracleKinFu, params_from_dict
+    g = load_golden("pipeline_s1_n64.npz")
+    kf = OracleKinFu(oracle, params_from_dict(synth.s1_params(64)))
+    vox = g["voxel_index"]
+    for k in range(2):
+        d = synth.s1_frame(k)
+        assert int(d.astype(np.uint64).sum()) == int(g["depth_checksums"][k])
+        assert kf.process_frame(d) == 1
+        assert np.array_equal(kf.world2camera(), g[f"w2c_{k}"])
+        v, w, gr = kf.volume()
+        assert np.array_equal(v[vox], g[f"value_{k}"]) and np.array_equal(w[vox], g[f"weight_{k}"])
+        assert np.array_equal(gr[vox], g[f"grad_{k}"])
+        assert kf.last_U() == g[f"sums_{k}"][4] and kf.last_hits() == g[f"sums_{k}"][5]
+    assert np.array_equal(kf.icp_log(), g["icp_1"])
+    kf.close()
+
+
+def test_survey_recorded_reference_counts_256(oracle):
+    """the reference's tsdfFusionKernal / rayCastKernel bodies on scene S1 frame 0."""
+    fig = json.load(open(os.path.join(GOLDEN, "survey_reference_kernel_figures.json")))
+    n = 256
+    prm = synth.s1_params(n, seed=None)
+    res = [n, n, n]
+    T = s1_transforms(0, prm, seed=None)
+    v, w, g = oracle.new_volume(res)
+    U = oracle.integrate(oracle.scale_depth(synth.s1_frame(0)), v, w, g, res, tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm),
+                         prm["tsdf_voxel_size"])
+    assert abs(U - fig["integrate_U"]["256"]) <= 1e-4 * U
+    _, _, hits = oracle.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], v, g,
+                                synth.HEIGHT, synth.WIDTH)
+    assert abs(hits - fig["raycast_hits"]["256"]) <= 2
+
+
+def test_oracle_hessian_fixture(oracle):
+    gd = load_golden("hessian_s1_n64.npz")
+    n = 64
+    prm = synth.s1_params(n)
+    from oracle.oracle import OracleKinFu, params_from_dict
+    kf = OracleKinFu(oracle, params_from_dict(prm))
+    assert kf.process_frame(synth.s1_frame(0)) == 1
+    gt, _, _ = kf.volume()
+    for tag, k in (("a", 1), ("b", 4)):
+        ds = oracle.scale_depth(synth.s1_frame(k))
+        out = oracle.tsdf_hessian(ds, [n, n, n], prm["tsdf_voxel_size"], gd[f"R_{tag}"], gd[f"t_{tag}"], float(gd["trunc"]), intr_of(prm), gt)
+        assert np.allclose(out, gd[f"hess_{tag}"], rtol=1e-11, atol=0)  # OpenMP sums the per-thread doubles in any order
+        # derivative sanity: d(loss)/dt_x by CSFD agrees with a real central difference of the loss kernel
+        R9, t3 = gd[f"R_{tag}"][..., 0].reshape(9).copy(), gd[f"t_{tag}"][..., 0].reshape(3).copy()
+        eps = 2e-3
+        lp = oracle.tsdf_loss(ds, [n, n, n], prm["tsdf_voxel_size"], R9, t3 + np.array([eps, 0, 0], np.float32), float(gd["trunc"]), intr_of(prm), gt)[0]
+        lm = oracle.tsdf_loss(ds, [n, n, n], prm["tsdf_voxel_size"], R9, t3 - np.array([eps, 0, 0], np.float32), float(gd["trunc"]), intr_of(prm), gt)[0]
+        fd = (lp - lm) / (2 * eps)
+        csfd = out[1] / 1e-6
+        assert abs(csfd - fd) <= 0.15 * abs(fd) + 5.0  # the loss is piecewise (voxel set changes with the pose)
+    kf.close()
+
+
+def test_host_algebra_restatement(oracle):
+    rng = np.random.default_rng(5)
+    m = np.eye(4)[..., None] * np.array([1.0, 0.0]) + rng.normal(size=(4, 4, 2)) * np.array([0.2, 1e-7])
+    m = m.astype(np.float32)
+    inv = oracle.m4_inverse(m)
+    prod = oracle.m4_mul(m, inv)
+    eye = np.zeros((4, 4, 2), np.float32)
+    eye[[0, 1, 2, 3], [0, 1, 2, 3], 0] = 1
+    assert np.allclose(prod, eye, atol=2e-6)
+    mc = m[..., 0].astype(np.complex128) + 1j * m[..., 1]
+    ref = np.linalg.inv(mc)
+    assert np.allclose(inv[..., 0], ref.real, atol=3e-6) and np.allclose(inv[..., 1], ref.imag, atol=3e-6 * 1e-6 + 1e-12)
+    # 6x6: real SPD + small imaginary symmetric part; Hermitian LLT semantics
+    B = rng.normal(size=(6, 6))
+    Ar = B @ B.T + 6 * np.eye(6)
+    Ai = rng.normal(size=(6, 6)) * 1e-6
+    Ai = Ai + Ai.T
+    A = np.stack([Ar, Ai], -1)
+    b = np.stack([rng.normal(size=6), rng.normal(size=6) * 1e-6], -1)
+    x = oracle.llt_solve6(A, b)
+    assert abs(oracle.det6_real(A) - np.linalg.det(Ar)) <= 1e-9 * abs(np.linalg.det(Ar))
+    # Eigen's LLT reads the lower triangle as Hermitian: A_h = lower + conj(lower)^T, real diagonal
+    Ac = Ar + 1j * Ai
+    L = np.tril(Ac)
+    Ah = L + np.conj(np.tril(Ac, -1)).T
+    Ah[np.diag_indices(6)] = np.diag(Ar)
+    want = np.linalg.solve(Ah, b[:, 0] + 1j * b[:, 1])
+    assert np.allclose(x[:, 0], want.real, rtol=1e-10) and np.allclose(x[:, 1], want.imag, rtol=1e-6, atol=1e-14)
+    # Rinc at small complex angles ~ I + [w]x
+    r = oracle.rinc([1e-3, 1e-9], [2e-3, 0], [-1e-3, 0])
+    assert abs(r[0, 1, 0] - 1e-3) < 1e-5 and abs(r[2, 1, 0] - 1e-3) < 1e-5 and abs(r[2, 1, 1] - 1e-9) < 1e-11
