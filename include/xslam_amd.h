@@ -115,6 +115,22 @@ int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, cons
                float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, void *stream);
 
+/* Slab form for a z-sharded volume (the reference is single-GPU; per-ray semantics are those of
+ * RayCaster.cu:197-310).  value / grad hold planes [zs0, zs1) = owned slab + halo (6 planes);
+ * only march steps whose sample voxel lies in the owned planes [z0, z1) are evaluated.
+ * keys_dev[rows*cols]: per pixel (step << 1 | no_vertex) of the first event among those steps, or
+ * INT_MAX.  vmap / nmap: this rank's vertex / normal for its own event, zeros elsewhere.
+ * Protocol: keys -> all-reduce(min) -> xs_raycast_compose_mask -> all-reduce(sum) of the maps as
+ * int32 -> xs_raycast_compose_finish. */
+int xs_raycast_slab(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                    float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+                    int zs0, int zs1, int z0, int z1, float *vmap, float *nmap, size_t map_step, int rows, int cols, int *keys_dev,
+                    void *stream);
+int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows,
+                            int cols, void *stream);
+int xs_raycast_compose_finish(const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows, int cols,
+                              unsigned long long *hits_dev, void *stream);
+
 /* ---- ICP normal equations ----------------------------------------------------------------- */
 size_t xs_icp_workspace_bytes(void);
 /* zero the workspace's arrival ticket once after allocation; every launch leaves it zero */

@@ -20,6 +20,16 @@ void xs_kf_set_stream(void *stream);
 /* KinectFusionReconstruction() + SetYamlParameters(config)     KinectFusionReconstruction.cpp:4-73
  * returns NULL (and prints) on a missing key */
 void *xs_kf_create(const char *yaml_text);
+/* Sharded instance (the reference is single-GPU): rank r of count owns the z planes
+ * [r*Z/count, (r+1)*Z/count) (+ 6 halo planes each side) and the pixel rows [r*H/count, ...) of
+ * every ICP level.  collective(user, op, dev_ptr, count) must all-reduce dev_ptr in place over
+ * the ranks, ordered on the current stream: op 0 = sum of doubles (the 27 complex<double>
+ * normal-equation sums + inlier count), 1 = min of int32 (first raycast event per pixel),
+ * 2 = sum of int32 (vertex / normal maps as bit patterns).  xs_kf_download_volume then returns
+ * the stored planes only (xs_kf_shard_planes). */
+void *xs_kf_create_sharded(const char *yaml_text, int rank, int count, void (*collective)(void *user, int op, void *dev_ptr, long n),
+                           void *user);
+void xs_kf_shard_planes(void *kf, int *owned2, int *stored2);
 void xs_kf_destroy(void *kf);
 /* gt_poses (camera-to-world) for flag_use_gtPose: n matrices of 32 floats   .h:36, .cpp:239-247 */
 void xs_kf_set_gt_poses(void *kf, int n, const float *c2w32);

@@ -216,6 +216,14 @@ long long ORC(raycast)(const float *intr4, const float *Rc2v18, const float *tc2
                        voxel_size, value, grad, vstep, vmap, nmap, mstep, rows, cols);
 }
 
+long long ORC(raycast_slab)(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                            float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vstep, int zs0,
+                            int zs1, int z0, int z1, float *vmap, float *nmap, size_t mstep, int rows, int cols, int *keys) {
+    Intr k{intr4[0], intr4[1], intr4[2], intr4[3]};
+    return raycast_slab<CF>(k, load_mat33<CF>(Rc2v18), load_vec3<CF>(tc2v6), load_mat33<CF>(Rv2w18), load_vec3<CF>(tv2w6), tranc_dist, res,
+                            voxel_size, value, grad, vstep, zs0, zs1, z0, z1, vmap, nmap, mstep, rows, cols, keys);
+}
+
 void ORC(bilateral)(const uint16_t *src, size_t sstep, int rows, int cols, float *dst, size_t dstep) { bilateral<CF>(src, sstep, rows, cols, dst, dstep); }
 void ORC(pyr_down)(const float *src, size_t sstep, int srows, int scols, float *dst, size_t dstep) { pyr_down<CF>(src, sstep, srows, scols, dst, dstep); }
 void ORC(create_vmap)(const float *intr4, const float *depth, size_t dstep, int rows, int cols, float *vmap, size_t mstep) {

@@ -290,6 +290,117 @@ struct RayCasterO {
     }
 };
 
+// Slab form used by the multi-GPU protocol tests (no reference counterpart): the same march,
+// but only the steps whose sample voxel lies in the owned planes [z0, z1) are evaluated, and
+// every volume read asserts that it stays inside the stored planes [zs0, zs1).  Writes the
+// rank's first event key (step << 1 | no_vertex, INT_MAX if none) and its vertex / normal
+// (zeros unless it produced them).  Returns the number of reads outside the stored planes.
+template <class C>
+struct RaySlabO : RayCasterO<C> {
+    typedef RayCasterO<C> B;
+    int zs0, zs1, z0, z1;
+    mutable long long violations = 0;
+    float rv(int x, int y, int z) const {
+        if (z < zs0 || z >= zs1) { ++violations; return 0.f; }
+        return row_ptr(B::value, B::vstep, B::res[1] * z + y)[x] + 1e-5f;
+    }
+    C rc(int x, int y, int z) const {
+        x = x % B::res[0]; y = y % B::res[1]; z = z % B::res[2];
+        if (z < zs0 || z >= zs1) { ++violations; return C(0.f, 0.f); }
+        C r(row_ptr(B::value, B::vstep, B::res[1] * z + y)[x], row_ptr(B::grad, B::vstep, B::res[1] * z + y)[x]);
+        r += 1e-5f;
+        return r;
+    }
+    C interp(const vec3<C> &point) const {
+        int g[3];
+        B::getVoxel(point.x.real(), point.y.real(), point.z.real(), g);
+        float qnan = qnan_f();
+        if (g[0] <= 0 || g[0] >= B::res[0] - 1) return C(qnan, 0);
+        if (g[1] <= 0 || g[1] >= B::res[1] - 1) return C(qnan, 0);
+        if (g[2] <= 0 || g[2] >= B::res[2] - 1) return C(qnan, 0);
+        float vs = B::voxel_size;
+        float vx = (g[0] + 0.5f) * vs, vy = (g[1] + 0.5f) * vs, vz = (g[2] + 0.5f) * vs;
+        g[0] += -(B::sgn(vx - point.x.real()) + 1) >> 1;
+        g[1] += -(B::sgn(vy - point.y.real()) + 1) >> 1;
+        g[2] += -(B::sgn(vz - point.z.real()) + 1) >> 1;
+        C a0 = (point.x - (g[0] + 0.5f) * vs) / vs, b0 = (point.y - (g[1] + 0.5f) * vs) / vs, c0 = (point.z - (g[2] + 0.5f) * vs) / vs;
+        C one(1.0f, 0.0f);
+        C a1 = one - a0, b1 = one - b0, c1 = one - c0;
+        return rc(g[0] + 0, g[1] + 0, g[2] + 0) * a1 * b1 * c1 + rc(g[0] + 0, g[1] + 0, g[2] + 1) * a1 * b1 * c0 +
+               rc(g[0] + 0, g[1] + 1, g[2] + 0) * a1 * b0 * c1 + rc(g[0] + 0, g[1] + 1, g[2] + 1) * a1 * b0 * c0 +
+               rc(g[0] + 1, g[1] + 0, g[2] + 0) * a0 * b1 * c1 + rc(g[0] + 1, g[1] + 0, g[2] + 1) * a0 * b1 * c0 +
+               rc(g[0] + 1, g[1] + 1, g[2] + 0) * a0 * b0 * c1 + rc(g[0] + 1, g[1] + 1, g[2] + 1) * a0 * b0 * c0;
+    }
+    int pixel_slab(int x, int y) const {
+        const int rows = B::rows;
+        for (int p = 0; p < 3; ++p) { *B::map_at(B::vmap, y + p * rows, x) = C(0.f, 0.f); *B::map_at(B::nmap, y + p * rows, x) = C(0.f, 0.f); }
+        vec3<C> ray_start = B::tc2v, rn;
+        rn.x = (x - B::intr.cx) / B::intr.fx; rn.y = (y - B::intr.cy) / B::intr.fy; rn.z = 1;
+        vec3<C> ray_dir = normalized3(B::Rc2v * rn + B::tc2v - ray_start);
+        ray_dir.x = (ray_dir.x == 0.f) ? C(1e-15f) : ray_dir.x;
+        ray_dir.y = (ray_dir.y == 0.f) ? C(1e-15f) : ray_dir.y;
+        ray_dir.z = (ray_dir.z == 0.f) ? C(1e-15f) : ray_dir.z;
+        float time_curr = 0.2f;
+        const float max_time = 5.0f, time_step = B::time_step;
+        int g[3], q[3];
+        { vec3<C> p = ray_start + ray_dir * time_curr; B::getVoxel(p.x.real(), p.y.real(), p.z.real(), q); }
+        for (int i = 0; i < 3; ++i) q[i] = std::max(0, std::min(q[i], B::res[i] - 1));
+        int step = 0;
+        for (; time_curr < max_time; time_curr += time_step, ++step) {
+            vec3<C> cp = ray_start + ray_dir * (time_curr + time_step);
+            B::getVoxel(cp.x.real(), cp.y.real(), cp.z.real(), g);
+            if (!B::checkInds(g)) break;
+            int pq[3] = {q[0], q[1], q[2]};
+            q[0] = g[0]; q[1] = g[1]; q[2] = g[2];
+            if (!(g[2] >= z0 && g[2] < z1)) continue;
+            float tsdf_prev = rv(pq[0], pq[1], pq[2]);
+            float tsdf = rv(g[0], g[1], g[2]);
+            if (tsdf_prev < 0.f && tsdf > 0.f) return (step << 1) | 1;
+            if (tsdf_prev > 0.f && tsdf < 0.f) {
+                C Ftdt = interp(ray_start + ray_dir * (time_curr + time_step));
+                if (std::isnan(Ftdt.real())) return (step << 1) | 1;
+                C Ft = interp(ray_start + ray_dir * time_curr);
+                if (std::isnan(Ft.real())) return (step << 1) | 1;
+                C coef = Ft / (Ftdt - Ft);
+                if (Ft.real() < 0.0f || Ftdt.real() > 0.0f) return (step << 1) | 1;
+                C Ts = time_curr - time_step * coef;
+                vec3<C> vf = ray_start + ray_dir * Ts;
+                vec3<C> vw = B::Rv2w * vf + B::tv2w;
+                *B::map_at(B::vmap, y, x) = vw.x; *B::map_at(B::vmap, y + rows, x) = vw.y; *B::map_at(B::vmap, y + 2 * rows, x) = vw.z;
+                *B::map_at(B::nmap, y, x) = C(qnan_f(), 0);
+                B::getVoxel(vf.x.real(), vf.y.real(), vf.z.real(), g);
+                if (g[0] > 1 && g[1] > 1 && g[2] > 1 && g[0] < B::res[0] - 2 && g[1] < B::res[1] - 2 && g[2] < B::res[2] - 2) {
+                    vec3<C> t, n;
+                    float h = B::voxel_size * 0.5f;
+                    t = vf; t.x += h; C Fx1 = interp(t); t = vf; t.x -= h; C Fx2 = interp(t); n.x = Fx1 - Fx2;
+                    t = vf; t.y += h; C Fy1 = interp(t); t = vf; t.y -= h; C Fy2 = interp(t); n.y = Fy1 - Fy2;
+                    t = vf; t.z += h; C Fz1 = interp(t); t = vf; t.z -= h; C Fz2 = interp(t); n.z = Fz1 - Fz2;
+                    if (squarednorm3(n).real() == 0) return step << 1;
+                    vec3<C> ng = B::Rv2w * normalized3(n);
+                    *B::map_at(B::nmap, y, x) = ng.x; *B::map_at(B::nmap, y + rows, x) = ng.y; *B::map_at(B::nmap, y + 2 * rows, x) = ng.z;
+                }
+                return step << 1;
+            }
+        }
+        return 0x7fffffff;
+    }
+};
+
+template <class C>
+long long raycast_slab(Intr intr, const mat33<C> &Rc2v, const vec3<C> &tc2v, const mat33<C> &Rv2w, const vec3<C> &tv2w, float tranc_dist,
+                       const int res[3], float voxel_size, const float *value, const float *grad, size_t vstep, int zs0, int zs1, int z0,
+                       int z1, float *vmap, float *nmap, size_t mstep, int rows, int cols, int *keys) {
+    RaySlabO<C> rc;
+    rc.Rc2v = Rc2v; rc.tc2v = tc2v; rc.Rv2w = Rv2w; rc.tv2w = tv2w;
+    rc.res[0] = res[0]; rc.res[1] = res[1]; rc.res[2] = res[2];
+    rc.voxel_size = voxel_size; rc.time_step = tranc_dist * 0.8f; rc.cols = cols; rc.rows = rows;
+    rc.intr = intr; rc.value = value; rc.grad = grad; rc.vstep = vstep; rc.vmap = vmap; rc.nmap = nmap; rc.mstep = mstep;
+    rc.zs0 = zs0; rc.zs1 = zs1; rc.z0 = z0; rc.z1 = z1;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) keys[y * cols + x] = rc.pixel_slab(x, y);
+    return rc.violations;
+}
+
 template <class C>
 long long raycast(Intr intr, const mat33<C> &Rc2v, const vec3<C> &tc2v, const mat33<C> &Rv2w, const vec3<C> &tv2w,
                   float tranc_dist, const int res[3], float voxel_size, const float *value, const float *grad,

@@ -73,6 +73,8 @@ class Oracle:
                                               C.c_float, C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int])
         self._fn("raycast", C.c_longlong, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _f32p, _f32p,
                                             C.c_size_t, _f32p, _f32p, C.c_size_t, C.c_int, C.c_int])
+        self._fn("raycast_slab", C.c_longlong, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _f32p, _f32p, C.c_size_t,
+                                                 C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _i32p])
         self._fn("bilateral", None, [_u16p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t])
         self._fn("pyr_down", None, [_f32p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t])
         self._fn("create_vmap", None, [_f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t])
@@ -198,6 +200,20 @@ class Oracle:
                              _p(r, _i32p), voxel_size, _p(value, _f32p), _p(grad, _f32p), int(r[0]) * 4, _p(vmap, _f32p),
                              _p(nmap, _f32p), cols * 8, rows, cols)
         return vmap, nmap, hits
+
+    def raycast_slab(self, intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, rows, cols, stored, owned):
+        """value / grad are full-size arrays of which only planes stored[0]..stored[1] may be read.
+        Returns (vmap, nmap, keys, reads_outside_the_stored_planes)."""
+        r = self._res(res)
+        k = np.ascontiguousarray(intr, dtype=np.float32)
+        a = [np.ascontiguousarray(x, dtype=np.float32).reshape(-1) for x in (Rc2v, tc2v, Rv2w, tv2w)]
+        vmap = np.zeros((3 * rows, cols, 2), np.float32)
+        nmap = np.zeros((3 * rows, cols, 2), np.float32)
+        keys = np.zeros(rows * cols, np.int32)
+        bad = self._raycast_slab(_p(k, _f32p), _p(a[0], _f32p), _p(a[1], _f32p), _p(a[2], _f32p), _p(a[3], _f32p), tranc_dist,
+                                 _p(r, _i32p), voxel_size, _p(value, _f32p), _p(grad, _f32p), int(r[0]) * 4, stored[0], stored[1],
+                                 owned[0], owned[1], _p(vmap, _f32p), _p(nmap, _f32p), cols * 8, rows, cols, _p(keys, _i32p))
+        return vmap, nmap, keys, bad
 
     def bilateral(self, depth_u16):
         d = np.ascontiguousarray(depth_u16, dtype=np.uint16)

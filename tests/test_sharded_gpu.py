@@ -1,0 +1,114 @@
+"""GPU: the sharded C++ pipeline (z-slab volume + ICP row shards + raycast composite) against the
+single-GPU pipeline, with all ranks inside one process (one thread per rank, shared GPU and
+stream; collectives meet at a barrier — x-slam_amd/sharded.py LocalWorld).  Integrate, the
+raycast composite and the maps must be bit-identical to the unsharded run; the ICP sums differ
+only in the association of double additions."""
+import importlib
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch, importlib.import_module("x-slam_amd.pipeline"), importlib.import_module("x-slam_amd.sharded")
+
+
+def run_world(torch, sh, prm, world, frames):
+    lw = sh.LocalWorld(torch, world)
+    shards = [sh.ShardedKinectFusion(prm, r, world, collective=lw.collective_for(r)) for r in range(world)]
+    depth = [torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda() for k in frames]
+    results = [None] * world
+    errors = []
+
+    def work(r):
+        try:
+            for d in depth:
+                assert shards[r].process_frame(d) == 1
+            results[r] = (shards[r].world2camera(), shards[r].last_U(), shards[r].last_hits(), shards[r].icp_log())
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    return shards, results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single(dev, world):
+    torch, pl, sh = dev
+    n = 96
+    prm = synth.s1_params(n)
+    frames = [0, 1, 2]
+    single = pl.KinectFusion(prm)
+    for k in frames:
+        assert single.process_frame(torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()) == 1
+    sv, sw, sg = single.volume()
+    shards, results = run_world(torch, sh, prm, world, frames)
+    # every rank ends with the same pose; equal to the single-GPU pose up to the double-sum association
+    for r in range(world):
+        assert np.array_equal(results[r][0], results[0][0])
+    assert np.allclose(results[0][0], single.world2camera(), rtol=0, atol=2e-7)
+    assert sum(res[1] for res in results) == single.last_U()
+    assert results[0][2] == single.last_hits()
+    # ICP: first iteration of the last frame sees identical inputs -> sums agree to double rounding
+    a, b = results[0][3], single.icp_log()
+    assert a.shape == b.shape and np.array_equal(a[:, 54], b[:, 54])
+    assert np.allclose(a[0, :54], b[0, :54], rtol=1e-12, atol=1e-12 * np.abs(b[0, :54]).max())
+    # volume: owned slabs tile the single-GPU volume
+    if np.array_equal(results[0][0], single.world2camera()):
+        pieces = [s.owned_volume() for s in shards]
+        for i, full in enumerate((sv, sw, sg)):
+            assert np.array_equal(np.concatenate([p[i] for p in pieces]), full)
+        # halo planes carry the neighbour's exact bits
+        v0, _, _ = shards[0].volume()
+        o, st = shards[0].owned, shards[0].stored
+        plane = n * n
+        assert np.array_equal(v0[(o[1] - st[0]) * plane:], sv[o[1] * plane: st[1] * plane])
+    # composed previous-frame maps identical on every rank, and to the single-GPU maps when the poses are
+    for which in ("vmaps_g_prev", "nmaps_g_prev"):
+        m0 = shards[0].map(which, 0)
+        for s in shards[1:]:
+            assert np.array_equal(np.nan_to_num(m0, nan=-7.0), np.nan_to_num(s.map(which, 0), nan=-7.0))
+    for s in shards:
+        s.close()
+    single.close()
+
+
+def test_sharded_first_frame_bit_exact(dev):
+    """Frame 0 has no ICP: the sharded integrate + raycast composite must reproduce the single-GPU
+    volume and maps bit for bit."""
+    torch, pl, sh = dev
+    n = 128
+    prm = synth.s1_params(n)
+    single = pl.KinectFusion(prm)
+    assert single.process_frame(torch.from_numpy(synth.s1_frame(0).view(np.int16)).cuda()) == 1
+    shards, results = run_world(torch, sh, prm, 4, [0])
+    sv, sw, sg = single.volume()
+    pieces = [s.owned_volume() for s in shards]
+    for i, full in enumerate((sv, sw, sg)):
+        assert np.array_equal(np.concatenate([p[i] for p in pieces]), full)
+    assert results[0][2] == single.last_hits()
+    H = synth.HEIGHT
+    for which in ("vmaps_g_prev", "nmaps_g_prev"):
+        for level in range(3):
+            a, b = shards[1].map(which, level), single.map(which, level)
+            rows = H >> level
+            nan_a, nan_b = np.isnan(a[:rows, :, 0]), np.isnan(b[:rows, :, 0])
+            assert np.array_equal(nan_a, nan_b)
+            ok = ~nan_b
+            for p in range(3):
+                assert np.array_equal(a[p * rows:(p + 1) * rows][ok], b[p * rows:(p + 1) * rows][ok]), (which, level, p)
+    for s in shards:
+        s.close()
+    single.close()

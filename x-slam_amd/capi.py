@@ -58,6 +58,10 @@ _SIGS = {
     "xs_resize_nmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_raycast": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
                              C.c_int, C.c_int, _vp, _vp]),
+    "xs_raycast_slab": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
+    "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_icp_workspace_bytes": (_sz, []),
     "xs_icp_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -216,6 +220,23 @@ def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, gr
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
                           vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
+
+
+def raycast_slab(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap,
+                 map_step, rows, cols, keys, stream=None):
+    r = _ia(res, 3)
+    k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    check(_lib.xs_raycast_slab(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
+                               vol_step, zs0, zs1, z0, z1, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(keys), _stream(stream)))
+
+
+def raycast_compose_mask(own_keys, min_keys, vmap, nmap, map_step, rows, cols, stream=None):
+    check(_lib.xs_raycast_compose_mask(_ptr(own_keys), _ptr(min_keys), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _stream(stream)))
+
+
+def raycast_compose_finish(min_keys, vmap, nmap, map_step, rows, cols, hits=None, stream=None):
+    check(_lib.xs_raycast_compose_finish(_ptr(min_keys), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
 
 
 def icp_workspace_bytes():

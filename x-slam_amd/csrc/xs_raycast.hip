@@ -22,7 +22,9 @@ struct RaycastArgs {
     const float *value; const float *grad; size_t vstep;
     Intr intr;
     cfloat *vmap; cfloat *nmap; size_t mstep;
-    int z0, z1;  // z-slab resident behind value/grad (whole volume: 0, Z)
+    int zs0, zs1;  // z planes resident behind value/grad: storage starts at plane zs0 (whole volume: 0, Z)
+    int z0, z1;    // z planes this launch owns (slab mode): only steps whose sample lands here are evaluated
+    int *keys;     // slab mode: per pixel, (step << 1 | no_hit) of the first event among owned steps, INT_MAX if none
     unsigned long long *hits;
 };
 
@@ -30,13 +32,14 @@ namespace {
 __device__ __forceinline__ int sgn(float v) { return (0.0f < v) - (v < 0.0f); }
 
 struct Vol {
-    const float *value; const float *grad; size_t vstep; int X, Y, Z; float vs;
+    const float *value; const float *grad; size_t vstep; int X, Y, Z; float vs; int zs0, zs1;
     __device__ __forceinline__ float read_value(int x, int y, int z) const {
-        return row_ptr(value, vstep, Y * z + y)[x] + 1e-5f;  // RayCaster.cu:76
+        return row_ptr(value, vstep, Y * (z - zs0) + y)[x] + 1e-5f;  // RayCaster.cu:76
     }
     __device__ __forceinline__ cfloat read(int x, int y, int z) const {  // readTsdf, :69-78
         x = x % X; y = y % Y; z = z % Z;
-        cfloat r(row_ptr(value, vstep, Y * z + y)[x], row_ptr(grad, vstep, Y * z + y)[x]);
+        z = min(max(z, zs0), zs1 - 1);  // stay inside the resident planes (a no-op unless a slab's halo were too thin)
+        cfloat r(row_ptr(value, vstep, Y * (z - zs0) + y)[x], row_ptr(grad, vstep, Y * (z - zs0) + y)[x]);
         r += 1e-5f;
         return r;
     }
@@ -63,6 +66,7 @@ struct Vol {
 };
 }  // namespace
 
+template <bool SLAB>
 __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -70,9 +74,20 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     unsigned hit = 0;
     if (x < a.cols && y < a.rows) {
-        row_ptr(a.vmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
-        row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
-        Vol vol{a.value, a.grad, a.vstep, a.X, a.Y, a.Z, a.voxel_size};
+        int key = 0x7fffffff, step_index = 0;
+        if (SLAB) {
+            // contributions of the ranks are added (as int32 bit patterns) after the first event
+            // along each ray has been agreed on: start from all-zero entries
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                row_ptr(a.vmap, a.mstep, y + p * a.rows)[x] = cfloat(0.f, 0.f);
+                row_ptr(a.nmap, a.mstep, y + p * a.rows)[x] = cfloat(0.f, 0.f);
+            }
+        } else {
+            row_ptr(a.vmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
+            row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
+        }
+        Vol vol{a.value, a.grad, a.vstep, a.X, a.Y, a.Z, a.voxel_size, a.zs0, a.zs1};
         const cfloat3 ray_start = a.tc2v;
         cfloat3 rn;
         rn.x = cfloat((x - a.intr.cx) / a.intr.fx);
@@ -92,14 +107,27 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
         int gy = __float2int_rd((sy + dy * time_curr) / vs);
         int gz = __float2int_rd((sz + dz * time_curr) / vs);
         gx = max(0, min(gx, a.X - 1)); gy = max(0, min(gy, a.Y - 1)); gz = max(0, min(gz, a.Z - 1));
-        float tsdf = vol.read_value(gx, gy, gz);
-        for (; time_curr < max_time; time_curr += time_step) {
-            const float tsdf_prev = tsdf;
+        // slab mode: every rank walks the same sequence of steps (the times are a float running sum,
+        // so all of them must be taken) but evaluates only those whose sample voxel it owns; the
+        // previous sample lies at most 3 planes away, inside the halo it also stores
+        int pgx = gx, pgy = gy, pgz = gz;
+        float tsdf = SLAB ? 0.f : vol.read_value(gx, gy, gz);
+        for (; time_curr < max_time; time_curr += time_step, ++step_index) {
+            float tsdf_prev = tsdf;
             const float tn = time_curr + time_step;
             gx = __float2int_rd((sx + dx * tn) / vs);
             gy = __float2int_rd((sy + dy * tn) / vs);
             gz = __float2int_rd((sz + dz * tn) / vs);
             if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < a.X && gy < a.Y && gz < a.Z)) break;
+            if (SLAB) {
+                const bool owned = gz >= a.z0 && gz < a.z1;
+                const int qx = pgx, qy = pgy, qz = pgz;
+                pgx = gx; pgy = gy; pgz = gz;
+                if (!owned) continue;
+                if (qz < a.zs0 || qz >= a.zs1) { key = (step_index << 1) | 1; break; }  // halo too thin: never expected
+                tsdf_prev = vol.read_value(qx, qy, qz);
+                key = (step_index << 1) | 1;  // provisional: an event without a vertex
+            }
             tsdf = vol.read_value(gx, gy, gz);
             if (tsdf_prev < 0.f && tsdf > 0.f) break;
             if (tsdf_prev > 0.f && tsdf < 0.f) {  // zero crossing
@@ -109,6 +137,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 if (isnan(Ft.re)) break;
                 const cfloat coef = Ft / (Ftdt - Ft);
                 if (Ft.re < 0.0f || Ftdt.re > 0.0f) break;
+                if (SLAB) key = step_index << 1;
                 const cfloat Ts = time_curr - time_step * coef;
                 const cfloat3 vertex_found = ray_start + ray_dir * Ts;
                 const cfloat3 vw = a.Rv2w * vertex_found + a.tv2w;
@@ -119,6 +148,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 gx = __float2int_rd(vertex_found.x.re / vs);
                 gy = __float2int_rd(vertex_found.y.re / vs);
                 gz = __float2int_rd(vertex_found.z.re / vs);
+                if (SLAB) row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);  // until a normal is written
                 if (gx > 1 && gy > 1 && gz > 1 && gx < a.X - 2 && gy < a.Y - 2 && gz < a.Z - 2) {
                     cfloat3 t, n;
                     const float half = vs * 0.5f;
@@ -139,7 +169,9 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 }
                 break;
             }
+            if (SLAB) key = 0x7fffffff;  // no event at this step
         }
+        if (SLAB) a.keys[y * a.cols + x] = key;
     }
     if (a.hits) {
         unsigned s = wave_sum_u32(hit);
@@ -177,10 +209,90 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.value = value; a.grad = grad; a.vstep = vol_step;
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
-    a.z0 = 0; a.z1 = res[2];
+    a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
     a.hits = hits_dev;
     dim3 block(256), grid(div_up(cols, 16), div_up(rows, 16));
-    hipLaunchKernelGGL(k_raycast, grid, block, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_raycast<false>, grid, block, 0, (hipStream_t)stream, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* Slab form of raycast for a z-sharded volume (no reference counterpart: the reference is
+ * single-GPU; semantics are those of RayCaster.cu:197-310 restricted to one rank's steps).
+ * value / grad hold planes [zs0, zs1) (owned slab + halo); only march steps whose sample voxel
+ * lies in the owned planes [z0, z1) are evaluated.  keys_dev[rows*cols] receives, per pixel,
+ * (step << 1 | no_vertex) of the first event among those steps or INT_MAX; vmap / nmap receive
+ * this rank's vertex / normal for its own event and zeros elsewhere.  The caller takes the
+ * minimum of the keys over ranks, calls xs_raycast_compose_mask, adds the maps over ranks as
+ * int32, then xs_raycast_compose_finish.  Halo needed: 6 planes. */
+extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                               float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+                               int zs0, int zs1, int z0, int z1, float *vmap, float *nmap, size_t map_step, int rows, int cols,
+                               int *keys_dev, void *stream) {
+    if (!intr4 || !Rc2v18 || !tc2v6 || !Rv2w18 || !tv2w6 || !res || !value || !grad || !vmap || !nmap || !keys_dev)
+        return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: null pointer");
+    if (zs0 < 0 || zs1 > res[2] || z0 < zs0 || z1 > zs1 || z1 < z0) return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: bad slab");
+    if (rows <= 0 || cols <= 0) return 0;
+    RaycastArgs a;
+    ld_mat(Rc2v18, a.Rc2v); ld_vec(tc2v6, a.tc2v); ld_mat(Rv2w18, a.Rv2w); ld_vec(tv2w6, a.tv2w);
+    a.X = res[0]; a.Y = res[1]; a.Z = res[2];
+    a.voxel_size = voxel_size;
+    a.time_step = tranc_dist * 0.8f;
+    a.cols = cols; a.rows = rows;
+    a.value = value; a.grad = grad; a.vstep = vol_step;
+    a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
+    a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
+    a.hits = nullptr;
+    dim3 block(256), grid(div_up(cols, 16), div_up(rows, 16));
+    hipLaunchKernelGGL(k_raycast<true>, grid, block, 0, (hipStream_t)stream, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) k_compose_mask(const int *own_keys, const int *min_keys, cfloat *vmap, cfloat *nmap, size_t mstep, int rows, int cols) {
+    const int x = threadIdx.x + blockIdx.x * 64, y = threadIdx.y + blockIdx.y * 4;
+    if (x >= cols || y >= rows) return;
+    const int k = own_keys[y * cols + x], m = min_keys[y * cols + x];
+    if (k == m && !(k & 1) && k != 0x7fffffff) return;  // this rank holds the ray's first event and it has a vertex
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        row_ptr(vmap, mstep, y + p * rows)[x] = cfloat(0.f, 0.f);
+        row_ptr(nmap, mstep, y + p * rows)[x] = cfloat(0.f, 0.f);
+    }
+}
+__global__ void __launch_bounds__(256) k_compose_finish(const int *min_keys, cfloat *vmap, cfloat *nmap, size_t mstep, int rows, int cols,
+                                                        unsigned long long *hits) {
+    const int x = threadIdx.x + blockIdx.x * 64, y = threadIdx.y + blockIdx.y * 4;
+    unsigned hit = 0;
+    if (x < cols && y < rows) {
+        const int m = min_keys[y * cols + x];
+        if ((m & 1) || m == 0x7fffffff) {  // no vertex on this ray: the NaN sentinel of RayCaster.cu:204-205
+            row_ptr(vmap, mstep, y)[x] = cfloat(qnan_f(), 0.f);
+            row_ptr(nmap, mstep, y)[x] = cfloat(qnan_f(), 0.f);
+        } else
+            hit = 1;
+    }
+    if (hits) {
+        unsigned s = wave_sum_u32(hit);
+        if (((threadIdx.y * 64 + threadIdx.x) & 63) == 0 && s) atomicAdd(hits, (unsigned long long)s);
+    }
+}
+/* keep this rank's vertex / normal only where it owns the ray's first event (own key == min key) */
+extern "C" int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows,
+                                       int cols, void *stream) {
+    if (!own_keys_dev || !min_keys_dev || !vmap || !nmap) return xs_set_error(hipErrorInvalidValue, "xs_raycast_compose_mask: null pointer");
+    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
+    hipLaunchKernelGGL(k_compose_mask, grid, block, 0, (hipStream_t)stream, own_keys_dev, min_keys_dev, (cfloat *)vmap, (cfloat *)nmap, map_step, rows, cols);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+/* after the maps were added over ranks: write the NaN sentinel where the first event has no vertex */
+extern "C" int xs_raycast_compose_finish(const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows, int cols,
+                                         unsigned long long *hits_dev, void *stream) {
+    if (!min_keys_dev || !vmap || !nmap) return xs_set_error(hipErrorInvalidValue, "xs_raycast_compose_finish: null pointer");
+    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
+    hipLaunchKernelGGL(k_compose_finish, grid, block, 0, (hipStream_t)stream, min_keys_dev, (cfloat *)vmap, (cfloat *)nmap, map_step, rows, cols, hits_dev);
     XS_CHECK(hipGetLastError());
     return 0;
 }

@@ -3,6 +3,7 @@
 // launcher shim.  One stream, no per-frame allocation, synchronisation only where the host
 // needs a result (the 6x6 normal equations of each ICP iteration).
 #include "KinectFusionReconstruction.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -19,10 +20,16 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
         ev_used_[s] = false;
     }
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, 2 * sizeof(unsigned long long)));
+    hipSafeCall(hipHostMalloc((void **)&pinned_sums_, 64 * sizeof(double)));
+}
+
+void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn fn, void *user) {
+    shard_rank = rank; shard_count = count < 1 ? 1 : count; collective = fn; collective_user = user;
 }
 
 KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
+    if (pinned_sums_) (void)hipHostFree(pinned_sums_);
     if (tsdf_volume_d_ptr) ReleaseBuffers();
     for (int s = 0; s < ST_COUNT; ++s) {
         (void)hipEventDestroy(ev_[s][0]);
@@ -85,8 +92,13 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     biInterpolate_threshold = config.as<float>("biInterpolate_threshold");
     trunc_logistic_k = config.as<float>("trunc_logistic_k", 0.f);
 
+    // planes owned / stored by this rank (whole volume when not sharded)
+    zo0 = (int)((long long)resolutionZ * shard_rank / shard_count);
+    zo1 = (int)((long long)resolutionZ * (shard_rank + 1) / shard_count);
+    zs0 = shard_count > 1 ? std::max(0, zo0 - HALO) : 0;
+    zs1 = shard_count > 1 ? std::min(resolutionZ, zo1 + HALO) : resolutionZ;
     AllocateBuffers();
-    tsdf_volume_d_ptr = new TsdfVolume(volume_resolution, voxel_size, thres_range);
+    tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
 
     use_gtPose = config.as<bool>("flag_use_gtPose", false);
     gt_poses.resize(0);
@@ -112,7 +124,14 @@ void KinectFusionReconstruction::AllocateBuffers() {
     depthRawScaled_d.create(depth_height, depth_width);
     {
         const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
-        integrate_ws_.create(xs_integrate_workspace_bytes(res, res[2]));
+        integrate_ws_.create(xs_integrate_workspace_bytes(res, zs1 - zs0));
+        icp_ws_.create(xs_icp_workspace_bytes());
+        check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
+        icp_sums_.create(64);
+        if (shard_count > 1) {
+            ray_keys_.create((size_t)depth_width * depth_height);
+            ray_min_keys_.create((size_t)depth_width * depth_height);
+        }
     }
     counters_.create(3);  // [0] updated voxels, [1] raycast hits, [2] bits of the frame's largest valid depth
     hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 3 * sizeof(unsigned long long), current_stream()));
@@ -196,8 +215,8 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
             auto &device_tcurr = device_cast<devComplex3>(tcurr);
             hostComplexICP A[36], b[6];
             long long inliers = 0;
-            estimateCombined(device_Rcurr, device_tcurr, vmap_curr, nmap_curr, device_Rprev_inv, device_tprev, kinect_intrinsic(level_index),
-                             vmap_g_prev, nmap_g_prev, distThres, angleThres, g_buf, sum_buf, A, b, &inliers);
+            (void)vmap_curr; (void)nmap_curr; (void)vmap_g_prev; (void)nmap_g_prev;
+            icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
             {   // diagnostics: re-pack the 27 sums in launch order
                 int shift = 0;
                 for (int i = 0; i < 6; ++i)
@@ -238,6 +257,25 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
     return 1;
 }
 
+// estimateCombined (ICP.cu:365-429) on this rank's pixel rows, summed over ranks, then unpacked
+void KinectFusionReconstruction::icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv,
+                                                      const devComplex3 &tprev, int level, hostComplexICP *A, hostComplexICP *b,
+                                                      long long *inliers) {
+    MapArr &vc = vmaps_curr_d[level], &nc = nmaps_curr_d[level], &vp = vmaps_g_prev_d[level], &np_ = nmaps_g_prev_d[level];
+    const Intr k = kinect_intrinsic(level);
+    const int rows = vc.rows() / 3, cols = vc.cols();
+    const int y0 = (int)((long long)rows * shard_rank / shard_count), y1 = (int)((long long)rows * (shard_rank + 1) / shard_count);
+    hipStream_t st = current_stream();
+    check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re, &k.fx,
+                               &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1, icp_ws_.ptr(),
+                               icp_sums_.ptr(), st), "estimateCombined");
+    if (shard_count > 1 && collective) collective(collective_user, 0, icp_sums_.ptr(), 55);  // the 440-byte all-reduce
+    hipSafeCall(hipMemcpyAsync(pinned_sums_, icp_sums_.ptr(), 55 * sizeof(double), hipMemcpyDeviceToHost, st));
+    hipSafeCall(hipStreamSynchronize(st));
+    xs_icp_unpack(pinned_sums_, reinterpret_cast<double *>(A), reinterpret_cast<double *>(b));
+    if (inliers) *inliers = (long long)pinned_sums_[54];
+}
+
 // reference :237-278
 int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d) {
     if (use_gtPose) {
@@ -272,10 +310,21 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
                                 depthRawScaled_d.step(), depth_max_dev, st), "scaleDepth");
     stage_end(ST_SCALE);
     stage_begin(ST_INTEGRATE);
-    check_rc(xs_integrate_scaled(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
-                                 &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re, &device_tv2c.x.re,
-                                 tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(), weight.ptr(), grad.ptr(), value.step(),
-                                 biInterpolate_threshold, 0, res[2], counters_.ptr(), depth_max_dev, integrate_ws_.ptr(), st), "integrateTsdfVolume");
+    {
+        // owned planes (counted), then the two halo bands every neighbour also integrates: the
+        // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
+        const int zr[3][2] = {{zo0, zo1}, {zs0, zo0}, {zo1, zs1}};
+        for (int i = 0; i < 3; ++i) {
+            const int za = zr[i][0], zb = zr[i][1];
+            if (zb <= za) continue;
+            const size_t off = (size_t)(za - zs0) * res[1];
+            check_rc(xs_integrate_scaled(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
+                                         &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
+                                         &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
+                                         grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters_.ptr() : nullptr,
+                                         depth_max_dev, integrate_ws_.ptr(), st), "integrateTsdfVolume");
+        }
+    }
     stage_end(ST_INTEGRATE);
 
     stage_begin(ST_RAYCAST);
@@ -323,8 +372,28 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.x = volume_resolution.x();
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
-    raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
-            voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1);
+    if (shard_count == 1) {
+        raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
+                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1);
+        return 0;
+    }
+    // sharded: march this rank's planes, agree on the first event of every ray, add the winners
+    const int res[3] = {volume_res.x, volume_res.y, volume_res.z};
+    const int rows = xyz_g_d.rows() / 3, cols = xyz_g_d.cols();
+    hipStream_t st = current_stream();
+    DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
+    check_rc(xs_raycast_slab(&kinect_intrinsic.fx, &device_Rc2v.data[0].x.re, &device_tc2v.x.re, &device_Rv2w.data[0].x.re, &device_tv2w.x.re,
+                             tsdf_volume_d_ptr->getTsdfTruncDist(), res, voxel_size, value.ptr(), grad.ptr(), value.step(), zs0, zs1, zo0, zo1,
+                             &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, ray_keys_.ptr(), st), "raycast");
+    hipSafeCall(hipMemcpyAsync(ray_min_keys_.ptr(), ray_keys_.ptr(), (size_t)rows * cols * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (collective) collective(collective_user, 1, ray_min_keys_.ptr(), (long)rows * cols);
+    check_rc(xs_raycast_compose_mask(ray_keys_.ptr(), ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, st), "raycast");
+    if (collective) {
+        collective(collective_user, 2, xyz_g_d.ptr(), (long)(xyz_g_d.step() / 4) * xyz_g_d.rows());
+        collective(collective_user, 2, normal_g_d.ptr(), (long)(normal_g_d.step() / 4) * normal_g_d.rows());
+    }
+    check_rc(xs_raycast_compose_finish(ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols,
+                                       counters_.ptr() + 1, st), "raycast");
     return 0;
 }
 

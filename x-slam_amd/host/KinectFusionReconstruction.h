@@ -57,6 +57,20 @@ public:
     int csfd_seed_row = -1, csfd_seed_col = -1;
     float csfd_seed_h = 1e-7f;
 
+    // z-slab / pixel-row sharding across GPUs (no counterpart in the single-GPU
+    // reference).  Rank r of G owns z planes [zo0, zo1) and stores [zs0, zs1) = owned + halo; it
+    // integrates its own storage, evaluates the ICP rows [r*H/G, (r+1)*H/G) of each level and the
+    // march steps of every ray that land in its planes.  collective(user, op, dev_ptr, count)
+    // must all-reduce in place over the ranks on the current stream: op 0 = sum of doubles,
+    // 1 = min of int32, 2 = sum of int32.
+    typedef void (*collective_fn)(void *user, int op, void *dev_ptr, long count);
+    enum { HALO = 6 };
+    int shard_rank = 0, shard_count = 1;
+    int zo0 = 0, zo1 = 0, zs0 = 0, zs1 = 0;
+    collective_fn collective = nullptr;
+    void *collective_user = nullptr;
+    void SetSharding(int rank, int count, collective_fn fn, void *user);  // call before SetYamlParameters
+
     // instrumentation
     bool profiling = false;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -100,6 +114,12 @@ public:
 private:
     DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits, [2] frame depth max (float bits)
     DeviceArray<unsigned char> integrate_ws_;  // brick work list of the integrate kernel
+    DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
+    DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
+    DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
+    double *pinned_sums_ = nullptr;
+    void icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv, const devComplex3 &tprev, int level,
+                              hostComplexICP *A, hostComplexICP *b, long long *inliers);
     unsigned long long *pinned_counters_ = nullptr;
     hipEvent_t ev_[ST_COUNT + 1][2];
     bool ev_used_[ST_COUNT];

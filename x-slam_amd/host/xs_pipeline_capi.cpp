@@ -11,6 +11,22 @@ extern "C" {
 
 void xs_kf_set_stream(void *stream) { xs_host::current_stream() = (hipStream_t)stream; }
 
+void *xs_kf_create_sharded(const char *yaml_text, int rank, int count, void (*collective)(void *, int, void *, long), void *user) {
+    try {
+        KF *k = new KF();
+        k->SetSharding(rank, count, collective, user);
+        k->SetYamlParameters(xs_host::FlatYaml::Load(yaml_text ? yaml_text : ""));
+        return k;
+    } catch (const std::exception &e) {
+        printf("xs_kf_create_sharded: %s\n", e.what());
+        return nullptr;
+    }
+}
+void xs_kf_shard_planes(void *kf, int *owned2, int *stored2) {
+    KF *k = (KF *)kf;
+    if (owned2) { owned2[0] = k->zo0; owned2[1] = k->zo1; }
+    if (stored2) { stored2[0] = k->zs0; stored2[1] = k->zs1; }
+}
 void *xs_kf_create(const char *yaml_text) {
     try {
         KF *k = new KF();

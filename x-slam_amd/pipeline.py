@@ -18,7 +18,10 @@ _lib = C.CDLL(LIB_PATH)
 
 _vp, _sz = C.c_void_p, C.c_size_t
 _f32p, _f64p, _i32p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+COLLECTIVE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_long)  # (user, op, dev_ptr, count)
 _SIGS = {
+    "xs_kf_create_sharded": (_vp, [C.c_char_p, C.c_int, C.c_int, COLLECTIVE_CB, _vp]),
+    "xs_kf_shard_planes": (None, [_vp, _i32p, _i32p]),
     "xs_kf_set_stream": (None, [_vp]),
     "xs_kf_create": (_vp, [C.c_char_p]),
     "xs_kf_destroy": (None, [_vp]),
