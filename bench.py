@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s2", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal: put every rank on cuda:0 (needs --backend gloo)")
     a = ap.parse_args()
 
     import torch
@@ -119,7 +121,7 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if a.same_gpu else local_rank)
     synth = importlib.import_module("x-slam_amd.synth")
     capi = importlib.import_module("x-slam_amd.capi")
     pl = importlib.import_module("x-slam_amd.pipeline")
@@ -135,7 +137,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group(a.backend)
         sharded = importlib.import_module("x-slam_amd.sharded")
         runner = sharded.ShardedKinectFusion(synth.s1_params(N), rank, world, dist)
     else:

@@ -110,10 +110,12 @@ int xs_resize_nmap(const float *in, size_t in_step, int src_rows, int src_cols, 
  *         const devComplex3& tv2w, float tranc_dist, const int3& res, float voxel_size,
  *         const PtrStep<float>& value, const PtrStep<float>& grad, MapArr& vmap, MapArr& nmap)
  *                                                  RayCaster.h:21-25, RayCaster.cu:197-368
- * rows / cols: one map plane.  hits_dev: optional device counter of pixels given a vertex. */
+ * rows / cols: one map plane.  hits_dev: optional device counter of pixels given a vertex.
+ * workspace: optional rows*cols device floats (march kernel + crossing kernel instead of one). */
 int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
-               float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, void *stream);
+               float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
+               void *stream);
 
 /* Slab form for a z-sharded volume (the reference is single-GPU; per-ray semantics are those of
  * RayCaster.cu:197-310).  value / grad hold planes [zs0, zs1) = owned slab + halo (6 planes);

@@ -141,6 +141,21 @@ def test_raycast(dev, oracle, n):
     assert ohits > 0.5 * H * W
     cmap_close(vm.cpu().numpy(), ov, H, budget=1e-4)
     cmap_close(nm.cpu().numpy(), on, H, budget=1e-4)
+    # march kernel + crossing kernel (workspace given): the same bits as the single kernel
+    vm2 = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    nm2 = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    hits2 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"],
+                 to_dev(torch, v), to_dev(torch, g), n * 4, vm2, nm2, W * 8, H, W, hits=hits2, workspace=ws)
+    torch.cuda.synchronize()
+    assert int(hits2.item()) == int(hits.item())
+    for a_, b_ in ((vm, vm2), (nm, nm2)):
+        a_, b_ = a_.cpu().numpy(), b_.cpu().numpy()
+        valid = ~np.isnan(a_[:H, :, 0])
+        assert np.array_equal(valid, ~np.isnan(b_[:H, :, 0]))
+        for p in range(3):
+            assert np.array_equal(a_[p * H:(p + 1) * H][valid], b_[p * H:(p + 1) * H][valid])
 
 
 def test_raycast_empty_volume(dev, oracle):

@@ -126,7 +126,8 @@ def test_pipeline_against_live_oracle_128(dev, oracle):
     for level in range(3):
         for which in ("depths_curr", "vmaps_curr", "nmaps_curr"):
             a, b = kf.map(which, level), ok_.map(which, level)
-            nan_a, nan_b = np.isnan(a[..., 0]), np.isnan(b[..., 0])
+            rows = H >> level  # the sentinel lives in the x plane only; y/z planes hold stale data there
+            nan_a, nan_b = np.isnan(a[:rows, :, 0]), np.isnan(b[:rows, :, 0])
             assert (nan_a != nan_b).mean() <= 1e-4
     kf.close()
 

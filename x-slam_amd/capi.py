@@ -57,7 +57,7 @@ _SIGS = {
     "xs_resize_vmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_resize_nmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_raycast": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
-                             C.c_int, C.c_int, _vp, _vp]),
+                             C.c_int, C.c_int, _vp, _vp, _vp]),
     "xs_raycast_slab": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, C.c_int, C.c_int,
                                   C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
@@ -214,12 +214,12 @@ def resize_nmap(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
 
 
 def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols,
-            hits=None, stream=None):
+            hits=None, workspace=None, stream=None):
     r = _ia(res, 3)
     k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
-                          vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
+                          vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _ptr(workspace), _stream(stream)))
 
 
 def raycast_slab(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap,

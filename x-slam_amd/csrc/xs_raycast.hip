@@ -24,6 +24,7 @@ struct RaycastArgs {
     cfloat *vmap; cfloat *nmap; size_t mstep;
     int zs0, zs1;  // z planes resident behind value/grad: storage starts at plane zs0 (whole volume: 0, Z)
     int z0, z1;    // z planes this launch owns (slab mode): only steps whose sample lands here are evaluated
+    float *cross_t; // two-kernel path: per pixel, the march time of the step before the crossing (or < 0)
     int *keys;     // slab mode: per pixel, (step << 1 | no_hit) of the first event among owned steps, INT_MAX if none
     unsigned long long *hits;
 };
@@ -66,8 +67,11 @@ struct Vol {
 };
 }  // namespace
 
-template <bool SLAB>
+// MODE 0: whole ray in one kernel; 1: slab (multi-GPU); 2: march only, records the crossing time;
+// 3: crossing only (trilinear samples, vertex, normal) for the pixels MODE 2 marked.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
+    constexpr bool SLAB = MODE == 1;
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 row_ptr(a.vmap, a.mstep, y + p * a.rows)[x] = cfloat(0.f, 0.f);
                 row_ptr(a.nmap, a.mstep, y + p * a.rows)[x] = cfloat(0.f, 0.f);
             }
-        } else {
+        } else if (MODE != 3) {
             row_ptr(a.vmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
             row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
         }
@@ -107,69 +111,113 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
         int gy = __float2int_rd((sy + dy * time_curr) / vs);
         int gz = __float2int_rd((sz + dz * time_curr) / vs);
         gx = max(0, min(gx, a.X - 1)); gy = max(0, min(gy, a.Y - 1)); gz = max(0, min(gz, a.Z - 1));
-        // slab mode: every rank walks the same sequence of steps (the times are a float running sum,
-        // so all of them must be taken) but evaluates only those whose sample voxel it owns; the
-        // previous sample lies at most 3 planes away, inside the halo it also stores
-        int pgx = gx, pgy = gy, pgz = gz;
-        float tsdf = SLAB ? 0.f : vol.read_value(gx, gy, gz);
-        for (; time_curr < max_time; time_curr += time_step, ++step_index) {
-            float tsdf_prev = tsdf;
-            const float tn = time_curr + time_step;
-            gx = __float2int_rd((sx + dx * tn) / vs);
-            gy = __float2int_rd((sy + dy * tn) / vs);
-            gz = __float2int_rd((sz + dz * tn) / vs);
-            if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < a.X && gy < a.Y && gz < a.Z)) break;
-            if (SLAB) {
+        // zero crossing between time_curr and tn (RayCaster.cu:247-306): returns 1 if a vertex was written
+        auto crossing = [&](float tc, float tn) -> int {
+            const cfloat Ftdt = vol.interp(ray_start + ray_dir * tn);
+            if (isnan(Ftdt.re)) return 0;
+            const cfloat Ft = vol.interp(ray_start + ray_dir * tc);
+            if (isnan(Ft.re)) return 0;
+            const cfloat coef = Ft / (Ftdt - Ft);
+            if (Ft.re < 0.0f || Ftdt.re > 0.0f) return 0;
+            const cfloat Ts = tc - time_step * coef;
+            const cfloat3 vertex_found = ray_start + ray_dir * Ts;
+            const cfloat3 vw = a.Rv2w * vertex_found + a.tv2w;
+            row_ptr(a.vmap, a.mstep, y)[x] = vw.x;
+            row_ptr(a.vmap, a.mstep, y + a.rows)[x] = vw.y;
+            row_ptr(a.vmap, a.mstep, y + 2 * a.rows)[x] = vw.z;
+            const int vx = __float2int_rd(vertex_found.x.re / vs);
+            const int vy = __float2int_rd(vertex_found.y.re / vs);
+            const int vz = __float2int_rd(vertex_found.z.re / vs);
+            if (SLAB) row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);  // until a normal is written
+            if (vx > 1 && vy > 1 && vz > 1 && vx < a.X - 2 && vy < a.Y - 2 && vz < a.Z - 2) {
+                cfloat3 t, n;
+                const float half = vs * 0.5f;
+                t = vertex_found; t.x += half; const cfloat Fx1 = vol.interp(t);
+                t = vertex_found; t.x -= half; const cfloat Fx2 = vol.interp(t);
+                n.x = Fx1 - Fx2;
+                t = vertex_found; t.y += half; const cfloat Fy1 = vol.interp(t);
+                t = vertex_found; t.y -= half; const cfloat Fy2 = vol.interp(t);
+                n.y = Fy1 - Fy2;
+                t = vertex_found; t.z += half; const cfloat Fz1 = vol.interp(t);
+                t = vertex_found; t.z -= half; const cfloat Fz2 = vol.interp(t);
+                n.z = Fz1 - Fz2;
+                if (squarednorm(n).re == 0) return 1;
+                const cfloat3 n_g = a.Rv2w * normalized(n);
+                row_ptr(a.nmap, a.mstep, y)[x] = n_g.x;
+                row_ptr(a.nmap, a.mstep, y + a.rows)[x] = n_g.y;
+                row_ptr(a.nmap, a.mstep, y + 2 * a.rows)[x] = n_g.z;
+            }
+            return 1;
+        };
+        if (MODE == 3) {
+            const float tc = a.cross_t[y * a.cols + x];
+            if (tc >= 0.f) hit = crossing(tc, tc + time_step);
+        } else if (SLAB) {
+            // slab mode: every rank walks the same sequence of steps (the times are a float running
+            // sum, so all of them must be taken) but evaluates only those whose sample voxel it owns;
+            // the previous sample lies at most 3 planes away, inside the halo it also stores
+            int pgx = gx, pgy = gy, pgz = gz;
+            for (; time_curr < max_time; time_curr += time_step, ++step_index) {
+                const float tn = time_curr + time_step;
+                gx = __float2int_rd((sx + dx * tn) / vs);
+                gy = __float2int_rd((sy + dy * tn) / vs);
+                gz = __float2int_rd((sz + dz * tn) / vs);
+                if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < a.X && gy < a.Y && gz < a.Z)) break;
                 const bool owned = gz >= a.z0 && gz < a.z1;
                 const int qx = pgx, qy = pgy, qz = pgz;
                 pgx = gx; pgy = gy; pgz = gz;
                 if (!owned) continue;
-                if (qz < a.zs0 || qz >= a.zs1) { key = (step_index << 1) | 1; break; }  // halo too thin: never expected
-                tsdf_prev = vol.read_value(qx, qy, qz);
                 key = (step_index << 1) | 1;  // provisional: an event without a vertex
-            }
-            tsdf = vol.read_value(gx, gy, gz);
-            if (tsdf_prev < 0.f && tsdf > 0.f) break;
-            if (tsdf_prev > 0.f && tsdf < 0.f) {  // zero crossing
-                const cfloat Ftdt = vol.interp(ray_start + ray_dir * tn);
-                if (isnan(Ftdt.re)) break;
-                const cfloat Ft = vol.interp(ray_start + ray_dir * time_curr);
-                if (isnan(Ft.re)) break;
-                const cfloat coef = Ft / (Ftdt - Ft);
-                if (Ft.re < 0.0f || Ftdt.re > 0.0f) break;
-                if (SLAB) key = step_index << 1;
-                const cfloat Ts = time_curr - time_step * coef;
-                const cfloat3 vertex_found = ray_start + ray_dir * Ts;
-                const cfloat3 vw = a.Rv2w * vertex_found + a.tv2w;
-                row_ptr(a.vmap, a.mstep, y)[x] = vw.x;
-                row_ptr(a.vmap, a.mstep, y + a.rows)[x] = vw.y;
-                row_ptr(a.vmap, a.mstep, y + 2 * a.rows)[x] = vw.z;
-                hit = 1;
-                gx = __float2int_rd(vertex_found.x.re / vs);
-                gy = __float2int_rd(vertex_found.y.re / vs);
-                gz = __float2int_rd(vertex_found.z.re / vs);
-                if (SLAB) row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);  // until a normal is written
-                if (gx > 1 && gy > 1 && gz > 1 && gx < a.X - 2 && gy < a.Y - 2 && gz < a.Z - 2) {
-                    cfloat3 t, n;
-                    const float half = vs * 0.5f;
-                    t = vertex_found; t.x += half; const cfloat Fx1 = vol.interp(t);
-                    t = vertex_found; t.x -= half; const cfloat Fx2 = vol.interp(t);
-                    n.x = Fx1 - Fx2;
-                    t = vertex_found; t.y += half; const cfloat Fy1 = vol.interp(t);
-                    t = vertex_found; t.y -= half; const cfloat Fy2 = vol.interp(t);
-                    n.y = Fy1 - Fy2;
-                    t = vertex_found; t.z += half; const cfloat Fz1 = vol.interp(t);
-                    t = vertex_found; t.z -= half; const cfloat Fz2 = vol.interp(t);
-                    n.z = Fz1 - Fz2;
-                    if (squarednorm(n).re == 0) break;
-                    const cfloat3 n_g = a.Rv2w * normalized(n);
-                    row_ptr(a.nmap, a.mstep, y)[x] = n_g.x;
-                    row_ptr(a.nmap, a.mstep, y + a.rows)[x] = n_g.y;
-                    row_ptr(a.nmap, a.mstep, y + 2 * a.rows)[x] = n_g.z;
+                if (qz < a.zs0 || qz >= a.zs1) break;  // halo too thin: never expected
+                const float tsdf_prev = vol.read_value(qx, qy, qz);
+                const float tsdf = vol.read_value(gx, gy, gz);
+                if (tsdf_prev < 0.f && tsdf > 0.f) break;
+                if (tsdf_prev > 0.f && tsdf < 0.f) {
+                    if (crossing(time_curr, tn)) { key = step_index << 1; hit = 1; }
+                    break;
                 }
-                break;
+                key = 0x7fffffff;  // no event at this step
             }
-            if (SLAB) key = 0x7fffffff;  // no event at this step
+        } else {
+            // The sample positions do not depend on the loaded values, so four steps are issued at a
+            // time (four gathers in flight per lane instead of one dependent chain) and then tested
+            // in order; whatever lies behind the first event is discarded.  The times are the same
+            // float running sum the one-step loop forms.
+            float tsdf = vol.read_value(gx, gy, gz);
+            float cross = -1.f;
+            bool done = false;
+            while (!done && time_curr < max_time) {
+                float tc[4], val[4];
+                bool live[4], inb[4];
+                float t = time_curr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tc[j] = t;
+                    live[j] = t < max_time;
+                    const float tn = t + time_step;
+                    const int jx = __float2int_rd((sx + dx * tn) / vs);
+                    const int jy = __float2int_rd((sy + dy * tn) / vs);
+                    const int jz = __float2int_rd((sz + dz * tn) / vs);
+                    inb[j] = jx >= 0 && jy >= 0 && jz >= 0 && jx < a.X && jy < a.Y && jz < a.Z;
+                    val[j] = (live[j] && inb[j]) ? vol.read_value(jx, jy, jz) : 0.f;
+                    t += time_step;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (done) break;
+                    if (!live[j] || !inb[j]) { done = true; break; }
+                    const float tsdf_prev = tsdf;
+                    tsdf = val[j];
+                    if (tsdf_prev < 0.f && tsdf > 0.f) { done = true; break; }
+                    if (tsdf_prev > 0.f && tsdf < 0.f) {
+                        if (MODE == 2) cross = tc[j]; else hit = crossing(tc[j], tc[j] + time_step);
+                        done = true;
+                        break;
+                    }
+                }
+                time_curr = t;
+            }
+            if (MODE == 2) a.cross_t[y * a.cols + x] = cross;
         }
         if (SLAB) a.keys[y * a.cols + x] = key;
     }
@@ -193,10 +241,13 @@ static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y =
  *         const PtrStep<float>& value, const PtrStep<float>& grad, MapArr& vmap, MapArr& nmap)
  *                                                   RayCaster.h:21-25, RayCaster.cu:327-368
  * rows/cols: size of one map plane.  hits_dev: optional device counter of pixels that got a
- * vertex.  No synchronisation (neither does the reference, :367). */
+ * vertex.  workspace: optional rows*cols floats; with it the ray is split into a march kernel
+ * and a crossing kernel (same arithmetic, higher occupancy).  No synchronisation (neither does
+ * the reference, :367). */
 extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                           float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
-                          float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, void *stream) {
+                          float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
+                          void *stream) {
     if (!intr4 || !Rc2v18 || !tc2v6 || !Rv2w18 || !tv2w6 || !res || !value || !grad || !vmap || !nmap)
         return xs_set_error(hipErrorInvalidValue, "xs_raycast: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
@@ -210,9 +261,16 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
-    a.hits = hits_dev;
+    a.hits = hits_dev; a.cross_t = workspace;
     dim3 block(256), grid(div_up(cols, 16), div_up(rows, 16));
-    hipLaunchKernelGGL(k_raycast<false>, grid, block, 0, (hipStream_t)stream, a);
+    if (workspace) {
+        // march (few registers, many waves, four gathers in flight per lane) then the crossings
+        a.hits = nullptr;
+        hipLaunchKernelGGL(k_raycast<2>, grid, block, 0, (hipStream_t)stream, a);
+        a.hits = hits_dev;
+        hipLaunchKernelGGL(k_raycast<3>, grid, block, 0, (hipStream_t)stream, a);
+    } else
+        hipLaunchKernelGGL(k_raycast<0>, grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -243,9 +301,9 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
-    a.hits = nullptr;
+    a.hits = nullptr; a.cross_t = nullptr;
     dim3 block(256), grid(div_up(cols, 16), div_up(rows, 16));
-    hipLaunchKernelGGL(k_raycast<true>, grid, block, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_raycast<1>, grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }

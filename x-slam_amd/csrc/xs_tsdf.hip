@@ -197,6 +197,10 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
     float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
     const size_t zstride = (size_t)a.Y * (a.vstep / 4);
     for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
+        // the voxel's current state is requested up front (coalesced 256 B rows) so the HBM latency
+        // runs under the projection arithmetic instead of after it
+        const float pre_v = *pos, pre_g = *gpos;
+        const int pre_w = *wpos;
         const float vgz = (z + 0.5f) * a.voxel_size;
         cfloat3 v_c;
         v_c.x = (base[0] + a.R.data[0].z * vgz) + a.t.x;
@@ -232,16 +236,29 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
                 Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
             }
         }
-        if (!(Dp.re > 0)) continue;  // the update needs Re Dp > 0 (TsdfFusion.cu:150); skip the norms early
-        const cfloat xl = (image_x - cx) / fx;
-        const cfloat yl = (image_y - cy) / fy;
-        const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
-        const cfloat sdf = norm(v_c_1) - norm(v_c);
-        if (sdf.re >= -a.tranc_dist) {
-            cfloat tsdf = sdf * a.tranc_dist_inv;
-            if (sdf.re > a.tranc_dist) tsdf = cfloat(1.0f, 0.0f);
-            const cfloat tsdf_prev(*pos, *gpos);
-            const int weight_prev = *wpos;
+        if (!(Dp.re > 0)) continue;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
+        // v_c_1 = Dp*(xl, yl, 1) lies on the voxel's own ray (xl = v_c.x / v_c.z), so
+        // sdf = |v_c_1| - |v_c| = (Dp - c) * |v_c|/c with |v_c|/c >= 1.  Beyond the truncation band by
+        // a safe margin (0.1 % of the band + 10 um, ~30x the float error of the two norms) the side is
+        // decided by the depth difference alone: behind the surface nothing is written, in front the
+        // value is the truncated constant (1, 0) — exactly what the reference computes — and the
+        // two complex norms (6 complex products, 2 square roots, 6 divides) are only evaluated
+        // inside the band.
+        const float depth_diff = Dp.re - c;
+        const float band = a.tranc_dist * 1.001f + 1e-5f;
+        if (depth_diff < -band) continue;
+        cfloat tsdf(1.0f, 0.0f);
+        if (!(depth_diff > band)) {
+            const cfloat xl = (image_x - cx) / fx;
+            const cfloat yl = (image_y - cy) / fy;
+            const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
+            const cfloat sdf = norm(v_c_1) - norm(v_c);
+            if (!(sdf.re >= -a.tranc_dist)) continue;
+            if (!(sdf.re > a.tranc_dist)) tsdf = sdf * a.tranc_dist_inv;
+        }
+        {
+            const cfloat tsdf_prev(pre_v, pre_g);
+            const int weight_prev = pre_w;
             const cfloat tsdf_new = (tsdf_prev * __int2float_rn(weight_prev) + 1.0f * tsdf) / __int2float_rn(weight_prev + 1);
             *pos = tsdf_new.re;
             *wpos = min(weight_prev + 1, a.max_weight);

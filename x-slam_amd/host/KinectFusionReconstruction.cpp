@@ -128,6 +128,7 @@ void KinectFusionReconstruction::AllocateBuffers() {
         icp_ws_.create(xs_icp_workspace_bytes());
         check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
         icp_sums_.create(64);
+        ray_ws_.create((size_t)depth_width * depth_height);
         if (shard_count > 1) {
             ray_keys_.create((size_t)depth_width * depth_height);
             ray_min_keys_.create((size_t)depth_width * depth_height);
@@ -374,7 +375,7 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.z = volume_resolution.z();
     if (shard_count == 1) {
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
-                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1);
+                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1, ray_ws_.ptr());
         return 0;
     }
     // sharded: march this rank's planes, agree on the first event of every ray, add the winners

@@ -116,6 +116,7 @@ private:
     DeviceArray<unsigned char> integrate_ws_;  // brick work list of the integrate kernel
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
+    DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
     double *pinned_sums_ = nullptr;
     void icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv, const devComplex3 &tprev, int level,
