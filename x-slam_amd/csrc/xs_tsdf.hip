@@ -17,6 +17,7 @@
 // takes the exact path.  Only voxels that pass the reference's predicate touch memory.
 #include "xs_device.h"
 #include <algorithm>
+#include <stdlib.h>
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
@@ -98,9 +99,9 @@ extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows
 }
 
 // ------------------------------------------------------------------------------------------
-// Brick geometry: 64 (x) x 4 (y) x 8 (z) voxels = one 256-thread workgroup, lane = x, so every
+// Brick geometry: 64 (x) x 4 (y) x 16 (z) voxels = one 256-thread workgroup, lane = x, so every
 // volume access of a wave is one 256-byte row segment.
-enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
+enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 16 };
 
 // Half-spaces of the (padded) view frustum in the volume's voxel-index space, built on the
 // host and passed as kernel arguments (wave-uniform: they live in scalar registers).  Along any
@@ -113,6 +114,8 @@ enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
 // frame's largest depth on the device (alpha[5] holds everything but cfar).
 struct Frustum {
     float alpha[6], bx[6], by[6], bz[6], slack[6];
+    float inv_bz[6];  // 1/bz for the column clip, 0 where bz is too small to divide by
+    int kind[6];      // +1: the plane bounds k from below, -1: from above, 0: no dependence on k worth using
 };
 
 struct IntegrateArgs {
@@ -128,7 +131,7 @@ struct IntegrateArgs {
     unsigned long long *updated;  // optional device counter
     const float *depth_max;       // optional: largest valid depth of the frame (device)
     int *brick_list; unsigned *brick_count;  // work list of the two-phase path
-    int bricks_x, bricks_y, bricks_z;
+    int bricks_x, bricks_y, bricks_z, brick_z;  // brick_z: planes per brick (runtime; BRICK_Z by default)
 };
 
 namespace {
@@ -143,24 +146,22 @@ __device__ __forceinline__ Frustum device_frustum(const IntegrateArgs &a) {
     f.alpha[5] += dmax * 1.0001f + 1.05f * a.tranc_dist;
     return f;
 }
-// Intersect {k : alpha + beta*k >= -slack} with [lo, hi]
-__device__ __forceinline__ void clip_halfspace(float alpha, float beta, float slack, float &lo, float &hi) {
-    const float av = alpha + slack;
-    if (fabsf(beta) <= 1e-12f * (fabsf(alpha) + slack)) {
-        if (av < 0.f) { lo = 1.f; hi = 0.f; }
-        return;
-    }
-    const float root = -av * __frcp_rn(beta);  // approximate: the caller pads the interval
-    if (beta > 0.f) lo = fmaxf(lo, root); else hi = fminf(hi, root);
-}
-// z interval [zb, ze) of column (x, y) that can pass the tests, padded by two voxels
+// z interval [zb, ze) of column (x, y) that can pass the tests, padded by two voxels.  Branch-free:
+// the plane slopes along z and their reciprocals are wave-uniform kernel arguments.
 __device__ __forceinline__ void clip_column(const Frustum &f, int x, int y, int &zb, int &ze) {
     float lo = (float)zb, hi = (float)ze;
     const float i = x + 0.5f, j = y + 0.5f;
+    bool empty = false;
 #pragma unroll
-    for (int p = 0; p < 6; ++p) clip_halfspace(f.alpha[p] + f.bx[p] * i + f.by[p] * j, f.bz[p], f.slack[p], lo, hi);
+    for (int p = 0; p < 6; ++p) {
+        const float v = (f.alpha[p] + f.bx[p] * i + f.by[p] * j) + f.slack[p];  // v + bz*k >= 0
+        const float root = -v * f.inv_bz[p];
+        if (f.kind[p] > 0) lo = fmaxf(lo, root);
+        else if (f.kind[p] < 0) hi = fminf(hi, root);
+        else empty = empty || (v < 0.f);
+    }
     zb = max(zb, (int)floorf(lo - 0.5f) - 2);
-    ze = min(ze, (int)ceilf(hi - 0.5f) + 3);
+    ze = empty ? zb : min(ze, (int)ceilf(hi - 0.5f) + 3);
 }
 // can any voxel of the index box [x0,x1) x [y0,y1) x [z0,z1) pass?  (all corners outside one
 // half-space => no)
@@ -176,95 +177,106 @@ __device__ __forceinline__ bool box_may_pass(const Frustum &f, int x0, int x1, i
     return true;
 }
 
-// The reference's per-voxel body (TsdfFusion.cu:110-168) for z in [zb, ze) of column (x, y).
+// The reference's per-voxel body (TsdfFusion.cu:110-168) for one voxel whose current state
+// (value, grad, weight) has already been loaded.  Returns true and the new state if the voxel is
+// written.
+struct VoxelCtx {
+    cfloat base[3];
+    float fx, fy, cx, cy, ulo, uhi, vlo, vhi;
+};
+template <bool BILINEAR>
+__device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
+                                                float &out_v, float &out_g, int &out_w) {
+    const float vgz = (z + 0.5f) * a.voxel_size;
+    cfloat3 v_c;
+    v_c.x = (k.base[0] + a.R.data[0].z * vgz) + a.t.x;
+    v_c.y = (k.base[1] + a.R.data[1].z * vgz) + a.t.y;
+    v_c.z = (k.base[2] + a.R.data[2].z * vgz) + a.t.z;
+    const float c = v_c.z.re;
+    if (c < 0) return false;  // Re(1/v_c.z) < 0
+    const cfloat px = v_c.x * k.fx, py = v_c.y * k.fy;
+    // early reject before the divides: |true image coordinate - (px/c + cx)| << 1 pixel
+    if (c > 0) {
+        if (px.re < k.ulo * c || px.re > k.uhi * c) return false;
+        if (py.re < k.vlo * c || py.re > k.vhi * c) return false;
+    }
+    const cfloat inv_z = 1.0f / v_c.z;
+    const cfloat image_x = px * inv_z + k.cx;
+    const cfloat image_y = py * inv_z + k.cy;
+    const int coo_x = __float2int_rd(image_x.re - 0.5f);
+    const int coo_y = __float2int_rd(image_y.re - 0.5f);
+    if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return false;
+    const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
+    cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
+    if (BILINEAR) {
+        const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
+        const float d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
+        const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x];
+        const float d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+        const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
+        const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
+        if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+            const cfloat one(1.0f, 0.0f);
+            const cfloat fa = image_x - cfloat(coo_x + 0.5f, 0.0f);
+            const cfloat fb = image_y - cfloat(coo_y + 0.5f, 0.0f);
+            Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+        }
+    }
+    if (!(Dp.re > 0)) return false;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
+    // v_c_1 = Dp*(xl, yl, 1) lies on the voxel's own ray (xl = v_c.x / v_c.z), so
+    // sdf = |v_c_1| - |v_c| = (Dp - c) * |v_c|/c with |v_c|/c >= 1.  Beyond the truncation band by
+    // a safe margin (0.1 % of the band + 10 um, ~30x the float error of the two norms) the side is
+    // decided by the depth difference alone: behind the surface nothing is written, in front the
+    // value is the truncated constant (1, 0) — exactly what the reference computes — and the
+    // two complex norms (6 complex products, 2 square roots, 6 divides) are only evaluated
+    // inside the band.
+    const float depth_diff = Dp.re - c;
+    const float band = a.tranc_dist * 1.001f + 1e-5f;
+    if (depth_diff < -band) return false;
+    cfloat tsdf(1.0f, 0.0f);
+    if (!(depth_diff > band)) {
+        const cfloat xl = (image_x - k.cx) / k.fx;
+        const cfloat yl = (image_y - k.cy) / k.fy;
+        const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
+        const cfloat sdf = norm(v_c_1) - norm(v_c);
+        if (!(sdf.re >= -a.tranc_dist)) return false;
+        if (!(sdf.re > a.tranc_dist)) tsdf = sdf * a.tranc_dist_inv;
+    }
+    const cfloat tsdf_prev(pre_v, pre_g);
+    const cfloat tsdf_new = (tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf) / __int2float_rn(pre_w + 1);
+    out_v = tsdf_new.re;
+    out_g = tsdf_new.im;
+    out_w = min(pre_w + 1, a.max_weight);
+    return true;
+}
+
+// z in [zb, ze) of column (x, y).  The voxel's current state (coalesced 256 B rows) is requested
+// before the projection arithmetic so its HBM latency runs under it.  (Two planes per trip with
+// six reads in flight was measured slower: 102 VGPRs halve the resident waves.)
 template <bool BILINEAR>
 __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x, int y, int zb, int ze) {
     unsigned n_upd = 0;
     const float vgx = (x + 0.5f) * a.voxel_size;
     const float vgy = (y + 0.5f) * a.voxel_size;
+    VoxelCtx k;
     // z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy); v_g has zero imaginary
     // part, so each complex product is (re*vg, im*vg)
-    cfloat base[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
-    const float fx = a.intr.fx, fy = a.intr.fy, cx = a.intr.cx, cy = a.intr.cy;
+    for (int r = 0; r < 3; ++r) k.base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
+    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
     // conservative image window in un-divided form (one pixel of slack on each side)
-    const float ulo = 1.5f - cx, uhi = (a.dcols - 0.5f) - cx + 1.0f;
-    const float vlo = 1.5f - cy, vhi = (a.drows - 0.5f) - cy + 1.0f;
+    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
+    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
     const size_t row = (size_t)(zb - a.z0) * a.Y + y;
     float *pos = row_ptr(a.value, a.vstep, 0) + row * (a.vstep / 4) + x;
     int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
     float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
     const size_t zstride = (size_t)a.Y * (a.vstep / 4);
     for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
-        // the voxel's current state is requested up front (coalesced 256 B rows) so the HBM latency
-        // runs under the projection arithmetic instead of after it
-        const float pre_v = *pos, pre_g = *gpos;
-        const int pre_w = *wpos;
-        const float vgz = (z + 0.5f) * a.voxel_size;
-        cfloat3 v_c;
-        v_c.x = (base[0] + a.R.data[0].z * vgz) + a.t.x;
-        v_c.y = (base[1] + a.R.data[1].z * vgz) + a.t.y;
-        v_c.z = (base[2] + a.R.data[2].z * vgz) + a.t.z;
-        const float c = v_c.z.re;
-        if (c < 0) continue;  // Re(1/v_c.z) < 0
-        const cfloat px = v_c.x * fx, py = v_c.y * fy;
-        // early reject before the divides: |true image coordinate - (px/c + cx)| << 1 pixel
-        if (c > 0) {
-            if (px.re < ulo * c || px.re > uhi * c) continue;
-            if (py.re < vlo * c || py.re > vhi * c) continue;
-        }
-        const cfloat inv_z = 1.0f / v_c.z;
-        const cfloat image_x = px * inv_z + cx;
-        const cfloat image_y = py * inv_z + cy;
-        const int coo_x = __float2int_rd(image_x.re - 0.5f);
-        const int coo_y = __float2int_rd(image_y.re - 0.5f);
-        if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
-        const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
-        cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
-        if (BILINEAR) {
-            const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
-            const float d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
-            const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x];
-            const float d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
-            const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
-            const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
-            if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
-                const cfloat one(1.0f, 0.0f);
-                const cfloat fa = image_x - cfloat(coo_x + 0.5f, 0.0f);
-                const cfloat fb = image_y - cfloat(coo_y + 0.5f, 0.0f);
-                Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
-            }
-        }
-        if (!(Dp.re > 0)) continue;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
-        // v_c_1 = Dp*(xl, yl, 1) lies on the voxel's own ray (xl = v_c.x / v_c.z), so
-        // sdf = |v_c_1| - |v_c| = (Dp - c) * |v_c|/c with |v_c|/c >= 1.  Beyond the truncation band by
-        // a safe margin (0.1 % of the band + 10 um, ~30x the float error of the two norms) the side is
-        // decided by the depth difference alone: behind the surface nothing is written, in front the
-        // value is the truncated constant (1, 0) — exactly what the reference computes — and the
-        // two complex norms (6 complex products, 2 square roots, 6 divides) are only evaluated
-        // inside the band.
-        const float depth_diff = Dp.re - c;
-        const float band = a.tranc_dist * 1.001f + 1e-5f;
-        if (depth_diff < -band) continue;
-        cfloat tsdf(1.0f, 0.0f);
-        if (!(depth_diff > band)) {
-            const cfloat xl = (image_x - cx) / fx;
-            const cfloat yl = (image_y - cy) / fy;
-            const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
-            const cfloat sdf = norm(v_c_1) - norm(v_c);
-            if (!(sdf.re >= -a.tranc_dist)) continue;
-            if (!(sdf.re > a.tranc_dist)) tsdf = sdf * a.tranc_dist_inv;
-        }
-        {
-            const cfloat tsdf_prev(pre_v, pre_g);
-            const int weight_prev = pre_w;
-            const cfloat tsdf_new = (tsdf_prev * __int2float_rn(weight_prev) + 1.0f * tsdf) / __int2float_rn(weight_prev + 1);
-            *pos = tsdf_new.re;
-            *wpos = min(weight_prev + 1, a.max_weight);
-            *gpos = tsdf_new.im;
-            ++n_upd;
-        }
+        const float v0 = *pos, g0 = *gpos;
+        const int w0 = *wpos;
+        float ov, og; int ow;
+        if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) { *pos = ov; *wpos = ow; *gpos = og; ++n_upd; }
     }
     return n_upd;
 }
@@ -301,9 +313,9 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     bool active = false;
     if (b < nb) {
         const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
-        const int x0 = bx * BRICK_X, y0 = by * BRICK_Y, z0 = a.z0 + bz * BRICK_Z;
+        const int x0 = bx * BRICK_X, y0 = by * BRICK_Y, z0 = a.z0 + bz * a.brick_z;
         const Frustum f = device_frustum(a);
-        active = box_may_pass(f, x0, min(x0 + BRICK_X, a.X), y0, min(y0 + BRICK_Y, a.Y), z0, min(z0 + BRICK_Z, a.z1));
+        active = box_may_pass(f, x0, min(x0 + BRICK_X, a.X), y0, min(y0 + BRICK_Y, a.Y), z0, min(z0 + a.brick_z, a.z1));
     }
     const unsigned long long m = __ballot(active);
     const int lane = threadIdx.x & 63;
@@ -314,7 +326,7 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
 }
 
 template <bool BILINEAR>
-__global__ void __launch_bounds__(256) k_integrate_bricks(const IntegrateArgs a) {
+__global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs a) {
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
     const Frustum f = device_frustum(a);
@@ -323,7 +335,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks(const IntegrateArgs a)
         const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
         const int x = bx * BRICK_X + threadIdx.x, y = by * BRICK_Y + threadIdx.y;
         if (x < a.X && y < a.Y) {
-            int zb = a.z0 + bz * BRICK_Z, ze = min(zb + BRICK_Z, a.z1);
+            int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
             clip_column(f, x, y, zb, ze);
             if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
         }
@@ -372,12 +384,22 @@ static void host_frustum(IntegrateArgs &a) {
     set_plane(f, 3, T, M, 0.f, fy, -vl, rel * (fabsf(fy) * mag1 + fabsf(vl) * mag2));      // fy*Y >= vl*c
     set_plane(f, 4, T, M, 0.f, -fy, vh, rel * (fabsf(fy) * mag1 + fabsf(vh) * mag2));      // fy*Y <= vh*c
     set_plane(f, 5, T, M, 0.f, 0.f, -1.f, rel * mag2);                                     // c <= cfar (cfar added on the device)
+    for (int p = 0; p < 6; ++p) {
+        // a slope along z too small to divide by is dropped from the column clip; what it could
+        // contribute over the whole column goes into the slack instead
+        const float scale = fabsf(f.alpha[p]) + (fabsf(f.bx[p]) + fabsf(f.by[p])) * ext + f.slack[p] + (p == 5 ? 6.f : 0.f);
+        if (fabsf(f.bz[p]) * ext <= 1e-6f * scale) {
+            f.kind[p] = 0; f.inv_bz[p] = 0.f; f.slack[p] += fabsf(f.bz[p]) * ext;
+        } else {
+            f.kind[p] = f.bz[p] > 0.f ? 1 : -1; f.inv_bz[p] = 1.0f / f.bz[p];
+        }
+    }
 }
 
 /* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
-    const size_t nb = (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, BRICK_Z);
+    const size_t nb = (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2);  // room for 2-plane bricks
     return 256 + nb * sizeof(int);
 }
 
@@ -401,7 +423,9 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
     a.brick_list = nullptr; a.brick_count = nullptr;
     host_frustum(a);
     const int nz = z1 - z0;
-    a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, BRICK_Z);
+    static const int env_bz = getenv("XS_BRICK_Z") ? atoi(getenv("XS_BRICK_Z")) : 0;  // tuning aid
+    a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
+    a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, a.brick_z);
     a.zchunk = nz;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(64, 4);
@@ -412,7 +436,9 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         XS_CHECK(hipMemsetAsync(a.brick_count, 0, sizeof(unsigned), st));
         hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
         // resident workgroups stride over the list: 256 CUs x 8
-        const int g = nb < 2048 ? nb : 2048;
+        static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
+        const int gmax = env_g > 0 ? env_g : 8192;
+        const int g = nb < gmax ? nb : gmax;
         if (threshold > 0.0f)
             hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
         else
