@@ -184,29 +184,32 @@ struct VoxelCtx {
     cfloat base[3];
     float fx, fy, cx, cy, ulo, uhi, vlo, vhi;
 };
+struct VoxelProj {  // what the projection hands to the update
+    cfloat3 v_c; cfloat image_x, image_y, Dp; float c;
+};
+// phase 1 (TsdfFusion.cu:110-143): project the voxel, fetch its depth.  false = not written.
 template <bool BILINEAR>
-__device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
-                                                float &out_v, float &out_g, int &out_w) {
+__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, VoxelProj &o) {
     const float vgz = (z + 0.5f) * a.voxel_size;
-    cfloat3 v_c;
-    v_c.x = (k.base[0] + a.R.data[0].z * vgz) + a.t.x;
-    v_c.y = (k.base[1] + a.R.data[1].z * vgz) + a.t.y;
-    v_c.z = (k.base[2] + a.R.data[2].z * vgz) + a.t.z;
-    const float c = v_c.z.re;
+    o.v_c.x = (k.base[0] + a.R.data[0].z * vgz) + a.t.x;
+    o.v_c.y = (k.base[1] + a.R.data[1].z * vgz) + a.t.y;
+    o.v_c.z = (k.base[2] + a.R.data[2].z * vgz) + a.t.z;
+    const float c = o.v_c.z.re;
+    o.c = c;
     if (c < 0) return false;  // Re(1/v_c.z) < 0
-    const cfloat px = v_c.x * k.fx, py = v_c.y * k.fy;
+    const cfloat px = o.v_c.x * k.fx, py = o.v_c.y * k.fy;
     // early reject before the divides: |true image coordinate - (px/c + cx)| << 1 pixel
     if (c > 0) {
         if (px.re < k.ulo * c || px.re > k.uhi * c) return false;
         if (py.re < k.vlo * c || py.re > k.vhi * c) return false;
     }
-    const cfloat inv_z = 1.0f / v_c.z;
-    const cfloat image_x = px * inv_z + k.cx;
-    const cfloat image_y = py * inv_z + k.cy;
-    const int coo_x = __float2int_rd(image_x.re - 0.5f);
-    const int coo_y = __float2int_rd(image_y.re - 0.5f);
+    const cfloat inv_z = 1.0f / o.v_c.z;
+    o.image_x = px * inv_z + k.cx;
+    o.image_y = py * inv_z + k.cy;
+    const int coo_x = __float2int_rd(o.image_x.re - 0.5f);
+    const int coo_y = __float2int_rd(o.image_y.re - 0.5f);
     if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return false;
-    const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
+    const int near_x = __float2int_rn(o.image_x.re), near_y = __float2int_rn(o.image_y.re);
     cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
     if (BILINEAR) {
         const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
@@ -217,12 +220,17 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Vo
         const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
         if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
             const cfloat one(1.0f, 0.0f);
-            const cfloat fa = image_x - cfloat(coo_x + 0.5f, 0.0f);
-            const cfloat fb = image_y - cfloat(coo_y + 0.5f, 0.0f);
+            const cfloat fa = o.image_x - cfloat(coo_x + 0.5f, 0.0f);
+            const cfloat fb = o.image_y - cfloat(coo_y + 0.5f, 0.0f);
             Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
         }
     }
-    if (!(Dp.re > 0)) return false;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
+    o.Dp = Dp;
+    return Dp.re > 0;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
+}
+// phase 2 (TsdfFusion.cu:144-167): signed distance, truncation, running mean.
+__device__ __forceinline__ bool update_voxel(const IntegrateArgs &a, const VoxelCtx &k, const VoxelProj &p, float pre_v, float pre_g,
+                                             int pre_w, float &out_v, float &out_g, int &out_w) {
     // v_c_1 = Dp*(xl, yl, 1) lies on the voxel's own ray (xl = v_c.x / v_c.z), so
     // sdf = |v_c_1| - |v_c| = (Dp - c) * |v_c|/c with |v_c|/c >= 1.  Beyond the truncation band by
     // a safe margin (0.1 % of the band + 10 um, ~30x the float error of the two norms) the side is
@@ -230,15 +238,15 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Vo
     // value is the truncated constant (1, 0) — exactly what the reference computes — and the
     // two complex norms (6 complex products, 2 square roots, 6 divides) are only evaluated
     // inside the band.
-    const float depth_diff = Dp.re - c;
+    const float depth_diff = p.Dp.re - p.c;
     const float band = a.tranc_dist * 1.001f + 1e-5f;
     if (depth_diff < -band) return false;
     cfloat tsdf(1.0f, 0.0f);
     if (!(depth_diff > band)) {
-        const cfloat xl = (image_x - k.cx) / k.fx;
-        const cfloat yl = (image_y - k.cy) / k.fy;
-        const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
-        const cfloat sdf = norm(v_c_1) - norm(v_c);
+        const cfloat xl = (p.image_x - k.cx) / k.fx;
+        const cfloat yl = (p.image_y - k.cy) / k.fy;
+        const cfloat3 v_c_1 = mk3(p.Dp * xl, p.Dp * yl, p.Dp);
+        const cfloat sdf = norm(v_c_1) - norm(p.v_c);
         if (!(sdf.re >= -a.tranc_dist)) return false;
         if (!(sdf.re > a.tranc_dist)) tsdf = sdf * a.tranc_dist_inv;
     }
@@ -248,6 +256,13 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Vo
     out_g = tsdf_new.im;
     out_w = min(pre_w + 1, a.max_weight);
     return true;
+}
+template <bool BILINEAR>
+__device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
+                                                float &out_v, float &out_g, int &out_w) {
+    VoxelProj p;
+    if (!project_voxel<BILINEAR>(a, k, z, p)) return false;
+    return update_voxel(a, k, p, pre_v, pre_g, pre_w, out_v, out_g, out_w);
 }
 
 // z in [zb, ze) of column (x, y).  The voxel's current state (coalesced 256 B rows) is requested
@@ -272,6 +287,8 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
     int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
     float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
     const size_t zstride = (size_t)a.Y * (a.vstep / 4);
+    // (Requesting the state of voxel z+1 one trip ahead, in front of or behind the depth gather, was
+    // measured slower: loads return in issue order and the extra live registers cost a wave.)
     for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
         const float v0 = *pos, g0 = *gpos;
         const int w0 = *wpos;
@@ -338,6 +355,84 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
             int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
             clip_column(f, x, y, zb, ze);
             if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
+        }
+    }
+    if (a.updated) {
+        unsigned s = wave_sum_u32(n_upd);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.updated, (unsigned long long)s);
+    }
+}
+
+// ---- path 2b: brick work list, four x per lane ---------------------------------------------
+// Same bricks, but a lane owns four consecutive x: the voxel state moves as 16-byte vectors
+// (1 KiB per wave-instruction, three of them in flight per wave before any arithmetic), i.e.
+// four times the bytes in flight of the one-voxel-per-lane form at the same occupancy.  The
+// four voxels are then evaluated one after the other by the same per-voxel body; their state
+// waits in LDS meanwhile, so the register footprint stays that of a single voxel.  A wave covers
+// 64 x by 4 y of one plane; the four waves of a workgroup take planes z, z+1, z+2, z+3.
+template <bool BILINEAR>
+__global__ void __launch_bounds__(256) k_integrate_bricks_q(const IntegrateArgs a) {
+    __shared__ float s_v[256][4], s_g[256][4];
+    __shared__ int s_w[256][4];
+    const unsigned count = *a.brick_count;
+    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
+    const int xq = lane & 15, yq = lane >> 4;
+    unsigned n_upd = 0;
+    const Frustum f = device_frustum(a);
+    VoxelCtx k;
+    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
+    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
+    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
+    const size_t pitch = a.vstep / 4;
+    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+        const int b = a.brick_list[e];
+        const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
+        const int x0 = bx * BRICK_X + xq * 4, y = by * BRICK_Y + yq;
+        if (x0 >= a.X || y >= a.Y) continue;
+        int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
+        {   // union of the z intervals of the quad's first and last column
+            int zb1 = zb, ze1 = ze, zb2 = zb, ze2 = ze;
+            clip_column(f, x0, y, zb1, ze1);
+            clip_column(f, min(x0 + 3, a.X - 1), y, zb2, ze2);
+            zb = min(zb1, zb2); ze = max(ze1, ze2);
+        }
+        const float vgy = (y + 0.5f) * a.voxel_size;
+        const bool vec = (x0 + 3 < a.X);
+        for (int z = zb + wave; z < ze; z += 4) {
+            const size_t off = ((size_t)(z - a.z0) * a.Y + y) * pitch + x0;
+            float *pv = a.value + off, *pg = a.grad + off;
+            int *pw = a.weight + off;
+            if (vec) {
+                *reinterpret_cast<float4 *>(s_v[tid]) = *reinterpret_cast<const float4 *>(pv);
+                *reinterpret_cast<float4 *>(s_g[tid]) = *reinterpret_cast<const float4 *>(pg);
+                *reinterpret_cast<int4 *>(s_w[tid]) = *reinterpret_cast<const int4 *>(pw);
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    if (x0 + j < a.X) { s_v[tid][j] = pv[j]; s_g[tid][j] = pg[j]; s_w[tid][j] = pw[j]; }
+            }
+            unsigned mask = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j;
+                if (x >= a.X) break;
+                const float vgx = (x + 0.5f) * a.voxel_size;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) k.base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
+                float ov, og; int ow;
+                if (integrate_voxel<BILINEAR>(a, k, z, s_v[tid][j], s_g[tid][j], s_w[tid][j], ov, og, ow)) {
+                    s_v[tid][j] = ov; s_g[tid][j] = og; s_w[tid][j] = ow;
+                    mask |= 1u << j;
+                }
+            }
+            if (mask == 0xFu) {
+                *reinterpret_cast<float4 *>(pv) = *reinterpret_cast<const float4 *>(s_v[tid]);
+                *reinterpret_cast<float4 *>(pg) = *reinterpret_cast<const float4 *>(s_g[tid]);
+                *reinterpret_cast<int4 *>(pw) = *reinterpret_cast<const int4 *>(s_w[tid]);
+            } else if (mask) {
+                for (int j = 0; j < 4; ++j)
+                    if (mask & (1u << j)) { pv[j] = s_v[tid][j]; pg[j] = s_g[tid][j]; pw[j] = s_w[tid][j]; }
+            }
+            n_upd += __popc(mask);
         }
     }
     if (a.updated) {
@@ -439,7 +534,14 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
         const int gmax = env_g > 0 ? env_g : 8192;
         const int g = nb < gmax ? nb : gmax;
-        if (threshold > 0.0f)
+        static const int env_q = getenv("XS_BRICK_QUAD") ? atoi(getenv("XS_BRICK_QUAD")) : 0;
+        const bool quad = env_q == 1 && (vol_step % 16) == 0 && (((size_t)value | (size_t)weight | (size_t)grad) % 16) == 0;
+        if (quad) {
+            if (threshold > 0.0f)
+                hipLaunchKernelGGL(k_integrate_bricks_q<true>, dim3(g), block, 0, st, a);
+            else
+                hipLaunchKernelGGL(k_integrate_bricks_q<false>, dim3(g), block, 0, st, a);
+        } else if (threshold > 0.0f)
             hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
         else
             hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
