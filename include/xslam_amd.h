@@ -139,11 +139,13 @@ size_t xs_icp_workspace_bytes(void);
 int xs_icp_workspace_init(void *workspace, void *stream);
 /* Device half of estimateCombined (ICP.h:24-31, ICP.cu:166-281 + 120-164): sums_dev receives 55
  * doubles — the 27 complex<double> sums in the reference's mbuf order, then the inlier count.
- * workspace replaces gbuf.  [y0, y1): pixel rows covered.  No synchronisation. */
+ * workspace replaces gbuf.  [y0, y1): pixel rows covered.  done_flag (optional; with sums_dev in
+ * host-coherent pinned memory): the kernel stores done_seq there, system-scope release, after the
+ * sums — the host may spin on it instead of copying + synchronising.  No synchronisation. */
 int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
                       const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                       const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
-                      void *workspace, double *sums_dev, void *stream);
+                      void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq, void *stream);
 /* estimateCombined(...) whole: accumulate, synchronise the stream, download, unpack into the
  * symmetric A (36 complex<double>, A[i*6+j] = A[j*6+i]) and b (6)          ICP.cu:365-429 */
 int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,

@@ -29,6 +29,7 @@ struct IcpArgs {
     double *partials;       // [gridDim.x][56]
     unsigned *ticket;       // zeroed before the launch
     double *out;            // 54 sums (27 x re,im) + [54] = inlier count
+    unsigned long long *done_flag; unsigned long long done_seq;  // optional: host-visible completion word
 };
 
 namespace {
@@ -170,6 +171,16 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
         if (c < NS + 1) smem[wave][c] = s;
         __syncthreads();
         if (threadIdx.x < NS + 1) a.out[threadIdx.x] = ((smem[0][threadIdx.x] + smem[1][threadIdx.x]) + smem[2][threadIdx.x]) + smem[3][threadIdx.x];
+        if (a.done_flag) {
+            // out (and the flag) may live in host-coherent pinned memory: push the sums out, then
+            // publish the sequence number the host is spinning on — no copy, no stream sync
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence_system();
+                __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -182,7 +193,7 @@ static void ld_mat(const float *p, MatS33 &m) {
 }
 static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
 
-enum { XS_ICP_MAX_BLOCKS = 256 };  // one workgroup per CU
+enum { XS_ICP_MAX_BLOCKS = 512 };  // two workgroups per CU (60 KB of LDS and 2 waves per SIMD each)
 
 extern "C" size_t xs_icp_workspace_bytes(void) { return (size_t)XS_ICP_MAX_BLOCKS * NP * sizeof(double) + 256; }
 /* zero the arrival ticket once after allocating the workspace (launches re-arm it themselves) */
@@ -200,11 +211,14 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
  * Device half: enqueue the reduction; sums_dev receives 55 doubles = the 27 complex<double>
  * sums in the reference's mbuf order (ICP.cu:266-280) followed by the inlier count.
  * workspace: xs_icp_workspace_bytes() bytes of device memory (replaces gbuf).  [y0, y1): pixel
- * rows covered (0, rows for one GPU).  No synchronisation, no download. */
+ * rows covered (0, rows for one GPU).  done_flag (optional, with sums_dev in host-coherent pinned
+ * memory): after the sums are written the kernel stores done_seq there with system-scope release,
+ * so a host thread can spin on it instead of copying and synchronising.  No synchronisation. */
 extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
                                  const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                                  const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
-                                 int y0, int y1, void *workspace, double *sums_dev, void *stream) {
+                                 int y0, int y1, void *workspace, double *sums_dev, unsigned long long *done_flag,
+                                 unsigned long long done_seq, void *stream) {
     if (!Rcurr18 || !tcurr6 || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
         !workspace || !sums_dev)
         return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate: null pointer");
@@ -217,7 +231,7 @@ extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, cons
     a.distThres = distThres; a.angleThres = angleThres; a.cols = cols; a.rows = rows; a.y0 = y0; a.y1 = y1;
     a.ticket = (unsigned *)workspace;
     a.partials = (double *)((char *)workspace + 256);
-    a.out = sums_dev;
+    a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
     const int tiles = div_up(cols, 64) * (y1 - y0);
     int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
     if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
@@ -237,7 +251,7 @@ extern "C" int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, c
                                     void *workspace, double *sums_dev, double *A72_host, double *b12_host, long long *inliers,
                                     void *stream) {
     int rc = xs_icp_accumulate(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step,
-                               rows, cols, distThres, angleThres, 0, rows, workspace, sums_dev, stream);
+                               rows, cols, distThres, angleThres, 0, rows, workspace, sums_dev, nullptr, 0, stream);
     if (rc) return rc;
     // pinned staging: a pageable destination would bounce through the runtime's own staging buffer
     static thread_local double *host = nullptr;

@@ -20,7 +20,8 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
         ev_used_[s] = false;
     }
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, 2 * sizeof(unsigned long long)));
-    hipSafeCall(hipHostMalloc((void **)&pinned_sums_, 64 * sizeof(double)));
+    hipSafeCall(hipHostMalloc((void **)&pinned_sums_, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    for (int i = 0; i < 64; ++i) pinned_sums_[i] = 0.0;
 }
 
 void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn fn, void *user) {
@@ -267,12 +268,31 @@ void KinectFusionReconstruction::icp_normal_equations(const MatS33 &Rcurr, const
     const int rows = vc.rows() / 3, cols = vc.cols();
     const int y0 = (int)((long long)rows * shard_rank / shard_count), y1 = (int)((long long)rows * (shard_rank + 1) / shard_count);
     hipStream_t st = current_stream();
-    check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re, &k.fx,
-                               &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1, icp_ws_.ptr(),
-                               icp_sums_.ptr(), st), "estimateCombined");
-    if (shard_count > 1 && collective) collective(collective_user, 0, icp_sums_.ptr(), 55);  // the 440-byte all-reduce
-    hipSafeCall(hipMemcpyAsync(pinned_sums_, icp_sums_.ptr(), 55 * sizeof(double), hipMemcpyDeviceToHost, st));
-    hipSafeCall(hipStreamSynchronize(st));
+    if (shard_count == 1 && !profiling_icp_sync) {
+        // single GPU: the kernel writes the sums straight into host-coherent pinned memory and then
+        // publishes a sequence number; the host spins on it (no copy kernel, no stream synchronise)
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
+        const unsigned long long seq = ++icp_seq_;
+        check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re,
+                                   &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,
+                                   icp_ws_.ptr(), pinned_sums_, reinterpret_cast<unsigned long long *>(pinned_sums_ + 56), seq, st),
+                 "estimateCombined");
+        long spins = 0;
+        while (*flag != seq) {
+            if (++spins > 2000000000L) { hipSafeCall(hipStreamSynchronize(st)); break; }  // never expected: fall back to a real wait
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+        check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re,
+                                   &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,
+                                   icp_ws_.ptr(), icp_sums_.ptr(), nullptr, 0, st), "estimateCombined");
+        if (shard_count > 1 && collective) collective(collective_user, 0, icp_sums_.ptr(), 55);  // the 440-byte all-reduce
+        hipSafeCall(hipMemcpyAsync(pinned_sums_, icp_sums_.ptr(), 55 * sizeof(double), hipMemcpyDeviceToHost, st));
+        hipSafeCall(hipStreamSynchronize(st));
+    }
     xs_icp_unpack(pinned_sums_, reinterpret_cast<double *>(A), reinterpret_cast<double *>(b));
     if (inliers) *inliers = (long long)pinned_sums_[54];
 }

@@ -118,7 +118,9 @@ private:
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
-    double *pinned_sums_ = nullptr;
+    double *pinned_sums_ = nullptr;            // host-coherent: [0..54] sums + count, [56] completion sequence word
+    unsigned long long icp_seq_ = 0;
+    bool profiling_icp_sync = false;           // true: copy + stream synchronise instead of the spin (debug aid)
     void icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv, const devComplex3 &tprev, int level,
                               hostComplexICP *A, hostComplexICP *b, long long *inliers);
     unsigned long long *pinned_counters_ = nullptr;
