@@ -38,7 +38,9 @@ struct Vol {
         return row_ptr(value, vstep, Y * (z - zs0) + y)[x] + 1e-5f;  // RayCaster.cu:76
     }
     __device__ __forceinline__ cfloat read(int x, int y, int z) const {  // readTsdf, :69-78
-        x = x % X; y = y % Y; z = z % Z;
+        // readTsdf wraps its indices with % resolution; every caller here passes 0 <= index < resolution
+        // (interp() rejects cells outside [1, N-2] before touching the +1 neighbours), where the wrap is
+        // the identity — and an integer modulo by a run-time value costs ~35 VALU ops, 192 of them per hit
         z = min(max(z, zs0), zs1 - 1);  // stay inside the resident planes (a no-op unless a slab's halo were too thin)
         cfloat r(row_ptr(value, vstep, Y * (z - zs0) + y)[x], row_ptr(grad, vstep, Y * (z - zs0) + y)[x]);
         r += 1e-5f;
@@ -72,10 +74,17 @@ struct Vol {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1;
-    // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup
+    // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
+    // round-robin over the 8 XCDs (each with its own 4 MB L2): the linear id is remapped so that
+    // XCD k marches one contiguous band of image tiles — an eighth of the frustum, which fits its
+    // L2 — instead of every XCD pulling every line.  Placement only affects speed.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int tiles_x = (a.cols + 15) / 16, tiles_y = (a.rows + 15) / 16, ntiles = tiles_x * tiles_y;
+    const int per_xcd = (ntiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int x = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
     unsigned hit = 0;
     if (x < a.cols && y < a.rows) {
         int key = 0x7fffffff, step_index = 0;
@@ -262,7 +271,7 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
     a.hits = hits_dev; a.cross_t = workspace;
-    dim3 block(256), grid(div_up(cols, 16), div_up(rows, 16));
+    dim3 block(256), grid(div_up(div_up(cols, 16) * div_up(rows, 16), 8) * 8);
     if (workspace) {
         // march (few registers, many waves, four gathers in flight per lane) then the crossings
         a.hits = nullptr;
@@ -302,7 +311,7 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
     a.hits = nullptr; a.cross_t = nullptr;
-    dim3 block(256), grid(div_up(cols, 16), div_up(rows, 16));
+    dim3 block(256), grid(div_up(div_up(cols, 16) * div_up(rows, 16), 8) * 8);
     hipLaunchKernelGGL(k_raycast<1>, grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;

@@ -14,12 +14,9 @@ using namespace xs_host;
 KinectFusionReconstruction::KinectFusionReconstruction() {
     depth_width = 0;
     depth_height = 0;
-    for (int s = 0; s < ST_COUNT; ++s) {
-        hipSafeCall(hipEventCreate(&ev_[s][0]));
-        hipSafeCall(hipEventCreate(&ev_[s][1]));
-        ev_used_[s] = false;
-    }
-    hipSafeCall(hipHostMalloc((void **)&pinned_counters_, 2 * sizeof(unsigned long long)));
+    hipSafeCall(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    hipSafeCall(hipEventCreateWithFlags(&surface_done_, hipEventDisableTiming));
+    hipSafeCall(hipHostMalloc((void **)&pinned_counters_, PROF_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < 64; ++i) pinned_sums_[i] = 0.0;
 }
@@ -29,13 +26,13 @@ void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn 
 }
 
 KinectFusionReconstruction::~KinectFusionReconstruction() {
+    if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
+    if (surface_done_) (void)hipEventDestroy(surface_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
     if (tsdf_volume_d_ptr) ReleaseBuffers();
-    for (int s = 0; s < ST_COUNT; ++s) {
-        (void)hipEventDestroy(ev_[s][0]);
-        (void)hipEventDestroy(ev_[s][1]);
-    }
+    for (auto &slot : prof_ring_)
+        for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(slot.ev[s][0]); (void)hipEventDestroy(slot.ev[s][1]); }
 }
 
 // reference :9-73
@@ -180,7 +177,7 @@ int KinectFusionReconstruction::ProcessFrame(const DeviceArray2D<ushort> &depth_
     }
     IntegrateFrame(depth_frame_d);
     frame_id += frame_step;
-    if (profiling) collect_stage_times();
+    if (profiling) end_profiled_frame();
     return 1;
 }
 
@@ -366,6 +363,12 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
         std::cout << "error::KinectFusionReconstruction, not created yet" << std::endl;
         return;
     }
+    // The current-frame maps depend only on the new depth image, which must be complete when
+    // ProcessFrame is called: they are built on a second stream, so they run under whatever the
+    // main stream still has in flight from the previous frame (raycast, pyramid), and the main
+    // stream picks them up through an event before the first ICP launch.
+    hipStream_t main_stream = current_stream();
+    current_stream() = aux_stream_;
     stage_begin(ST_SURFACE);
     SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
     for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
@@ -374,6 +377,9 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
         createNMap(vmaps_curr_d[i], nmaps_curr_d[i]);
     }
     stage_end(ST_SURFACE);
+    hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
+    current_stream() = main_stream;
+    hipSafeCall(hipStreamWaitEvent(main_stream, surface_done_, 0));
 }
 
 // reference :302-332
@@ -493,26 +499,47 @@ bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
 }
 
 // ---- per-stage HIP event timing (on the stream the kernels are launched on) -----------------
+void KinectFusionReconstruction::set_profiling(bool on) {
+    if (on && prof_ring_.empty()) {
+        prof_ring_.resize(PROF_RING);
+        for (auto &slot : prof_ring_)
+            for (int s = 0; s < ST_COUNT; ++s) {
+                hipSafeCall(hipEventCreate(&slot.ev[s][0]));
+                hipSafeCall(hipEventCreate(&slot.ev[s][1]));
+                slot.used[s] = false;
+            }
+    }
+    if (!on && profiling) collect_stage_times();
+    profiling = on;
+}
 void KinectFusionReconstruction::stage_begin(int st) {
     if (!profiling) return;
-    hipSafeCall(hipEventRecord(ev_[st][0], current_stream()));
+    hipSafeCall(hipEventRecord(prof_ring_[prof_pending_].ev[st][0], current_stream()));
 }
 void KinectFusionReconstruction::stage_end(int st) {
     if (!profiling) return;
-    hipSafeCall(hipEventRecord(ev_[st][1], current_stream()));
-    ev_used_[st] = true;
+    hipSafeCall(hipEventRecord(prof_ring_[prof_pending_].ev[st][1], current_stream()));
+    prof_ring_[prof_pending_].used[st] = true;
+}
+void KinectFusionReconstruction::end_profiled_frame() {
+    // counters of this frame -> pinned ring, asynchronously; nothing waits here
+    hipSafeCall(hipMemcpyAsync(pinned_counters_ + 2 * prof_pending_, counters_.ptr(), 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               current_stream()));
+    if (++prof_pending_ == PROF_RING) collect_stage_times();
 }
 void KinectFusionReconstruction::collect_stage_times() {
-    hipSafeCall(hipMemcpyAsync(pinned_counters_, counters_.ptr(), 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, current_stream()));
     synchronize();
-    cum_updated += (long long)pinned_counters_[0];
-    cum_hits += (long long)pinned_counters_[1];
-    for (int s = 0; s < ST_COUNT; ++s) {
-        if (!ev_used_[s]) continue;
-        float ms = 0.f;
-        hipSafeCall(hipEventElapsedTime(&ms, ev_[s][0], ev_[s][1]));
-        stage_ms[s] += ms;
-        stage_calls[s] += 1;
-        ev_used_[s] = false;
+    for (int f = 0; f < prof_pending_; ++f) {
+        cum_updated += (long long)pinned_counters_[2 * f];
+        cum_hits += (long long)pinned_counters_[2 * f + 1];
+        for (int s = 0; s < ST_COUNT; ++s) {
+            if (!prof_ring_[f].used[s]) continue;
+            float ms = 0.f;
+            hipSafeCall(hipEventElapsedTime(&ms, prof_ring_[f].ev[s][0], prof_ring_[f].ev[s][1]));
+            stage_ms[s] += ms;
+            stage_calls[s] += 1;
+            prof_ring_[f].used[s] = false;
+        }
     }
+    prof_pending_ = 0;
 }

@@ -120,13 +120,23 @@ private:
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
     double *pinned_sums_ = nullptr;            // host-coherent: [0..54] sums + count, [56] completion sequence word
     unsigned long long icp_seq_ = 0;
+    hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
+    hipEvent_t surface_done_ = nullptr;
     bool profiling_icp_sync = false;           // true: copy + stream synchronise instead of the spin (debug aid)
     void icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv, const devComplex3 &tprev, int level,
                               hostComplexICP *A, hostComplexICP *b, long long *inliers);
-    unsigned long long *pinned_counters_ = nullptr;
-    hipEvent_t ev_[ST_COUNT + 1][2];
-    bool ev_used_[ST_COUNT];
+    // deferred profiling: one slot of events + one pinned counter record per frame, folded into
+    // stage_ms / cum_* only when somebody asks (no per-frame synchronisation)
+    enum { PROF_RING = 1024 };
+    struct ProfSlot { hipEvent_t ev[ST_COUNT][2]; bool used[ST_COUNT]; };
+    std::vector<ProfSlot> prof_ring_;
+    int prof_pending_ = 0;
+    unsigned long long *pinned_counters_ = nullptr;  // [PROF_RING][2]
     void stage_begin(int st);
     void stage_end(int st);
-    void collect_stage_times();
+    void end_profiled_frame();
+public:
+    void collect_stage_times();  // synchronises and folds the pending frames
+    void set_profiling(bool on);
+private:
 };

@@ -26,7 +26,7 @@ inline void safe_call(hipError_t err, const char *msg = nullptr) {
         exit(-1);
     }
 }
-inline hipStream_t &current_stream() { static hipStream_t s = nullptr; return s; }
+inline hipStream_t &current_stream() { static thread_local hipStream_t s = nullptr; return s; }  // per host thread
 }  // namespace xs_host
 #define hipSafeCall(e) xs_host::safe_call((e), #e)
 

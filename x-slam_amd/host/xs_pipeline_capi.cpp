@@ -106,18 +106,21 @@ void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes) {
     return a.ptr();
 }
 
-void xs_kf_set_profiling(void *kf, int on) { ((KF *)kf)->profiling = on != 0; }
+void xs_kf_set_profiling(void *kf, int on) { ((KF *)kf)->set_profiling(on != 0); }
 void xs_kf_stage_times(void *kf, double *ms6, long long *calls6) {
     KF *k = (KF *)kf;
+    if (k->profiling) k->collect_stage_times();
     for (int i = 0; i < KF::ST_COUNT; ++i) { if (ms6) ms6[i] = k->stage_ms[i]; if (calls6) calls6[i] = k->stage_calls[i]; }
 }
 void xs_kf_cumulative_counters(void *kf, long long *updated, long long *hits) {
     KF *k = (KF *)kf;
+    if (k->profiling) k->collect_stage_times();
     if (updated) *updated = k->cum_updated;
     if (hits) *hits = k->cum_hits;
 }
 void xs_kf_reset_stage_times(void *kf) {
     KF *k = (KF *)kf;
+    if (k->profiling) k->collect_stage_times();
     k->cum_updated = 0; k->cum_hits = 0;
     for (int i = 0; i < KF::ST_COUNT; ++i) { k->stage_ms[i] = 0; k->stage_calls[i] = 0; }
 }
