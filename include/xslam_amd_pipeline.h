@@ -15,6 +15,11 @@
 extern "C" {
 #endif
 
+/* Host DoubleComplex (x-slam_amd/host/DoubleComplex.h, mirroring DeviceArray/include/DoubleComplex.h:15-95)
+ * over arrays of n groups (re.re, re.im, im.re, im.im).  op: 0 add 1 sub 2 mul 3 div 4 sqrt 5 abs 6 exp
+ * 7 log 8 sin 9 cos 10 pow(x, y.re.re) 11 f1(x, y) = (x + y)^2 12 conj 13 norm 14 (x > y, x < y).  CPU only. */
+int xs_host_double_complex_table(int op, long n, const float *a, const float *b, float *out);
+
 /* hipStream_t (as void*) every later call enqueues on; NULL = default stream */
 void xs_kf_set_stream(void *stream);
 /* KinectFusionReconstruction() + SetYamlParameters(config)     KinectFusionReconstruction.cpp:4-73

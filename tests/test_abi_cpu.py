@@ -59,3 +59,34 @@ def test_product_never_imports_the_oracle():
     for lib in ("libxslam_hip.so", "libxslam_host.so"):
         blob = open(os.path.join(pkg, lib), "rb").read()
         assert b"liboracle" not in blob and b"orc_" not in blob
+
+
+def test_host_double_complex_class_against_oracle(oracle):
+    """x-slam_amd/host/DoubleComplex.h (the product's host dual-complex class, CPU code) against the
+    oracle's restatement of DeviceArray/src/DoubleComplex.cpp and the test_CSFD known answers."""
+    import json
+    import numpy as np
+    from conftest import GOLDEN, load_golden, ulp_diff
+    pl = importlib.import_module("x-slam_amd.pipeline")
+    t = load_golden("scalar_tables.npz")
+    a, b, pos = t["d_a"], t["d_b"], t["d_pos"]
+    for op in ("add", "sub", "mul"):
+        assert ulp_diff(pl.host_double_complex(op, a, b), oracle.hdop(op, a, b)).max() == 0, op
+    got, want = pl.host_double_complex("div", a, b), oracle.hdop("div", a, b)  # std::complex '/' is lowered differently by clang and gcc
+    assert np.allclose(got[:, :3], want[:, :3], rtol=2e-5, atol=1e-12) and np.allclose(got[:, 3], want[:, 3], rtol=2e-4, atol=1e-18)
+    for op in ("sqrt", "abs", "exp", "log", "sin", "cos"):
+        got, want = pl.host_double_complex(op, pos), oracle.hdop(op, pos)
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-12), op  # clang vs gcc complex lowering: an ulp
+    y = np.zeros_like(pos); y[:, 0] = 2.5
+    assert np.allclose(pl.host_double_complex("pow", pos, y), oracle.hdop("pow", pos, y), rtol=5e-6, atol=1e-12)
+    assert ulp_diff(pl.host_double_complex("f1", a, b), oracle.hdop("f1", a, b)).max() == 0
+    c = pl.host_double_complex("cmp", a, b)
+    assert np.array_equal(c[:, 0] == 1, a[:, 0] > b[:, 0]) and np.array_equal(c[:, 1] == 1, a[:, 0] < b[:, 0])
+    # DCSFD of f(t) = (t^2 + sin t)^2 at t = 0.5 (test_CSFD part 2): gradient 2.73911, second derivative 9.26892
+    ka = json.load(open(os.path.join(GOLDEN, "test_csfd_known_answers.json")))
+    h = 1e-6
+    tt = np.array([[0.5, h, h, 0.0]], np.float32)
+    x = pl.host_double_complex("mul", tt, tt)
+    yv = pl.host_double_complex("sin", tt)
+    loss = pl.host_double_complex("f1", x, yv)[0]
+    assert abs(loss[1] / h - ka["dcsfd_gradient"]) < 2e-4 and abs(loss[3] / h / h - ka["dcsfd_second"]) < 2e-2

@@ -14,7 +14,8 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 #include <utility>
 #include <vector>
 

@@ -1,5 +1,6 @@
 // xs_pipeline_capi.cpp — C ABI over KinectFusionReconstruction (include/xslam_amd_pipeline.h).
 #include "../../include/xslam_amd_pipeline.h"
+#include "DoubleComplex.h"
 #include "KinectFusionReconstruction.h"
 #include <cstring>
 #include <exception>
@@ -8,6 +9,34 @@ typedef KinectFusionReconstruction KF;
 using xs_host::Matrix4cf;
 
 extern "C" {
+
+// host DoubleComplex over arrays of (re.re, re.im, im.re, im.im) groups
+int xs_host_double_complex_table(int op, long n, const float *a, const float *b, float *out) {
+    for (long i = 0; i < n; ++i) {
+        const DoubleComplex x(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]), y(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+        DoubleComplex r;
+        switch (op) {
+            case 0: r = x + y; break;
+            case 1: r = x - y; break;
+            case 2: r = x * y; break;
+            case 3: r = x / y; break;
+            case 4: r = sqrt(x); break;
+            case 5: r = DoubleComplex(abs(x)); break;
+            case 6: r = exp(x); break;
+            case 7: r = log(x); break;
+            case 8: r = sin(x); break;
+            case 9: r = cos(x); break;
+            case 10: r = pow(x, y.real().real()); break;
+            case 11: { const DoubleComplex s = x + y; r = s * s; break; }  // f1 of test_CSFD/main.cpp:8-11
+            case 12: r = conj(x); break;
+            case 13: r = DoubleComplex(norm(x)); break;
+            case 14: r = DoubleComplex(SingleComplex((x > y) ? 1.f : 0.f, (x < y) ? 1.f : 0.f)); break;
+            default: return -1;
+        }
+        out[4 * i] = r.real().real(); out[4 * i + 1] = r.real().imag(); out[4 * i + 2] = r.imag().real(); out[4 * i + 3] = r.imag().imag();
+    }
+    return 0;
+}
 
 void xs_kf_set_stream(void *stream) { xs_host::current_stream() = (hipStream_t)stream; }
 
@@ -42,7 +71,7 @@ void xs_kf_destroy(void *kf) { delete (KF *)kf; }
 void xs_kf_set_gt_poses(void *kf, int n, const float *c2w32) {
     KF *k = (KF *)kf;
     k->gt_poses.resize(n);
-    for (int i = 0; i < n; ++i) std::memcpy(&k->gt_poses[i], c2w32 + 32 * i, 32 * sizeof(float));
+    for (int i = 0; i < n; ++i) std::memcpy(static_cast<void *>(&k->gt_poses[i]), c2w32 + 32 * i, 32 * sizeof(float));
 }
 
 int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) {

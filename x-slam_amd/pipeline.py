@@ -22,6 +22,7 @@ COLLECTIVE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_long)  # 
 _SIGS = {
     "xs_kf_create_sharded": (_vp, [C.c_char_p, C.c_int, C.c_int, COLLECTIVE_CB, _vp]),
     "xs_kf_shard_planes": (None, [_vp, _i32p, _i32p]),
+    "xs_host_double_complex_table": (C.c_int, [C.c_int, C.c_long, _f32p, _f32p, _f32p]),
     "xs_kf_set_stream": (None, [_vp]),
     "xs_kf_create": (_vp, [C.c_char_p]),
     "xs_kf_destroy": (None, [_vp]),
@@ -65,6 +66,21 @@ def yaml_text(params: dict) -> str:
             v = repr(float(np.float32(v))) if abs(v) < 1e-3 and v != 0 else repr(v)
         out.append(f"{k}: {v}")
     return "\n".join(out) + "\n"
+
+
+HDC_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "sqrt": 4, "abs": 5, "exp": 6, "log": 7, "sin": 8, "cos": 9, "pow": 10, "f1": 11,
+           "conj": 12, "norm": 13, "cmp": 14}
+
+
+def host_double_complex(op, a, b=None):
+    """Elementwise host DoubleComplex op over [n, 4] float32 arrays (CPU; no GPU involved)."""
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 4)
+    out = np.empty_like(a)
+    rc = _lib.xs_host_double_complex_table(HDC_OPS[op], a.shape[0], a.ctypes.data_as(_f32p), b.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
+    if rc != 0:
+        raise ValueError("bad op")
+    return out
 
 
 def set_stream(stream):
