@@ -181,14 +181,14 @@ def main():
     if world > 1:
         nbytes = nbytes / world  # per launch: each rank's kernel covers its own slab
     out = {
-        "metric": "fps XKinectFusion 512^3 TSDF 640x480 CSFD", "value": round(fps, 3), "unit": "frames/s",
+        "metric": "fps XKinectFusion 512^3 TSDF 640x480 CSFD @1/2/4/8 GPU; HBM GB/s on integrate", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1000.0 * dt / K, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32 (complex<f32> CSFD)", "data": "synthetic",
         "config": {"workload": f"XKinectFusion scene S1 (plane+sphere, ICL intrinsics), {N}^3 TSDF, 640x480, first-order CSFD seed "
                                f"i*1e-7 on world2camera(0,3), 3 pyramid levels x (5,4,3) ICP iterations",
                    "volume": f"{N}^3", "voxel_size_m": round(7.68 / N, 6), "frames_resident_in_hbm": True,
                    "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + ICP row shards, RCCL all-reduce of the 6x6|6x1 normal equations"},
-        "roofline": {"kernel": "k_integrate (TSDF integrate)", "bound": "hbm", "achieved": round(nbytes / int_ms / 1e6, 2),
+        "roofline": {"kernel": "k_integrate_bricks (TSDF integrate)", "bound": "hbm", "achieved": round(nbytes / int_ms / 1e6, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / int_ms / 1e6 / HBM_PEAK_GBS, 5), "traffic": None,
                      "algorithmic_bytes_per_launch": round(nbytes), "U_per_frame": round(U, 1), "kernel_ms": round(int_ms, 5)},
         "stages_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in st.items()},

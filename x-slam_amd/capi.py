@@ -44,6 +44,7 @@ _SIGS = {
     "xs_integrate_scaled": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float,
                                       _vp, _vp, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
+    "xs_integrate_set_timing_events": (None, [_vp, _vp]),
     "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "xs_tsdf_reduce_workspace_bytes": (_sz, []),
     "xs_compute_local_tsdf_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,

@@ -491,6 +491,13 @@ static void host_frustum(IntegrateArgs &a) {
     }
 }
 
+// optional profiling hook: HIP events recorded immediately around the integrate kernel proper
+// (after the brick classification), on the launch stream
+static thread_local hipEvent_t g_int_ev0 = nullptr, g_int_ev1 = nullptr;
+extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) {
+    g_int_ev0 = (hipEvent_t)start_event; g_int_ev1 = (hipEvent_t)stop_event;
+}
+
 /* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
@@ -535,6 +542,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         const int gmax = env_g > 0 ? env_g : 8192;
         const int g = nb < gmax ? nb : gmax;
         static const int env_q = getenv("XS_BRICK_QUAD") ? atoi(getenv("XS_BRICK_QUAD")) : 0;
+        if (g_int_ev0) XS_CHECK(hipEventRecord(g_int_ev0, st));
         const bool quad = env_q == 1 && (vol_step % 16) == 0 && (((size_t)value | (size_t)weight | (size_t)grad) % 16) == 0;
         if (quad) {
             if (threshold > 0.0f)
@@ -545,6 +553,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
             hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
         else
             hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
+        if (g_int_ev1) XS_CHECK(hipEventRecord(g_int_ev1, st));
     } else {
         int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
         while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;

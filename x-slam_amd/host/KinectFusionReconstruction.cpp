@@ -327,7 +327,12 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
                                 depthRawScaled_d.step(), depth_max_dev, st), "scaleDepth");
     stage_end(ST_SCALE);
-    stage_begin(ST_INTEGRATE);
+    // ST_INTEGRATE brackets the integrate kernel proper of the owned planes (the events are recorded
+    // inside xs_integrate_scaled, after the brick classification): the figure the roofline uses
+    if (profiling) {
+        xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], prof_ring_[prof_pending_].ev[ST_INTEGRATE][1]);
+        prof_ring_[prof_pending_].used[ST_INTEGRATE] = true;
+    }
     {
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
@@ -341,9 +346,9 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
                                          &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
                                          grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters_.ptr() : nullptr,
                                          depth_max_dev, integrate_ws_.ptr(), st), "integrateTsdfVolume");
+            if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);
         }
     }
-    stage_end(ST_INTEGRATE);
 
     stage_begin(ST_RAYCAST);
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);

@@ -123,3 +123,17 @@ class ShardedKinectFusion(pl.KinectFusion):
         a = (self.owned[0] - self.stored[0]) * self.res[0] * self.res[1]
         b = (self.owned[1] - self.stored[0]) * self.res[0] * self.res[1]
         return v[a:b], w[a:b], g[a:b]
+
+
+def tsdf_hessian_sharded(dist, rank, world, depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, gt_slab,
+                         workspace, out4, stream=None):
+    """BASELINE config 4: the dual-complex Hessian kernel on this rank's z-slab of the ground-truth
+    TSDF (gt_slab: dense planes [z0, z1) of the slab_bounds(rank, world, Z) owned range), then one
+    all-reduce of the four sums {loss, grad, hessian, count}.  out4: 4-double CUDA tensor."""
+    from . import capi
+    (z0, z1), _ = slab_bounds(rank, world, int(res[2]))
+    capi.compute_local_tsdf_hessian(depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, gt_slab,
+                                    workspace, out4, z0=z0, z1=z1, stream=stream)
+    if world > 1:
+        reduce_tensor(dist, OP_SUM_F64, out4)
+    return out4
