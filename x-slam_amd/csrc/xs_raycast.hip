@@ -82,11 +82,11 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     const int tiles_x = (a.cols + 15) / 16, tiles_y = (a.rows + 15) / 16, ntiles = tiles_x * tiles_y;
     const int per_xcd = (ntiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles) return;
+    const bool tile_ok = tile < ntiles;
     const int x = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
     unsigned hit = 0;
-    if (x < a.cols && y < a.rows) {
+    if (tile_ok && x < a.cols && y < a.rows) {
         int key = 0x7fffffff, step_index = 0;
         if (SLAB) {
             // contributions of the ranks are added (as int32 bit patterns) after the first event
@@ -231,8 +231,16 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
         if (SLAB) a.keys[y * a.cols + x] = key;
     }
     if (a.hits) {
-        unsigned s = wave_sum_u32(hit);
-        if (lane == 0 && s) atomicAdd(a.hits, (unsigned long long)s);
+        // one atomic per workgroup: same-address atomics cost ~12 ns each at the memory side, and one
+        // per wave (4800 of them) would by itself take longer than the kernel
+        __shared__ unsigned s_hits[4];
+        const unsigned s = wave_sum_u32(hit);
+        if (lane == 0) s_hits[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = (s_hits[0] + s_hits[1]) + (s_hits[2] + s_hits[3]);
+            if (t) atomicAdd(a.hits, (unsigned long long)t);
+        }
     }
 }
 

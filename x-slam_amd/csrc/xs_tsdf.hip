@@ -99,9 +99,9 @@ extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows
 }
 
 // ------------------------------------------------------------------------------------------
-// Brick geometry: 64 (x) x 4 (y) x 16 (z) voxels = one 256-thread workgroup, lane = x, so every
+// Brick geometry: 64 (x) x 4 (y) x 8 (z) voxels = one 256-thread workgroup, lane = x, so every
 // volume access of a wave is one 256-byte row segment.
-enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 16 };
+enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
 
 // Half-spaces of the (padded) view frustum in the volume's voxel-index space, built on the
 // host and passed as kernel arguments (wave-uniform: they live in scalar registers).  Along any
@@ -299,6 +299,27 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
 }
 }  // namespace
 
+// One atomic per workgroup (a same-address atomic costs ~12 ns on this chip: one per wave of a
+// few thousand bricks would serialise into tens of microseconds), spread over `nslots` words.
+__device__ __forceinline__ void block_count_add(unsigned n_upd, unsigned long long *slots, unsigned nslots) {
+    __shared__ unsigned s_cnt[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const unsigned s = wave_sum_u32(n_upd);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (t) atomicAdd(slots + (b % nslots), (unsigned long long)t);
+    }
+}
+enum { COUNT_SLOTS = 16 };  // in the workspace header, after the brick count (8-byte words 1..16)
+__global__ void k_fold_count(unsigned long long *slots, unsigned long long *updated) {
+    unsigned long long t = 0;
+    for (int i = 0; i < COUNT_SLOTS; ++i) { t += slots[i]; slots[i] = 0; }
+    if (t) atomicAdd(updated, t);
+}
+
 // ---- path 1: column walk (no workspace): thread (x, y) walks its clipped z interval ---------
 template <bool BILINEAR>
 __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
@@ -312,10 +333,7 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
         clip_column(f, x, y, zb, ze);
         if (zb < ze) n_upd = integrate_span<BILINEAR>(a, x, y, zb, ze);
     }
-    if (a.updated) {
-        unsigned s = wave_sum_u32(n_upd);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.updated, (unsigned long long)s);
-    }
+    if (a.updated) block_count_add(n_upd, a.updated, 1);
 }
 
 // ---- path 2: brick work list ------------------------------------------------------------------
@@ -357,10 +375,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
             if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
         }
     }
-    if (a.updated) {
-        unsigned s = wave_sum_u32(n_upd);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.updated, (unsigned long long)s);
-    }
+    if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
 }
 
 // ---- path 2b: brick work list, four x per lane ---------------------------------------------
@@ -435,10 +450,7 @@ __global__ void __launch_bounds__(256) k_integrate_bricks_q(const IntegrateArgs 
             n_upd += __popc(mask);
         }
     }
-    if (a.updated) {
-        unsigned s = wave_sum_u32(n_upd);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.updated, (unsigned long long)s);
-    }
+    if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
 }
 
 static void load_mat(const float *p, MatS33 &m) {
@@ -535,7 +547,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         a.brick_count = (unsigned *)workspace;
         a.brick_list = (int *)((char *)workspace + 256);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-        XS_CHECK(hipMemsetAsync(a.brick_count, 0, sizeof(unsigned), st));
+        XS_CHECK(hipMemsetAsync(a.brick_count, 0, 8 * (1 + COUNT_SLOTS), st));  // brick count + update-count slots
         hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
         // resident workgroups stride over the list: 256 CUs x 8
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
@@ -554,6 +566,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         else
             hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
         if (g_int_ev1) XS_CHECK(hipEventRecord(g_int_ev1, st));
+        if (updated_dev) hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
     } else {
         int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
         while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
