@@ -20,6 +20,11 @@ extern "C" {
  * 7 log 8 sin 9 cos 10 pow(x, y.re.re) 11 f1(x, y) = (x + y)^2 12 conj 13 norm 14 (x > y, x < y).  CPU only. */
 int xs_host_double_complex_table(int op, long n, const float *a, const float *b, float *out);
 
+/* Flat "key: value" config reader (x-slam_amd/host/flat_yaml.hpp; stands in for yaml-cpp's
+ * config["k"].as<T>() of KinectFusionReconstruction.cpp:12-72): copies the value of key into out.
+ * Returns its length, -1 if the key is absent.  CPU only. */
+int xs_flat_yaml_get(const char *yaml_text, const char *key, char *out, int capacity);
+
 /* hipStream_t (as void*) every later call enqueues on; NULL = default stream */
 void xs_kf_set_stream(void *stream);
 /* KinectFusionReconstruction() + SetYamlParameters(config)     KinectFusionReconstruction.cpp:4-73

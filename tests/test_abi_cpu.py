@@ -90,3 +90,70 @@ def test_host_double_complex_class_against_oracle(oracle):
     yv = pl.host_double_complex("sin", tt)
     loss = pl.host_double_complex("f1", x, yv)[0]
     assert abs(loss[1] / h - ka["dcsfd_gradient"]) < 2e-4 and abs(loss[3] / h / h - ka["dcsfd_second"]) < 2e-2
+
+
+def test_flat_yaml_reads_the_reference_config_format():
+    """The reference's shipped config (Experiments/test_xkinect_fusion/configs/ICL_traj2.yaml) is flat
+    key: value with comments, quoted strings and blank lines; all 34 keys must come through."""
+    pl = importlib.import_module("x-slam_amd.pipeline")
+    text = """# -------------------------------------Dataset------------------------------------------------
+dataset_format: ICL
+dataset_dir: "../dataset/ICL/traj2/"
+output_dir: "../output/ICL/traj2/"   # trailing comment
+start_frame: 0
+end_frame: 300
+frame_step: 1
+factor: 1
+is_flip: false
+
+# ------------------------------ Output Setting -------------------------------
+log_slam_pose: true
+log_gt_pose: true
+draw_pcd: true
+# note: big threshold may influence the result
+biInterpolate_threshold: 0.00
+trunc_logistic_k: 0
+flag_use_gtPose: false
+
+# tsdf volume
+tsdf_size_x: 256
+tsdf_size_y: 256
+tsdf_size_z: 256
+tsdf_voxel_size: 0.03
+max_integration_weight: 100
+thres_range: 3
+init_x: 3.2
+init_y: 3.2
+init_z: 3.2
+r_x: 0
+r_y: 0
+r_z: 0
+depth_width: 640
+depth_height: 480
+fx: 481.20
+fy: -480.00
+cx: 319.50
+cy: 239.50
+
+# ICP
+num_levels: 3
+distThres: 0.10
+angleThres: 15
+"""
+    want = {"dataset_format": "ICL", "dataset_dir": "../dataset/ICL/traj2/", "output_dir": "../output/ICL/traj2/", "start_frame": "0",
+            "end_frame": "300", "frame_step": "1", "factor": "1", "is_flip": "false", "log_slam_pose": "true", "log_gt_pose": "true",
+            "draw_pcd": "true", "biInterpolate_threshold": "0.00", "trunc_logistic_k": "0", "flag_use_gtPose": "false",
+            "tsdf_size_x": "256", "tsdf_size_y": "256", "tsdf_size_z": "256", "tsdf_voxel_size": "0.03", "max_integration_weight": "100",
+            "thres_range": "3", "init_x": "3.2", "init_y": "3.2", "init_z": "3.2", "r_x": "0", "r_y": "0", "r_z": "0",
+            "depth_width": "640", "depth_height": "480", "fx": "481.20", "fy": "-480.00", "cx": "319.50", "cy": "239.50",
+            "num_levels": "3", "distThres": "0.10", "angleThres": "15"}
+    assert len(want) == 35
+    for k, v in want.items():
+        assert pl.flat_yaml_get(text, k) == v, k
+    assert pl.flat_yaml_get(text, "csfd_seed_row") is None
+    # the text produced from a parameter dict round-trips
+    synth = importlib.import_module("x-slam_amd.synth")
+    prm = synth.s1_params(512)
+    t2 = pl.yaml_text(prm)
+    assert float(pl.flat_yaml_get(t2, "tsdf_voxel_size")) == prm["tsdf_voxel_size"]
+    assert pl.flat_yaml_get(t2, "flag_use_gtPose") == "false" and int(pl.flat_yaml_get(t2, "csfd_seed_col")) == 3

@@ -185,3 +185,39 @@ def test_host_and_device_depth_entry_points_agree(dev):
         assert a.process_frame(upload(torch, d)) == 1 and b.process_frame_host(d) == 1
     assert np.array_equal(a.world2camera(), b.world2camera())
     a.close(); b.close()
+
+
+def test_alignment_failure_does_not_advance(dev):
+    """A frame with no valid depth gives a singular 6x6 system: ProcessFrame returns 0 and frame_id
+    stays (KinectFusionReconstruction.cpp:151-157, :203-210); the next good frame still tracks."""
+    torch, pl = dev
+    prm = synth.s1_params(64)
+    kf = pl.KinectFusion(prm)
+    assert kf.process_frame(upload(torch, synth.s1_frame(0))) == 1 and kf.frame_id == 1
+    blank = np.zeros((H, W), np.uint16)
+    poses = kf.num_poses()
+    assert kf.process_frame(upload(torch, blank)) == 0
+    assert kf.frame_id == 1 and kf.num_poses() == poses
+    assert kf.process_frame(upload(torch, synth.s1_frame(1))) == 1 and kf.frame_id == 2
+    kf.close()
+
+
+@pytest.mark.parametrize("levels,width,height", [(2, 640, 480), (3, 320, 240), (1, 640, 480)])
+def test_other_pyramid_depths_and_image_sizes(dev, oracle, levels, width, height):
+    torch, pl = dev
+    from oracle.oracle import OracleKinFu, params_from_dict
+    prm = synth.s1_params(64)
+    s = width / 640.0
+    prm.update(num_levels=levels, depth_width=width, depth_height=height, fx=synth.FX * s, fy=synth.FY * s,
+               cx=(synth.CX + 0.5) * s - 0.5, cy=(synth.CY + 0.5) * s - 0.5)
+    kf = pl.KinectFusion(prm)
+    ok_ = OracleKinFu(oracle, params_from_dict(prm))
+    for k in range(2):
+        d = synth.render_s1(synth.s1_pose(k), width=width, height=height, fx=prm["fx"], fy=prm["fy"], cx=prm["cx"], cy=prm["cy"])
+        assert kf.process_frame(upload(torch, d)) == 1 and ok_.process_frame(d) == 1
+        pose_close(kf.world2camera(), ok_.world2camera(), value_tol=1e-6, deriv_rel=1e-6)
+    assert abs(kf.last_U() - ok_.last_U()) <= max(3, 1e-4 * ok_.last_U())
+    v, w, g = kf.volume()
+    ov, ow, og = ok_.volume()
+    assert mismatch_fraction(w, ow) <= 1e-4
+    kf.close()

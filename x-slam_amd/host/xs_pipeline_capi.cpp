@@ -38,6 +38,20 @@ int xs_host_double_complex_table(int op, long n, const float *a, const float *b,
     return 0;
 }
 
+// flat-YAML reader probe (CPU only): value of `key` in `yaml_text` as the reader sees it
+int xs_flat_yaml_get(const char *yaml_text, const char *key, char *out, int capacity) {
+    try {
+        const xs_host::FlatYaml y = xs_host::FlatYaml::Load(yaml_text ? yaml_text : "");
+        if (!y.has(key)) return -1;
+        const std::string v = y.as<std::string>(key);
+        if ((int)v.size() + 1 > capacity) return -2;
+        std::memcpy(out, v.c_str(), v.size() + 1);
+        return (int)v.size();
+    } catch (const std::exception &) {
+        return -3;
+    }
+}
+
 void xs_kf_set_stream(void *stream) { xs_host::current_stream() = (hipStream_t)stream; }
 
 void *xs_kf_create_sharded(const char *yaml_text, int rank, int count, void (*collective)(void *, int, void *, long), void *user) {

@@ -23,6 +23,7 @@ _SIGS = {
     "xs_kf_create_sharded": (_vp, [C.c_char_p, C.c_int, C.c_int, COLLECTIVE_CB, _vp]),
     "xs_kf_shard_planes": (None, [_vp, _i32p, _i32p]),
     "xs_host_double_complex_table": (C.c_int, [C.c_int, C.c_long, _f32p, _f32p, _f32p]),
+    "xs_flat_yaml_get": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
     "xs_kf_set_stream": (None, [_vp]),
     "xs_kf_create": (_vp, [C.c_char_p]),
     "xs_kf_destroy": (None, [_vp]),
@@ -81,6 +82,12 @@ def host_double_complex(op, a, b=None):
     if rc != 0:
         raise ValueError("bad op")
     return out
+
+
+def flat_yaml_get(text, key):
+    buf = C.create_string_buffer(1024)
+    n = _lib.xs_flat_yaml_get(text.encode(), key.encode(), buf, 1024)
+    return None if n < 0 else buf.value.decode()
 
 
 def set_stream(stream):
