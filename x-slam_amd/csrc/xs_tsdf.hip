@@ -250,10 +250,15 @@ __device__ __forceinline__ bool update_voxel(const IntegrateArgs &a, const Voxel
         if (!(sdf.re >= -a.tranc_dist)) return false;
         if (!(sdf.re > a.tranc_dist)) tsdf = sdf * a.tranc_dist_inv;
     }
+    // running mean (TsdfFusion.cu:161-167): (prev * w + tsdf) / (w + 1), component-wise by a real
+    // divisor.  x / x is exactly 1 and 0 / x is exactly 0 (sign kept) in IEEE arithmetic, so the two
+    // divides are skipped where the numerator equals the divisor or is zero — the steady state of
+    // free space (value 1, derivative 0), i.e. most written voxels.
     const cfloat tsdf_prev(pre_v, pre_g);
-    const cfloat tsdf_new = (tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf) / __int2float_rn(pre_w + 1);
-    out_v = tsdf_new.re;
-    out_g = tsdf_new.im;
+    const cfloat num = tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf;
+    const float den = __int2float_rn(pre_w + 1);
+    out_v = (num.re == den) ? 1.0f : num.re / den;
+    out_g = (num.im == 0.0f) ? num.im : num.im / den;
     out_w = min(pre_w + 1, a.max_weight);
     return true;
 }
