@@ -18,6 +18,7 @@ struct RaycastArgs {
     MatS33 Rc2v; cfloat3 tc2v; MatS33 Rv2w; cfloat3 tv2w;
     int X, Y, Z;
     float voxel_size, time_step;
+    float inv_vs_lo, inv_vs_hi;  // 1/voxel_size nudged 4 ulp down / up (march index shortcut)
     int cols, rows;
     const float *value; const float *grad; size_t vstep;
     Intr intr;
@@ -31,6 +32,16 @@ struct RaycastArgs {
 
 namespace {
 __device__ __forceinline__ int sgn(float v) { return (0.0f < v) - (v < 0.0f); }
+
+// floor(fl(p / vs)) — getVoxel, RayCaster.cu:80-86 — without the IEEE divide: the two products bracket
+// fl(p / vs) (the reciprocals are 4 ulp either side of 1/vs), so when their floors agree that is the
+// answer; otherwise (the quotient lies within ~8 ulp of an integer, ~1e-4 of the samples) the
+// divide is done.
+__device__ __forceinline__ int voxel_index(float p, float vs, float r_lo, float r_hi) {
+    const float f_lo = floorf(p * r_lo), f_hi = floorf(p * r_hi);
+    if (f_lo == f_hi) return (int)f_lo;
+    return __float2int_rd(p / vs);
+}
 
 struct Vol {
     const float *value; const float *grad; size_t vstep; int X, Y, Z; float vs; int zs0, zs1;
@@ -196,34 +207,42 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
             float cross = -1.f;
             bool done = false;
             while (!done && time_curr < max_time) {
+                // four steps at once, straight-line: positions, clamped (always valid) gathers, then one
+                // event mask — out of range / past the end, - to + (no vertex), + to - (crossing) — whose
+                // lowest set bit is the first event along the ray; one branch per four steps
                 float tc[4], val[4];
-                bool live[4], inb[4];
+                unsigned oob = 0;
                 float t = time_curr;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     tc[j] = t;
-                    live[j] = t < max_time;
                     const float tn = t + time_step;
-                    const int jx = __float2int_rd((sx + dx * tn) / vs);
-                    const int jy = __float2int_rd((sy + dy * tn) / vs);
-                    const int jz = __float2int_rd((sz + dz * tn) / vs);
-                    inb[j] = jx >= 0 && jy >= 0 && jz >= 0 && jx < a.X && jy < a.Y && jz < a.Z;
-                    val[j] = (live[j] && inb[j]) ? vol.read_value(jx, jy, jz) : 0.f;
+                    const int jx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const int jy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const int jz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const bool ok = (t < max_time) && jx >= 0 && jy >= 0 && jz >= 0 && jx < a.X && jy < a.Y && jz < a.Z;
+                    oob |= (ok ? 0u : 1u) << j;
+                    val[j] = vol.read_value(min(max(jx, 0), a.X - 1), min(max(jy, 0), a.Y - 1), min(max(jz, 0), a.Z - 1));
                     t += time_step;
                 }
+                unsigned down = 0, up = 0;  // + to -, - to +
+                float prev = tsdf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (done) break;
-                    if (!live[j] || !inb[j]) { done = true; break; }
-                    const float tsdf_prev = tsdf;
-                    tsdf = val[j];
-                    if (tsdf_prev < 0.f && tsdf > 0.f) { done = true; break; }
-                    if (tsdf_prev > 0.f && tsdf < 0.f) {
-                        if (MODE == 2) cross = tc[j]; else hit = crossing(tc[j], tc[j] + time_step);
-                        done = true;
-                        break;
-                    }
+                    down |= ((prev > 0.f && val[j] < 0.f) ? 1u : 0u) << j;
+                    up |= ((prev < 0.f && val[j] > 0.f) ? 1u : 0u) << j;
+                    prev = val[j];
                 }
+                const unsigned ev = oob | down | up;
+                if (ev) {
+                    const int e = __ffs(ev) - 1;
+                    if (!((oob >> e) & 1u) && ((down >> e) & 1u)) {
+                        const float tce = e == 0 ? tc[0] : e == 1 ? tc[1] : e == 2 ? tc[2] : tc[3];
+                        if (MODE == 2) cross = tce; else hit = crossing(tce, tce + time_step);
+                    }
+                    done = true;
+                }
+                tsdf = val[3];
                 time_curr = t;
             }
             if (MODE == 2) a.cross_t[y * a.cols + x] = cross;
@@ -244,6 +263,11 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     }
 }
 
+static void set_inv_vs(RaycastArgs &a) {
+    float lo = 1.0f / a.voxel_size, hi = lo;
+    for (int i = 0; i < 4; ++i) { lo = nextafterf(lo, 0.f); hi = nextafterf(hi, INFINITY); }
+    a.inv_vs_lo = lo; a.inv_vs_hi = hi;
+}
 static void ld_mat(const float *p, MatS33 &m) {
     for (int r = 0; r < 3; ++r) {
         m.data[r].x = cfloat(p[r * 6 + 0], p[r * 6 + 1]);
@@ -273,6 +297,7 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.X = res[0]; a.Y = res[1]; a.Z = res[2];
     a.voxel_size = voxel_size;
     a.time_step = tranc_dist * 0.8f;  // RayCaster.cu:350
+    set_inv_vs(a);
     a.cols = cols; a.rows = rows;
     a.value = value; a.grad = grad; a.vstep = vol_step;
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
