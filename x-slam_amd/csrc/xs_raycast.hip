@@ -207,14 +207,15 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
             float cross = -1.f;
             bool done = false;
             while (!done && time_curr < max_time) {
-                // four steps at once, straight-line: positions, clamped (always valid) gathers, then one
+                // eight steps at once, straight-line: positions, clamped (always valid) gathers, then one
                 // event mask — out of range / past the end, - to + (no vertex), + to - (crossing) — whose
-                // lowest set bit is the first event along the ray; one branch per four steps
-                float tc[4], val[4];
+                // lowest set bit is the first event along the ray; one branch per eight steps
+                constexpr int NS = 8;
+                float tc[NS], val[NS];
                 unsigned oob = 0;
                 float t = time_curr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NS; ++j) {
                     tc[j] = t;
                     const float tn = t + time_step;
                     const int jx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 unsigned down = 0, up = 0;  // + to -, - to +
                 float prev = tsdf;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NS; ++j) {
                     down |= ((prev > 0.f && val[j] < 0.f) ? 1u : 0u) << j;
                     up |= ((prev < 0.f && val[j] > 0.f) ? 1u : 0u) << j;
                     prev = val[j];
@@ -237,12 +238,14 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 if (ev) {
                     const int e = __ffs(ev) - 1;
                     if (!((oob >> e) & 1u) && ((down >> e) & 1u)) {
-                        const float tce = e == 0 ? tc[0] : e == 1 ? tc[1] : e == 2 ? tc[2] : tc[3];
+                        float tce = tc[0];
+#pragma unroll
+                        for (int j = 1; j < NS; ++j) tce = (e == j) ? tc[j] : tce;
                         if (MODE == 2) cross = tce; else hit = crossing(tce, tce + time_step);
                     }
                     done = true;
                 }
-                tsdf = val[3];
+                tsdf = val[NS - 1];
                 time_curr = t;
             }
             if (MODE == 2) a.cross_t[y * a.cols + x] = cross;
