@@ -88,8 +88,8 @@ extern "C" int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int 
                                   float *max_dev, void *stream) {
     if (!depth || !scaled) return xs_set_error(hipErrorInvalidValue, "xs_scale_depth: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
-    int blocks = div_up(rows * cols, 256 * 16);
-    if (blocks > 256) blocks = 256;
+    int blocks = div_up(rows * cols, 256 * 4);
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(k_scale_depth, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, depth_step, rows, cols, scaled, scaled_step, (unsigned *)max_dev);
     XS_CHECK(hipGetLastError());
     return 0;

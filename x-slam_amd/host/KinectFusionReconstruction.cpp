@@ -16,6 +16,7 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     depth_height = 0;
     hipSafeCall(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     hipSafeCall(hipEventCreateWithFlags(&surface_done_, hipEventDisableTiming));
+    hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, PROF_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < 64; ++i) pinned_sums_[i] = 0.0;
@@ -28,6 +29,7 @@ void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn 
 KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (surface_done_) (void)hipEventDestroy(surface_done_);
+    if (integrate_done_) (void)hipEventDestroy(integrate_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
     if (tsdf_volume_d_ptr) ReleaseBuffers();
@@ -132,8 +134,9 @@ void KinectFusionReconstruction::AllocateBuffers() {
             ray_min_keys_.create((size_t)depth_width * depth_height);
         }
     }
-    counters_.create(3);  // [0] updated voxels, [1] raycast hits, [2] bits of the frame's largest valid depth
-    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 3 * sizeof(unsigned long long), current_stream()));
+    counters_.create(2);  // [0] updated voxels, [1] raycast hits
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), current_stream()));
+    depth_max_.create(4);
 }
 
 // reference :108-123
@@ -317,16 +320,12 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     hipStream_t st = current_stream();
-    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 3 * sizeof(unsigned long long), st));
-    float *depth_max_dev = reinterpret_cast<float *>(counters_.ptr() + 2);
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), st));
+    float *depth_max_dev = depth_max_.ptr();  // filled with the scaled depth by SurfaceMeasure, on the auxiliary stream
     // integrateTsdfVolume (TsdfFusion.cu:173-201), its two launches timed separately
     const int res[3] = {volume_res.x, volume_res.y, volume_res.z};
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
     DeviceArray2D<int> weight = tsdf_volume_d_ptr->weight();
-    stage_begin(ST_SCALE);
-    check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
-                                depthRawScaled_d.step(), depth_max_dev, st), "scaleDepth");
-    stage_end(ST_SCALE);
     // ST_INTEGRATE brackets the integrate kernel proper of the owned planes (the events are recorded
     // inside xs_integrate_scaled, after the brick classification): the figure the roofline uses
     if (profiling) {
@@ -350,6 +349,8 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
         }
     }
 
+    hipSafeCall(hipEventRecord(integrate_done_, st));
+    integrate_recorded_ = true;
     stage_begin(ST_RAYCAST);
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
     stage_end(ST_RAYCAST);
@@ -382,6 +383,16 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
         createNMap(vmaps_curr_d[i], nmaps_curr_d[i]);
     }
     stage_end(ST_SURFACE);
+    // scaleDepthKernal of integrateTsdfVolume (TsdfFusion.cu:182-187) also depends on the depth image
+    // alone: metres + the frame's largest valid depth, ready before integrate needs them
+    // (the previous frame's integrate, possibly still running on the main stream, reads the same
+    // buffers: wait for it — it is the first thing in that frame's tail)
+    if (integrate_recorded_) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_, 0));
+    stage_begin(ST_SCALE);
+    hipSafeCall(hipMemsetAsync(depth_max_.ptr(), 0, sizeof(float), aux_stream_));
+    check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                                depthRawScaled_d.step(), depth_max_.ptr(), aux_stream_), "scaleDepth");
+    stage_end(ST_SCALE);
     hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
     current_stream() = main_stream;
     hipSafeCall(hipStreamWaitEvent(main_stream, surface_done_, 0));
@@ -432,12 +443,12 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
 void KinectFusionReconstruction::synchronize() { hipSafeCall(hipStreamSynchronize(current_stream())); }
 
 long long KinectFusionReconstruction::lastUpdatedVoxels() {
-    unsigned long long h[3];
+    unsigned long long h[2];
     counters_.download(h);
     return (long long)h[0];
 }
 long long KinectFusionReconstruction::lastRaycastHits() {
-    unsigned long long h[3];
+    unsigned long long h[2];
     counters_.download(h);
     return (long long)h[1];
 }

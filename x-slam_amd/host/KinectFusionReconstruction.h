@@ -112,7 +112,8 @@ public:
     void synchronize();
 
 private:
-    DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits, [2] frame depth max (float bits)
+    DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits
+    DeviceArray<float> depth_max_;              // [0] largest valid depth of the frame (scale kernel -> integrate far clip)
     DeviceArray<unsigned char> integrate_ws_;  // brick work list of the integrate kernel
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
@@ -121,7 +122,8 @@ private:
     double *pinned_sums_ = nullptr;            // host-coherent: [0..54] sums + count, [56] completion sequence word
     unsigned long long icp_seq_ = 0;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
-    hipEvent_t surface_done_ = nullptr;
+    hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr;
+    bool integrate_recorded_ = false;
     bool profiling_icp_sync = false;           // true: copy + stream synchronise instead of the spin (debug aid)
     void icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv, const devComplex3 &tprev, int level,
                               hostComplexICP *A, hostComplexICP *b, long long *inliers);
