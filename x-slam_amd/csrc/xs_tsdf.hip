@@ -114,12 +114,22 @@ enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
 // frame's largest depth on the device (alpha[5] holds everything but cfar).
 struct Frustum {
     float alpha[6], bx[6], by[6], bz[6], slack[6];
-    float inv_bz[6];  // 1/bz for the column clip, 0 where bz is too small to divide by
-    int kind[6];      // +1: the plane bounds k from below, -1: from above, 0: no dependence on k worth using
+};
+
+// The same half-spaces solved for k, as the column clip wants them: plane p bounds k at
+//     root_p(i, j) = A + B*i + C*j     (kind +1: k >= root, -1: k <= root),
+// or, where the plane does not depend on k (kind 0), excludes the column when A + B*i + C*j < 0.
+// A already holds the slack.  Three scalars per plane instead of six: the integrate kernels are
+// short of scalar registers (72 at eight waves per SIMD).
+struct ClipPlanes {
+    float A[6], B[6], C[6];
+    float far_scale;  // what a unit of the far limit adds to A[5]
+    int kinds;        // two bits per plane: 0 = no k dependence, 1 = lower bound, 2 = upper bound
 };
 
 struct IntegrateArgs {
     Frustum fr;
+    ClipPlanes cp;
     const float *depth; size_t dstep; int drows, dcols;
     float *value; int *weight; float *grad; size_t vstep;
     int X, Y, Z;        // full resolution
@@ -140,25 +150,29 @@ namespace {
 // the voxel's own ray, so sdf = (Dp - c) * |v_c|/c with |v_c|/c >= 1 and Dp <= Dmax; c > Dmax +
 // trunc therefore gives sdf < -trunc.  Without a frame maximum the valid-depth gate of
 // scaleDepth (5 m, TsdfFusion.cu:77) bounds Dp.
+__device__ __forceinline__ float far_limit(const IntegrateArgs &a) {
+    const float dmax = a.depth_max ? *a.depth_max : 5.0f;
+    return dmax * 1.0001f + 1.05f * a.tranc_dist;
+}
 __device__ __forceinline__ Frustum device_frustum(const IntegrateArgs &a) {
     Frustum f = a.fr;
-    const float dmax = a.depth_max ? *a.depth_max : 5.0f;
-    f.alpha[5] += dmax * 1.0001f + 1.05f * a.tranc_dist;
+    f.alpha[5] += far_limit(a);
     return f;
 }
-// z interval [zb, ze) of column (x, y) that can pass the tests, padded by two voxels.  Branch-free:
-// the plane slopes along z and their reciprocals are wave-uniform kernel arguments.
-__device__ __forceinline__ void clip_column(const Frustum &f, int x, int y, int &zb, int &ze) {
+// z interval [zb, ze) of column (x, y) that can pass the tests, padded by two voxels.  Branch-free per
+// lane: the plane kinds are wave-uniform.
+__device__ __forceinline__ void clip_column(const ClipPlanes &c, float far, int x, int y, int &zb, int &ze) {
     float lo = (float)zb, hi = (float)ze;
     const float i = x + 0.5f, j = y + 0.5f;
     bool empty = false;
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
-        const float v = (f.alpha[p] + f.bx[p] * i + f.by[p] * j) + f.slack[p];  // v + bz*k >= 0
-        const float root = -v * f.inv_bz[p];
-        if (f.kind[p] > 0) lo = fmaxf(lo, root);
-        else if (f.kind[p] < 0) hi = fminf(hi, root);
-        else empty = empty || (v < 0.f);
+        const float a0 = (p == 5) ? c.A[5] + far * c.far_scale : c.A[p];
+        const float root = a0 + c.B[p] * i + c.C[p] * j;
+        const int kind = (c.kinds >> (2 * p)) & 3;
+        if (kind == 1) lo = fmaxf(lo, root);
+        else if (kind == 2) hi = fminf(hi, root);
+        else empty = empty || (root < 0.f);
     }
     zb = max(zb, (int)floorf(lo - 0.5f) - 2);
     ze = empty ? zb : min(ze, (int)ceilf(hi - 0.5f) + 3);
@@ -199,10 +213,9 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Voxe
     if (c < 0) return false;  // Re(1/v_c.z) < 0
     const cfloat px = o.v_c.x * k.fx, py = o.v_c.y * k.fy;
     // early reject before the divides: |true image coordinate - (px/c + cx)| << 1 pixel
-    if (c > 0) {
-        if (px.re < k.ulo * c || px.re > k.uhi * c) return false;
-        if (py.re < k.vlo * c || py.re > k.vhi * c) return false;
-    }
+    // (one min-chain and a single compare instead of four compare-and-branch pairs)
+    const float margin = fminf(fminf(px.re - k.ulo * c, k.uhi * c - px.re), fminf(py.re - k.vlo * c, k.vhi * c - py.re));
+    if (c > 0 && margin < 0) return false;
     const cfloat inv_z = 1.0f / o.v_c.z;
     o.image_x = px * inv_z + k.cx;
     o.image_y = py * inv_z + k.cy;
@@ -257,8 +270,12 @@ __device__ __forceinline__ bool update_voxel(const IntegrateArgs &a, const Voxel
     const cfloat tsdf_prev(pre_v, pre_g);
     const cfloat num = tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf;
     const float den = __int2float_rn(pre_w + 1);
-    out_v = (num.re == den) ? 1.0f : num.re / den;
-    out_g = (num.im == 0.0f) ? num.im : num.im / den;
+    const bool div_v = !(num.re == den), div_g = !(num.im == 0.0f);
+    out_v = 1.0f; out_g = num.im;
+    if (__builtin_amdgcn_ballot_w64(div_v || div_g) != 0) {  // wave-uniform: whole waves of steady free space skip both divides
+        if (div_v) out_v = num.re / den;
+        if (div_g) out_g = num.im / den;
+    }
     out_w = min(pre_w + 1, a.max_weight);
     return true;
 }
@@ -299,6 +316,10 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
         const int w0 = *wpos;
         float ov, og; int ow;
         if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) { *pos = ov; *wpos = ow; *gpos = og; ++n_upd; }
+        else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
+        // (the empty asm consumes the three loads on the paths that left early: without it they are
+        // still in flight at the loop head, and the wait the compiler puts there to protect their
+        // registers also waits for the previous trip's stores to be acknowledged)
     }
     return n_upd;
 }
@@ -334,8 +355,7 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
     if (x < a.X && y < a.Y) {
         int zb = a.z0 + blockIdx.z * a.zchunk;
         int ze = min(zb + a.zchunk, a.z1);
-        const Frustum f = device_frustum(a);
-        clip_column(f, x, y, zb, ze);
+        clip_column(a.cp, far_limit(a), x, y, zb, ze);
         if (zb < ze) n_upd = integrate_span<BILINEAR>(a, x, y, zb, ze);
     }
     if (a.updated) block_count_add(n_upd, a.updated, 1);
@@ -362,97 +382,25 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     unsigned base = 0;
     if (lane == 0 && m) base = atomicAdd(a.brick_count, (unsigned)__popcll(m));
     base = __shfl((int)base, 0, 64);
-    if (active) a.brick_list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    if (active) {  // packed (bx, by, bz), 10 bits each: the consumer decodes with shifts
+        const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
+        a.brick_list[base + __popcll(m & ((1ull << lane) - 1ull))] = bx | (by << 10) | (bz << 20);
+    }
 }
 
 template <bool BILINEAR>
 __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs a) {
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
-    const Frustum f = device_frustum(a);
+    const float far = far_limit(a);
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
         const int b = a.brick_list[e];
-        const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
+        const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int x = bx * BRICK_X + threadIdx.x, y = by * BRICK_Y + threadIdx.y;
         if (x < a.X && y < a.Y) {
             int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
-            clip_column(f, x, y, zb, ze);
+            clip_column(a.cp, far, x, y, zb, ze);
             if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
-        }
-    }
-    if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
-}
-
-// ---- path 2b: brick work list, four x per lane ---------------------------------------------
-// Same bricks, but a lane owns four consecutive x: the voxel state moves as 16-byte vectors
-// (1 KiB per wave-instruction, three of them in flight per wave before any arithmetic), i.e.
-// four times the bytes in flight of the one-voxel-per-lane form at the same occupancy.  The
-// four voxels are then evaluated one after the other by the same per-voxel body; their state
-// waits in LDS meanwhile, so the register footprint stays that of a single voxel.  A wave covers
-// 64 x by 4 y of one plane; the four waves of a workgroup take planes z, z+1, z+2, z+3.
-template <bool BILINEAR>
-__global__ void __launch_bounds__(256) k_integrate_bricks_q(const IntegrateArgs a) {
-    __shared__ float s_v[256][4], s_g[256][4];
-    __shared__ int s_w[256][4];
-    const unsigned count = *a.brick_count;
-    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
-    const int xq = lane & 15, yq = lane >> 4;
-    unsigned n_upd = 0;
-    const Frustum f = device_frustum(a);
-    VoxelCtx k;
-    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
-    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
-    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
-    const size_t pitch = a.vstep / 4;
-    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
-        const int b = a.brick_list[e];
-        const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
-        const int x0 = bx * BRICK_X + xq * 4, y = by * BRICK_Y + yq;
-        if (x0 >= a.X || y >= a.Y) continue;
-        int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
-        {   // union of the z intervals of the quad's first and last column
-            int zb1 = zb, ze1 = ze, zb2 = zb, ze2 = ze;
-            clip_column(f, x0, y, zb1, ze1);
-            clip_column(f, min(x0 + 3, a.X - 1), y, zb2, ze2);
-            zb = min(zb1, zb2); ze = max(ze1, ze2);
-        }
-        const float vgy = (y + 0.5f) * a.voxel_size;
-        const bool vec = (x0 + 3 < a.X);
-        for (int z = zb + wave; z < ze; z += 4) {
-            const size_t off = ((size_t)(z - a.z0) * a.Y + y) * pitch + x0;
-            float *pv = a.value + off, *pg = a.grad + off;
-            int *pw = a.weight + off;
-            if (vec) {
-                *reinterpret_cast<float4 *>(s_v[tid]) = *reinterpret_cast<const float4 *>(pv);
-                *reinterpret_cast<float4 *>(s_g[tid]) = *reinterpret_cast<const float4 *>(pg);
-                *reinterpret_cast<int4 *>(s_w[tid]) = *reinterpret_cast<const int4 *>(pw);
-            } else {
-                for (int j = 0; j < 4; ++j)
-                    if (x0 + j < a.X) { s_v[tid][j] = pv[j]; s_g[tid][j] = pg[j]; s_w[tid][j] = pw[j]; }
-            }
-            unsigned mask = 0;
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                const int x = x0 + j;
-                if (x >= a.X) break;
-                const float vgx = (x + 0.5f) * a.voxel_size;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) k.base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
-                float ov, og; int ow;
-                if (integrate_voxel<BILINEAR>(a, k, z, s_v[tid][j], s_g[tid][j], s_w[tid][j], ov, og, ow)) {
-                    s_v[tid][j] = ov; s_g[tid][j] = og; s_w[tid][j] = ow;
-                    mask |= 1u << j;
-                }
-            }
-            if (mask == 0xFu) {
-                *reinterpret_cast<float4 *>(pv) = *reinterpret_cast<const float4 *>(s_v[tid]);
-                *reinterpret_cast<float4 *>(pg) = *reinterpret_cast<const float4 *>(s_g[tid]);
-                *reinterpret_cast<int4 *>(pw) = *reinterpret_cast<const int4 *>(s_w[tid]);
-            } else if (mask) {
-                for (int j = 0; j < 4; ++j)
-                    if (mask & (1u << j)) { pv[j] = s_v[tid][j]; pg[j] = s_g[tid][j]; pw[j] = s_w[tid][j]; }
-            }
-            n_upd += __popc(mask);
         }
     }
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
@@ -496,14 +444,22 @@ static void host_frustum(IntegrateArgs &a) {
     set_plane(f, 3, T, M, 0.f, fy, -vl, rel * (fabsf(fy) * mag1 + fabsf(vl) * mag2));      // fy*Y >= vl*c
     set_plane(f, 4, T, M, 0.f, -fy, vh, rel * (fabsf(fy) * mag1 + fabsf(vh) * mag2));      // fy*Y <= vh*c
     set_plane(f, 5, T, M, 0.f, 0.f, -1.f, rel * mag2);                                     // c <= cfar (cfar added on the device)
+    // the column clip's form of the same planes (see ClipPlanes)
+    ClipPlanes &c = a.cp;
+    c.kinds = 0; c.far_scale = 1.0f;
     for (int p = 0; p < 6; ++p) {
         // a slope along z too small to divide by is dropped from the column clip; what it could
         // contribute over the whole column goes into the slack instead
         const float scale = fabsf(f.alpha[p]) + (fabsf(f.bx[p]) + fabsf(f.by[p])) * ext + f.slack[p] + (p == 5 ? 6.f : 0.f);
         if (fabsf(f.bz[p]) * ext <= 1e-6f * scale) {
-            f.kind[p] = 0; f.inv_bz[p] = 0.f; f.slack[p] += fabsf(f.bz[p]) * ext;
+            f.slack[p] += fabsf(f.bz[p]) * ext;
+            c.A[p] = f.alpha[p] + f.slack[p]; c.B[p] = f.bx[p]; c.C[p] = f.by[p];
         } else {
-            f.kind[p] = f.bz[p] > 0.f ? 1 : -1; f.inv_bz[p] = 1.0f / f.bz[p];
+            const double s = -1.0 / (double)f.bz[p];
+            c.A[p] = (float)(((double)f.alpha[p] + (double)f.slack[p]) * s);
+            c.B[p] = (float)(f.bx[p] * s); c.C[p] = (float)(f.by[p] * s);
+            if (p == 5) c.far_scale = (float)s;
+            c.kinds |= (f.bz[p] > 0.f ? 1 : 2) << (2 * p);
         }
     }
 }
@@ -548,7 +504,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
     a.zchunk = nz;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(64, 4);
-    if (workspace) {
+    if (workspace && a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047) {  // packed brick ids: 10 + 10 + 11 bits
         a.brick_count = (unsigned *)workspace;
         a.brick_list = (int *)((char *)workspace + 256);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
@@ -558,15 +514,8 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
         const int gmax = env_g > 0 ? env_g : 8192;
         const int g = nb < gmax ? nb : gmax;
-        static const int env_q = getenv("XS_BRICK_QUAD") ? atoi(getenv("XS_BRICK_QUAD")) : 0;
         if (g_int_ev0) XS_CHECK(hipEventRecord(g_int_ev0, st));
-        const bool quad = env_q == 1 && (vol_step % 16) == 0 && (((size_t)value | (size_t)weight | (size_t)grad) % 16) == 0;
-        if (quad) {
-            if (threshold > 0.0f)
-                hipLaunchKernelGGL(k_integrate_bricks_q<true>, dim3(g), block, 0, st, a);
-            else
-                hipLaunchKernelGGL(k_integrate_bricks_q<false>, dim3(g), block, 0, st, a);
-        } else if (threshold > 0.0f)
+        if (threshold > 0.0f)
             hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
         else
             hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
