@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s2", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--icp-solve", choices=["host", "device"], default=None,
+                    help="where the pose update between ICP iterations runs (default: the library's default)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: put every rank on cuda:0 (needs --backend gloo)")
     a = ap.parse_args()
 
@@ -142,7 +144,10 @@ def main():
         runner = sharded.ShardedKinectFusion(synth.s1_params(N), rank, world, dist)
     else:
         dist = None
-        runner = pl.KinectFusion(synth.s1_params(N))
+        prm = synth.s1_params(N)
+        if a.icp_solve is not None:
+            prm["icp_solve_on_device"] = (a.icp_solve == "device")
+        runner = pl.KinectFusion(prm)
 
     def frame(i):
         return dev_frames[i % len(dev_frames)]

@@ -149,6 +149,25 @@ int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vm
                       const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                       const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
                       void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq, void *stream);
+/* One whole ICP iteration without leaving the device: estimateCombined followed by the pose update
+ * the reference's host performs before the next launch (KinectFusionReconstruction.cpp:203-224:
+ * A.real().determinant() gate, complex<double> llt().solve, cast to complex<float>, AngleAxis
+ * Z*Y*X, tcurr = Rinc*tcurr + tinc, Rcurr = Rinc*Rcurr).  pose_state: xs_icp_pose_state_bytes()
+ * (128) bytes of device memory laid out {float R[18]; float t[6]; int status; int iters; double det;
+ * double pad[2]}.  With Rcurr18 / tcurr6 given the launch starts from them (first iteration of a
+ * frame), with both NULL from the state the previous launch on the stream left.  status: 0 ok,
+ * 1 |det| < 1e-15, 2 NaN det — once non-zero the following launches return at once, which is where
+ * the reference leaves PoseEstimate.  sums_dev: device memory, as above.  sums_host / pose_state_host
+ * (optional, host-coherent pinned memory) receive a copy of the 55 sums and of the state after every
+ * solve; done_flag / done_seq as above (published after both).  Each call enqueues the reduction and a
+ * one-workgroup solve kernel; the iterations of a frame queue back to back: no synchronisation, one
+ * host wait per frame instead of one per iteration. */
+size_t xs_icp_pose_state_bytes(void);
+int xs_icp_iterate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                   const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                   const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, void *workspace,
+                   double *sums_dev, double *sums_host, void *pose_state, void *pose_state_host, unsigned long long *done_flag,
+                   unsigned long long done_seq, void *stream);
 /* estimateCombined(...) whole: accumulate, synchronise the stream, download, unpack into the
  * symmetric A (36 complex<double>, A[i*6+j] = A[j*6+i]) and b (6)          ICP.cu:365-429 */
 int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,

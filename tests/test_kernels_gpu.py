@@ -247,6 +247,107 @@ def test_icp_row_shards_add_up(dev, oracle):
     assert not run(7, 7).any()
 
 
+def _cmul(a, b):
+    """complex<float> product the way the host and the kernels form it (four products, two sums, float each)."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array([np.float32(a[0] * b[0]) - np.float32(a[1] * b[1]), np.float32(a[0] * b[1]) + np.float32(a[1] * b[0])], np.float32)
+
+
+def _pose_update(oracle, sums55, R, t):
+    """KinectFusionReconstruction.cpp:203-221 through the oracle's host algebra: (status, R', t')."""
+    A = np.zeros((6, 6, 2)); b = np.zeros((6, 2))
+    shift = 0
+    for i in range(6):
+        for j in range(i, 7):
+            v = sums55[2 * shift:2 * shift + 2]; shift += 1
+            if j == 6:
+                b[i] = v
+            else:
+                A[i, j] = v; A[j, i] = v
+    det = oracle.det6_real(A)
+    if np.isnan(det):
+        return 2, R, t
+    if abs(det) < 1e-15:
+        return 1, R, t
+    x = oracle.llt_solve6(A, b).astype(np.float32)
+    Rinc = oracle.rinc(x[0], x[1], x[2])
+    t = np.asarray(t, np.float32).reshape(3, 2); R = np.asarray(R, np.float32).reshape(3, 3, 2)
+    tn = np.zeros((3, 2), np.float32); Rn = np.zeros((3, 3, 2), np.float32)
+    for i in range(3):
+        tn[i] = ((_cmul(Rinc[i, 0], t[0]) + _cmul(Rinc[i, 1], t[1])) + _cmul(Rinc[i, 2], t[2])) + x[3 + i]
+        for j in range(3):
+            Rn[i, j] = (_cmul(Rinc[i, 0], R[0, j]) + _cmul(Rinc[i, 1], R[1, j])) + _cmul(Rinc[i, 2], R[2, j])
+    return 0, Rn, tn
+
+
+def test_icp_iterate_device_pose_update(dev, oracle):
+    """xs_icp_iterate: the sums are those of xs_icp_accumulate bit for bit, and the pose the last
+    workgroup leaves in device memory is the host update (determinant gate, complex<double> LLT,
+    AngleAxis Z*Y*X, composition) of the oracle's algebra — identical in double, and equal to the float
+    ulp through the three angles' sin / cos; the second launch continues from the stored pose."""
+    torch, capi = dev
+    prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
+    k = intr_of(prm)
+    Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    dv = [to_dev(torch, x) for x in (cv, cn, pv, pn)]
+    assert capi._lib.xs_icp_pose_state_bytes() == 128
+    pose = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    R, t = np.asarray(T0["Rc2w"], np.float32).reshape(3, 3, 2), np.asarray(T0["tc2w"], np.float32).reshape(3, 2)
+    for it in range(3):
+        ref = torch.zeros(55, dtype=torch.float64, device="cuda")
+        capi.icp_accumulate(R, t, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, ref)
+        sums = torch.zeros(55, dtype=torch.float64, device="cuda")
+        capi.icp_iterate(R if it == 0 else None, t if it == 0 else None, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W,
+                         0.10, angle, ws, sums, pose)
+        torch.cuda.synchronize()
+        assert np.array_equal(sums.cpu().numpy(), ref.cpu().numpy())
+        raw = pose.cpu().numpy()
+        gR, gt = raw[:72].view(np.float32).reshape(3, 3, 2), raw[72:96].view(np.float32).reshape(3, 2)
+        status, iters = raw[96:104].view(np.int32)
+        det = raw[104:112].view(np.float64)[0]
+        st, wR, wt = _pose_update(oracle, sums.cpu().numpy(), R, t)
+        assert status == st == 0 and iters == it + 1
+        A72 = np.zeros(72); b12 = np.zeros(12)
+        capi._lib.xs_icp_unpack(sums.cpu().numpy().ctypes.data_as(capi._f64p), A72.ctypes.data_as(capi._f64p), b12.ctypes.data_as(capi._f64p))
+        assert det == oracle.det6_real(A72)   # double arithmetic only: same bits
+        # float: at most an ulp, from sin / cos of the three angles (values O(1), derivatives O(1e-7))
+        assert np.all(np.abs(gR[..., 0] - wR[..., 0]) <= 1.2e-7) and np.all(np.abs(gt[..., 0] - wt[..., 0]) <= 2.4e-7)
+        sc = max(np.abs(wR[..., 1]).max(), np.abs(wt[..., 1]).max())
+        assert sc > 0
+        assert np.all(np.abs(gR[..., 1] - wR[..., 1]) <= 1e-6 * sc) and np.all(np.abs(gt[..., 1] - wt[..., 1]) <= 1e-6 * sc)
+        assert (gR != wR).mean() <= 0.25, "more than a few last-bit differences"
+        R, t = gR.copy(), gt.copy()   # continue from what the device holds
+
+
+def test_icp_iterate_singular_system_stops_the_loop(dev):
+    """No valid pixel: zero sums, |det| < 1e-15 -> status 1, pose untouched; the next launch returns at
+    once (sums buffer not written), as PoseEstimate returns 0 on the host (KinectFusionReconstruction.cpp:203-210)."""
+    torch, capi = dev
+    nanmap = torch.full((3 * 60, 80, 2), float("nan"), dtype=torch.float32, device="cuda")
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    pose = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    I = np.zeros((3, 3, 2), np.float32); I[[0, 1, 2], [0, 1, 2], 0] = 1
+    t0 = np.array([[1, 0], [2, 0], [3, 1e-7]], np.float32)
+    sums = torch.ones(55, dtype=torch.float64, device="cuda")
+    capi.icp_iterate(I, t0, nanmap, nanmap, I, np.zeros(6), [100, 100, 40, 30], nanmap, nanmap, 80 * 8, 60, 80, 0.1, 0.2, ws, sums, pose)
+    torch.cuda.synchronize()
+    raw = pose.cpu().numpy()
+    assert not sums.cpu().numpy().any()
+    assert tuple(raw[96:104].view(np.int32)) == (1, 1)
+    assert np.array_equal(raw[:72].view(np.float32).reshape(3, 3, 2), I) and np.array_equal(raw[72:96].view(np.float32).reshape(3, 2), t0)
+    sums.fill_(7.0)
+    capi.icp_iterate(None, None, nanmap, nanmap, I, np.zeros(6), [100, 100, 40, 30], nanmap, nanmap, 80 * 8, 60, 80, 0.1, 0.2, ws, sums, pose)
+    torch.cuda.synchronize()
+    assert np.all(sums.cpu().numpy() == 7.0) and tuple(pose.cpu().numpy()[96:104].view(np.int32)) == (1, 1)
+    # a launch that reloads the pose clears the status
+    good = torch.zeros((3 * 60, 80, 2), dtype=torch.float32, device="cuda")
+    capi.icp_iterate(I, t0, good, good, I, np.zeros(6), [100, 100, 40, 30], good, good, 80 * 8, 60, 80, 0.1, 0.2, ws, sums, pose)
+    torch.cuda.synchronize()
+    assert pose.cpu().numpy()[100:104].view(np.int32)[0] == 1
+
+
 def test_icp_all_invalid(dev):
     torch, capi = dev
     nanmap = torch.full((3 * 60, 80, 2), float("nan"), dtype=torch.float32, device="cuda")

@@ -44,12 +44,13 @@ def pose_close(got, want, value_tol=1e-6, deriv_rel=1e-6):
     assert np.all(np.abs(got[..., 1] - want[..., 1]) <= deriv_rel * scale), (np.abs(got[..., 1] - want[..., 1]).max() / scale)
 
 
+@pytest.mark.parametrize("solve_on_device", [True, False], ids=["device_solve", "host_solve"])
 @pytest.mark.parametrize("name", ["pipeline_s1_n64.npz", "pipeline_s1_n96.npz"])
-def test_pipeline_against_committed_fixture(dev, name):
+def test_pipeline_against_committed_fixture(dev, name, solve_on_device):
     torch, pl = dev
     g = load_golden(name)
     n = int(g["n"])
-    kf = pl.KinectFusion(synth.s1_params(n))
+    kf = pl.KinectFusion(dict(synth.s1_params(n), icp_solve_on_device=solve_on_device))
     vox, pix = g["voxel_index"], g["pixel_index"]
     py, px = pix // W, pix % W
     frames = list(g["frames"])
@@ -130,6 +131,29 @@ def test_pipeline_against_live_oracle_128(dev, oracle):
             nan_a, nan_b = np.isnan(a[:rows, :, 0]), np.isnan(b[:rows, :, 0])
             assert (nan_a != nan_b).mean() <= 1e-4
     kf.close()
+
+
+def test_device_pose_solve_matches_host_solve(dev):
+    """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
+    the reference's one host solve per iteration — on the same frames: identical first-iteration sums,
+    poses equal to float rounding of three sin / cos pairs per iteration."""
+    torch, pl = dev
+    prm = synth.s1_params(128)
+    a = pl.KinectFusion(dict(prm, icp_solve_on_device=True))
+    b = pl.KinectFusion(dict(prm, icp_solve_on_device=False))
+    for k in range(4):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+        la, lb = a.icp_log(), b.icp_log()
+        assert la.shape == lb.shape
+        if k == 1:
+            assert np.array_equal(la[0], lb[0])   # same maps, same starting pose: same bits
+            assert np.all(np.abs(la[-1, :54] - lb[-1, :54]) <= 1e-5 * np.abs(lb[-1, :54]).max())
+        if k >= 1:
+            assert la.shape[0] == 12
+            pose_close(a.world2camera(), b.world2camera(), value_tol=1e-6 if k == 1 else 1e-5, deriv_rel=1e-6 if k == 1 else 1e-3)
+    assert abs(a.last_U() - b.last_U()) <= max(3, 1e-4 * b.last_U())
+    a.close(); b.close()
 
 
 def test_pipeline_gt_pose_mode_s2(dev, oracle):

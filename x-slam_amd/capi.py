@@ -67,6 +67,9 @@ _SIGS = {
     "xs_icp_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                     C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
+    "xs_icp_pose_state_bytes": (_sz, []),
+    "xs_icp_iterate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
+                                 C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_estimate_combined": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                        C.c_float, _vp, _vp, _f64p, _f64p, C.POINTER(C.c_longlong), _vp]),
     "xs_icp_unpack": (None, [_f64p, _f64p, _f64p]),
@@ -255,6 +258,22 @@ def icp_accumulate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, v
     y1 = rows if y1 is None else y1
     check(_lib.xs_icp_accumulate(P(a), P(b), _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
                                  map_step, rows, cols, distThres, angleThres, y0, y1, _ptr(workspace), _ptr(sums), None, 0, _stream(stream)))
+
+
+def icp_iterate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
+                distThres, angleThres, workspace, sums, pose_state, stream=None):
+    """One ICP iteration with the pose update on the device (xs_icp_iterate).  Rcurr / tcurr None:
+    continue from the pose the previous launch left in pose_state (a 128-byte device tensor)."""
+    c, d, k = _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    if Rcurr is None:
+        pa = pb = None
+    else:
+        a, b = _fa(Rcurr, 18), _fa(tcurr, 6)
+        pa, pb = P(a), P(b)
+    check(_lib.xs_icp_iterate(pa, pb, _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
+                              map_step, rows, cols, distThres, angleThres, _ptr(workspace), _ptr(sums), None, _ptr(pose_state), None, None, 0,
+                              _stream(stream)))
 
 
 def estimate_combined(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,

@@ -11,7 +11,9 @@
 // workgroup meet once in LDS, and the workgroup writes one 54-double partial.  The last
 // workgroup to arrive (agent-scope ticket) adds the partials in index order, so the result is
 // deterministic and there is no second launch.
+#include <string.h>
 #include "xs_device.h"
+#include "xs_icp_solve.h"
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
@@ -30,11 +32,15 @@ struct IcpArgs {
     unsigned *ticket;       // zeroed before the launch
     double *out;            // 54 sums (27 x re,im) + [54] = inlier count
     unsigned long long *done_flag; unsigned long long done_seq;  // optional: host-visible completion word
+    // optional device-side pose update (xs_icp_iterate): the last workgroup solves for the increment and
+    // composes it into *pose, which the next launch reads instead of Rcurr / tcurr above
+    IcpPoseState *pose; IcpPoseState *pose_host; int load_pose;
 };
 
 namespace {
 // ICP.cu:196-244
-__device__ __forceinline__ bool search(const IcpArgs &a, int x, int y, cfloat3 &n, cfloat3 &d, cfloat3 &s) {
+__device__ __forceinline__ bool search(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, cfloat3 &n, cfloat3 &d,
+                                       cfloat3 &s) {
     cfloat3 ncurr;
     ncurr.x = row_ptr(a.nmap_curr, a.mstep, y)[x];
     if (isnan(ncurr.x.re)) return false;
@@ -44,7 +50,7 @@ __device__ __forceinline__ bool search(const IcpArgs &a, int x, int y, cfloat3 &
     vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
     vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
     vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
-    const cfloat3 vcurr_g = a.Rcurr * vcurr + a.tcurr;
+    const cfloat3 vcurr_g = Rcurr * vcurr + tcurr;
     const cfloat3 vcp = a.Rprev_inv * (vcurr_g - a.tprev);
     const float cpx = vcp.x.re, cpy = vcp.y.re, cpz = vcp.z.re;
     const int ux = __float2int_rn(cpx * a.intr.fx / cpz + a.intr.cx);
@@ -61,7 +67,7 @@ __device__ __forceinline__ bool search(const IcpArgs &a, int x, int y, cfloat3 &
     vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
     const cfloat dist = norm(vprev_g - vcurr_g);
     if (dist.re > a.distThres) return false;
-    const cfloat3 ncurr_g = a.Rcurr * ncurr;
+    const cfloat3 ncurr_g = Rcurr * ncurr;
     const cfloat sine = norm(cross(ncurr_g, nprev_g));
     if (sine.re >= a.angleThres) return false;
     n = nprev_g; d = vprev_g; s = vcurr_g;
@@ -71,7 +77,36 @@ constexpr int NS = 54;      // 27 complex sums
 constexpr int NP = 56;      // partial record: 54 sums + count + pad
 }  // namespace
 
+// host-visible completion word: push everything out, then publish the sequence number
+__device__ __forceinline__ void publish_done(const IcpArgs &a) {
+    __threadfence_system();
+    __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// POSE_IN_MEMORY = false: Rcurr / tcurr are kernel arguments (xs_icp_accumulate, first iteration of
+// xs_icp_iterate).  true: they are what k_icp_solve left in device memory after the previous iteration.
+template <bool POSE_IN_MEMORY>
 __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
+    MatS33 Rcurr = a.Rcurr;
+    cfloat3 tcurr = a.tcurr;
+    if (POSE_IN_MEMORY) {
+        // the pose left by the previous launch on this stream; a failed solve ends the loop
+        if (a.pose->status != 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0 && a.done_flag) publish_done(a);
+            return;
+        }
+        // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel
+        // arguments they replace)
+        auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        const float *pr = a.pose->R, *pt = a.pose->t;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Rcurr.data[r].x = cfloat(uni(pr[6 * r + 0]), uni(pr[6 * r + 1]));
+            Rcurr.data[r].y = cfloat(uni(pr[6 * r + 2]), uni(pr[6 * r + 3]));
+            Rcurr.data[r].z = cfloat(uni(pr[6 * r + 4]), uni(pr[6 * r + 5]));
+        }
+        tcurr.x = cfloat(uni(pt[0]), uni(pt[1])); tcurr.y = cfloat(uni(pt[2]), uni(pt[3])); tcurr.z = cfloat(uni(pt[4]), uni(pt[5]));
+    }
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
@@ -85,7 +120,7 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
         const int x = (t % tiles_x) * 64 + lane;
         if (x >= a.cols) continue;
         cfloat3 n, d, s;
-        if (!search(a, x, y, n, d, s)) continue;
+        if (!search(a, Rcurr, tcurr, x, y, n, d, s)) continue;
         cfloat row[7];
         const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
         row[0] = cr.x; row[1] = cr.y; row[2] = cr.z;
@@ -176,10 +211,96 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
             // publish the sequence number the host is spinning on — no copy, no stream sync
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) {
-                __threadfence_system();
-                __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            if (threadIdx.x == 0) publish_done(a);
+        }
+    }
+}
+
+// ---- pose update on the device (xs_icp_iterate) ---------------------------------------------
+// KinectFusionReconstruction.cpp:203-224 as a one-workgroup kernel behind the reduction: wave 1 takes
+// the determinant gate while wave 0 factors and solves (one matrix row per lane); three lanes then
+// evaluate the three angles' sin / cos side by side and form one row each of Rinc, Rinc*tcurr + tinc
+// and Rinc*Rcurr.  It lives in its own kernel because the double-precision solve wants ~100 registers
+// of its own: inside k_icp it cost the pixel loop its second wave per SIMD.
+struct IcpSolveArgs {
+    const double *sums;     // the 55 values the reduction just wrote
+    double *sums_host;      // optional host-visible copy of them (per-iteration log)
+    MatS33 Rcurr; cfloat3 tcurr; int load_pose;  // load_pose: start from these instead of *pose
+    IcpPoseState *pose, *pose_host;
+    unsigned long long *done_flag; unsigned long long done_seq;
+};
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) k_icp_solve(const IcpSolveArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (!a.load_pose && a.pose->status != 0) {  // the loop ended at an earlier iteration
+        if (threadIdx.x == 0 && a.done_flag) {
+            __threadfence_system();
+            __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    __shared__ double s_sums[NP];
+    __shared__ double s_det;
+    __shared__ cfloat s_res[6], s_sn[3], s_cs[3];
+    if (threadIdx.x < NS + 1) {
+        const double v = a.sums[threadIdx.x];
+        s_sums[threadIdx.x] = v;
+        if (a.sums_host) a.sums_host[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (wave == 1) {
+        const double det = icp_solve::real_determinant6_wave(s_sums, lane);
+        if (lane == 0) s_det = det;
+    } else {
+        const cdouble sol = icp_solve::llt_solve6_wave(s_sums, lane);
+        if (lane < 6) s_res[lane] = cfloat((float)sol.re, (float)sol.im);
+        // (same wave: the three angles are in LDS once its writes have landed)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < 3) icp_solve::csincos(s_res[lane], s_sn[lane], s_cs[lane]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int i = threadIdx.x;
+        MatS33 Rcurr = a.Rcurr;
+        cfloat3 tcurr = a.tcurr;
+        int iters = 1;
+        if (!a.load_pose) {
+            const cfloat *pr = reinterpret_cast<const cfloat *>(a.pose->R), *pt = reinterpret_cast<const cfloat *>(a.pose->t);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { Rcurr.data[r].x = pr[3 * r]; Rcurr.data[r].y = pr[3 * r + 1]; Rcurr.data[r].z = pr[3 * r + 2]; }
+            tcurr.x = pt[0]; tcurr.y = pt[1]; tcurr.z = pt[2];
+            iters = a.pose->iters + 1;
+        }
+        const double det = s_det;
+        const int status = (det != det) ? 2 : (fabs(det) < 1e-15 ? 1 : 0);
+        icp_solve::Row3 Rn;
+        cfloat tn;
+        if (status == 0) icp_solve::compose_pose_rows(i, s_res, s_sn, s_cs, Rcurr, tcurr, Rn, tn);
+        else {  // the pose stays where it was
+            const cfloat3 r = i == 0 ? Rcurr.data[0] : (i == 1 ? Rcurr.data[1] : Rcurr.data[2]);
+            Rn.v[0] = r.x; Rn.v[1] = r.y; Rn.v[2] = r.z;
+            tn = i == 0 ? tcurr.x : (i == 1 ? tcurr.y : tcurr.z);
+        }
+        // every lane has read the old pose by now (same wave, program order), so it can be overwritten
+        __builtin_amdgcn_wave_barrier();
+        IcpPoseState *dst[2] = {a.pose, a.pose_host};
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            IcpPoseState *ps = dst[d];
+            if (!ps) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { ps->R[6 * i + 2 * j] = Rn.v[j].re; ps->R[6 * i + 2 * j + 1] = Rn.v[j].im; }
+            ps->t[2 * i] = tn.re; ps->t[2 * i + 1] = tn.im;
+            if (i == 0) { ps->status = status; ps->iters = iters; ps->det = det; }
+        }
+    }
+    if (a.done_flag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -203,6 +324,48 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
     return 0;
 }
 
+// shared launcher of xs_icp_accumulate / xs_icp_iterate
+static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr, const float *Rprev_inv18,
+                      const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev, size_t map_step, int rows,
+                      int cols, float distThres, float angleThres, int y0, int y1, void *workspace, double *sums_dev,
+                      unsigned long long *done_flag, unsigned long long done_seq, IcpPoseState *pose, IcpPoseState *pose_host, double *sums_host,
+                      void *stream, const char *who) {
+    if ((!pose && (!Rcurr18 || !tcurr6)) || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
+        !workspace || !sums_dev)
+        return xs_set_error(hipErrorInvalidValue, who);
+    if (y0 < 0 || y1 > rows || y1 < y0) return xs_set_error(hipErrorInvalidValue, "xs_icp: bad row range");
+    IcpArgs a;
+    if (Rcurr18) { ld_mat(Rcurr18, a.Rcurr); ld_vec(tcurr6, a.tcurr); }
+    else { memset(&a.Rcurr, 0, sizeof(a.Rcurr)); memset(&a.tcurr, 0, sizeof(a.tcurr)); }
+    ld_mat(Rprev_inv18, a.Rprev_inv); ld_vec(tprev6, a.tprev);
+    a.vmap_curr = (const cfloat *)vmap_curr; a.nmap_curr = (const cfloat *)nmap_curr;
+    a.vmap_g_prev = (const cfloat *)vmap_g_prev; a.nmap_g_prev = (const cfloat *)nmap_g_prev;
+    a.mstep = map_step; a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.distThres = distThres; a.angleThres = angleThres; a.cols = cols; a.rows = rows; a.y0 = y0; a.y1 = y1;
+    a.ticket = (unsigned *)workspace;
+    a.partials = (double *)((char *)workspace + 256);
+    a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
+    a.pose = pose; a.pose_host = pose_host; a.load_pose = (pose && Rcurr18) ? 1 : 0;
+    const int tiles = div_up(cols, 64) * (y1 - y0);
+    int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
+    if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    // the ticket word must be zero on first use (xs_icp_workspace_init); every launch leaves it zero
+    if (pose) {
+        // the reduction, then the pose update it feeds; the completion word belongs to the second kernel
+        IcpSolveArgs sa;
+        sa.sums = sums_dev; sa.sums_host = sums_host; sa.Rcurr = a.Rcurr; sa.tcurr = a.tcurr; sa.load_pose = a.load_pose;
+        sa.pose = pose; sa.pose_host = pose_host; sa.done_flag = done_flag; sa.done_seq = done_seq;
+        a.done_flag = nullptr;
+        if (a.load_pose) hipLaunchKernelGGL(k_icp<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_icp<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(128), 0, (hipStream_t)stream, sa);
+    } else
+        hipLaunchKernelGGL(k_icp<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
 /* estimateCombined(const MatS33& Rcurr, const devComplex3& tcurr, const MapArr& vmap_curr,
  *     const MapArr& nmap_curr, const MatS33& Rprev_inv, const devComplex3& tprev, const Intr&,
  *     const MapArr& vmap_g_prev, const MapArr& nmap_g_prev, float distThres, float angleThres,
@@ -219,27 +382,33 @@ extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, cons
                                  const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
                                  int y0, int y1, void *workspace, double *sums_dev, unsigned long long *done_flag,
                                  unsigned long long done_seq, void *stream) {
-    if (!Rcurr18 || !tcurr6 || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
-        !workspace || !sums_dev)
-        return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate: null pointer");
-    if (y0 < 0 || y1 > rows || y1 < y0) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate: bad row range");
-    IcpArgs a;
-    ld_mat(Rcurr18, a.Rcurr); ld_vec(tcurr6, a.tcurr); ld_mat(Rprev_inv18, a.Rprev_inv); ld_vec(tprev6, a.tprev);
-    a.vmap_curr = (const cfloat *)vmap_curr; a.nmap_curr = (const cfloat *)nmap_curr;
-    a.vmap_g_prev = (const cfloat *)vmap_g_prev; a.nmap_g_prev = (const cfloat *)nmap_g_prev;
-    a.mstep = map_step; a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
-    a.distThres = distThres; a.angleThres = angleThres; a.cols = cols; a.rows = rows; a.y0 = y0; a.y1 = y1;
-    a.ticket = (unsigned *)workspace;
-    a.partials = (double *)((char *)workspace + 256);
-    a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
-    const int tiles = div_up(cols, 64) * (y1 - y0);
-    int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
-    if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
-    if (blocks < 1) blocks = 1;
-    // the ticket word must be zero on first use (xs_icp_workspace_init); every launch leaves it zero
-    hipLaunchKernelGGL(k_icp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    XS_CHECK(hipGetLastError());
-    return 0;
+    if (!Rcurr18 || !tcurr6) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate: null pointer");
+    return icp_launch(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
+                      distThres, angleThres, y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream,
+                      "xs_icp_accumulate: null pointer");
+}
+
+/* One whole ICP iteration on the device: estimateCombined (ICP.cu:365-429) followed by the pose
+ * update the reference's host performs before the next launch (KinectFusionReconstruction.cpp:203-224:
+ * determinant gate, complex<double> LLT solve, cast to complex<float>, AngleAxis Z*Y*X, Rcurr / tcurr
+ * composition).  pose_state: xs_icp_pose_state_bytes() bytes of device memory holding
+ * {float R[18]; float t[6]; int status; int iters; double det; double pad[2]} (128 bytes); when Rcurr18 / tcurr6 are
+ * given the launch starts from them (first iteration of a frame) and otherwise from the state the
+ * previous launch on the stream left.  status: 0 ok, 1 |det| < 1e-15, 2 NaN; once non-zero the
+ * following launches return at once (the reference leaves PoseEstimate there).  sums_dev: device
+ * memory, as in xs_icp_accumulate; sums_host / pose_state_host (optional, host-coherent pinned
+ * memory) receive a copy of the 55 sums and of the state after every solve, then done_seq is
+ * published to done_flag (optional).  Two launches (reduction, one-workgroup solve); no synchronisation. */
+extern "C" size_t xs_icp_pose_state_bytes(void) { return sizeof(IcpPoseState); }
+extern "C" int xs_icp_iterate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                              const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                              const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
+                              void *workspace, double *sums_dev, double *sums_host, void *pose_state, void *pose_state_host,
+                              unsigned long long *done_flag, unsigned long long done_seq, void *stream) {
+    if (!pose_state || ((Rcurr18 == nullptr) != (tcurr6 == nullptr))) return xs_set_error(hipErrorInvalidValue, "xs_icp_iterate: null pointer");
+    return icp_launch(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
+                      distThres, angleThres, 0, rows, workspace, sums_dev, done_flag, done_seq, (IcpPoseState *)pose_state,
+                      (IcpPoseState *)pose_state_host, sums_host, stream, "xs_icp_iterate: null pointer");
 }
 
 /* Host half of estimateCombined (ICP.cu:414-428): synchronise the stream, download the 27

@@ -18,8 +18,8 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipEventCreateWithFlags(&surface_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, PROF_RING * 2 * sizeof(unsigned long long)));
-    hipSafeCall(hipHostMalloc((void **)&pinned_sums_, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
-    for (int i = 0; i < 64; ++i) pinned_sums_[i] = 0.0;
+    hipSafeCall(hipHostMalloc((void **)&pinned_sums_, PINNED_DOUBLES * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    for (int i = 0; i < PINNED_DOUBLES; ++i) pinned_sums_[i] = 0.0;
 }
 
 void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn fn, void *user) {
@@ -101,6 +101,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
 
     use_gtPose = config.as<bool>("flag_use_gtPose", false);
+    icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
     gt_poses.resize(0);
     frame_id = 0;
     frame_step = config.as<int>("frame_step", 1);
@@ -128,6 +129,7 @@ void KinectFusionReconstruction::AllocateBuffers() {
         icp_ws_.create(xs_icp_workspace_bytes());
         check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
         icp_sums_.create(64);
+        icp_pose_.create(xs_icp_pose_state_bytes());
         ray_ws_.create((size_t)depth_width * depth_height);
         if (shard_count > 1) {
             ray_keys_.create((size_t)depth_width * depth_height);
@@ -205,6 +207,10 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
     Matrix4cf c2w_curr = c2w_prev;
     auto &device_Rprev_inv = device_cast<MatS33>(Rprev_inv);
     auto &device_tprev = device_cast<devComplex3>(tprev);
+    int total_iters = 0;
+    for (int l = 0; l < num_levels; ++l) total_iters += icp_iterations[l];
+    if (icp_solve_on_device && shard_count == 1 && !profiling_icp_sync && total_iters >= 1 && total_iters <= ICP_LOG_MAX)
+        return PoseEstimateOnDevice(Rcurr, tcurr, Rprev_inv, tprev, c2w_curr, total_iters);
     stage_begin(ST_ICP);
     for (int level_index = num_levels - 1; level_index >= 0; --level_index) {
         MapArr &vmap_curr = vmaps_curr_d[level_index];
@@ -254,6 +260,61 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
         }
     }
     stage_end(ST_ICP);
+    world2camera = inverse(c2w_curr);
+    world2camera_record.push_back(world2camera);
+    return 1;
+}
+
+// The same loop with the pose update on the device (xs_icp_iterate): the launches of all levels and
+// iterations queue back to back, each leaving the pose for the next in device memory, and the host
+// waits once per frame for the final pose instead of once per iteration for the 27 sums.
+int KinectFusionReconstruction::PoseEstimateOnDevice(Matrix3frm Rcurr, Vector3cf tcurr, const Matrix3frm &Rprev_inv, const Vector3cf &tprev,
+                                                     Matrix4cf c2w_curr, int total_iters) {
+    struct PoseState { float R[18]; float t[6]; int status; int iters; double det; double pad[2]; };
+    static_assert(sizeof(PoseState) == 128, "pose state layout (xs_icp_iterate)");
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
+    PoseState *pose_host = reinterpret_cast<PoseState *>(pinned_sums_ + 64);
+    double *log_host = pinned_sums_ + 128;
+    const unsigned long long seq = ++icp_seq_;
+    hipStream_t st = current_stream();
+    stage_begin(ST_ICP);
+    int n = 0;
+    for (int level_index = num_levels - 1; level_index >= 0; --level_index) {
+        MapArr &vc = vmaps_curr_d[level_index], &nc = nmaps_curr_d[level_index];
+        MapArr &vp = vmaps_g_prev_d[level_index], &np_ = nmaps_g_prev_d[level_index];
+        const Intr k = kinect_intrinsic(level_index);
+        const int rows = vc.rows() / 3, cols = vc.cols();
+        for (int iter = 0; iter < icp_iterations[level_index]; ++iter, ++n) {
+            const bool first = (n == 0), last = (n == total_iters - 1);
+            check_rc(xs_icp_iterate(first ? Rcurr.data() : nullptr, first ? tcurr.data() : nullptr, &vc.ptr()->re, &nc.ptr()->re,
+                                    Rprev_inv.data(), tprev.data(), &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres,
+                                    angleThres, icp_ws_.ptr(), icp_sums_.ptr(), log_host + 64 * n, icp_pose_.ptr(), pose_host,
+                                    last ? reinterpret_cast<unsigned long long *>(pinned_sums_ + 56) : nullptr, seq, st),
+                     "xs_icp_iterate");
+        }
+    }
+    long spins = 0;
+    while (*flag != seq) {
+        if (++spins > 2000000000L) { hipSafeCall(hipStreamSynchronize(st)); break; }  // never expected: fall back to a real wait
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    stage_end(ST_ICP);
+    const PoseState ps = *pose_host;
+    for (int i = 0; i < ps.iters && i < total_iters; ++i)
+        for (int j = 0; j < 55; ++j) icp_log.push_back(log_host[64 * i + j]);
+    if (ps.status != 0) {
+        if (ps.status == 2) std::cout << "qnan det" << std::endl;
+        else std::cout << "eps det: " << fabs(ps.det) << std::endl;
+        return 0;
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c2w_curr(i, j) = hostComplex(ps.R[(i * 3 + j) * 2], ps.R[(i * 3 + j) * 2 + 1]);
+        c2w_curr(i, 3) = hostComplex(ps.t[2 * i], ps.t[2 * i + 1]);
+    }
+    c2w_curr(3, 3) = hostComplex(1.f, 0.f);
     world2camera = inverse(c2w_curr);
     world2camera_record.push_back(world2camera);
     return 1;

@@ -71,6 +71,13 @@ public:
     void *collective_user = nullptr;
     void SetSharding(int rank, int count, collective_fn fn, void *user);  // call before SetYamlParameters
 
+    // false (default): the reference's shape, one host solve per ICP iteration (the host spins on a
+    // completion word the kernel writes into pinned memory: ~3 us over back-to-back launches).  true: the
+    // pose update runs on the device (xs_icp_iterate) and the host waits once per frame — measured ~3 us
+    // per iteration slower on this machine (a serial double-precision Cholesky + substitution is ~9000
+    // cycles for one wave), kept for hosts that cannot spin.  YAML key icp_solve_on_device.
+    bool icp_solve_on_device = false;
+
     // instrumentation
     bool profiling = false;
     double stage_ms[ST_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -117,14 +124,20 @@ private:
     DeviceArray<unsigned char> integrate_ws_;  // brick work list of the integrate kernel
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
+    DeviceArray<unsigned char> icp_pose_;      // device-resident pose of the ICP loop (xs_icp_iterate)
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
-    double *pinned_sums_ = nullptr;            // host-coherent: [0..54] sums + count, [56] completion sequence word
+    // host-coherent: [0..54] sums + count, [56] completion sequence word, [64..80) pose state of the
+    // device-side loop, [128 + 64*n ..) the 55 values of its iteration n
+    enum { ICP_LOG_MAX = 62, PINNED_DOUBLES = 128 + 64 * ICP_LOG_MAX };
+    double *pinned_sums_ = nullptr;
     unsigned long long icp_seq_ = 0;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
     hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr;
     bool integrate_recorded_ = false;
     bool profiling_icp_sync = false;           // true: copy + stream synchronise instead of the spin (debug aid)
+    int PoseEstimateOnDevice(Matrix3frm Rcurr, Vector3cf tcurr, const Matrix3frm &Rprev_inv, const Vector3cf &tprev, Matrix4cf c2w_curr,
+                             int total_iters);
     void icp_normal_equations(const MatS33 &Rcurr, const devComplex3 &tcurr, const MatS33 &Rprev_inv, const devComplex3 &tprev, int level,
                               hostComplexICP *A, hostComplexICP *b, long long *inliers);
     // deferred profiling: one slot of events + one pinned counter record per frame, folded into
