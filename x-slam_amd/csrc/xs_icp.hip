@@ -164,10 +164,15 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
         }
     }
     __syncthreads();
-    if (threadIdx.x < NS + 1) {
-        const double v = ((smem[0][threadIdx.x] + smem[1][threadIdx.x]) + smem[2][threadIdx.x]) + smem[3][threadIdx.x];
-        // write-through store so the last workgroup reads it from memory, not a stale cache
-        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NP + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < NP / 2) {
+        // one 16-byte store per lane (a record is 28 of them; the pad entry is written as zero).  Plain
+        // stores: the agent-scope release below carries them out of this XCD's L2.
+        struct alignas(16) d2 { double x, y; };
+        const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
+        d2 v;
+        v.x = ((smem[0][k0] + smem[1][k0]) + smem[2][k0]) + smem[3][k0];
+        v.y = k1 <= NS ? ((smem[0][k1] + smem[1][k1]) + smem[2][k1]) + smem[3][k1] : 0.0;
+        reinterpret_cast<d2 *>(a.partials)[(size_t)blockIdx.x * (NP / 2) + threadIdx.x] = v;
     }
     // publish: every storing wave drains its stores, the workgroup meets, one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -182,30 +187,53 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             // the ticket re-arms itself: the next launch on this stream starts from zero
             __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // holds the barrier until the invalidate has completed
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (s_last) {
-        // after the acquire (this CU's L1 invalidated) + barrier, plain loads see every record.
-        // Column c = lane, records strided over the 4 waves, 8 independent loads in flight; the
-        // four wave sums are then added in wave order — a fixed association, so deterministic.
-        const int c = lane;
-        double s = 0.0;
-        if (c < NS + 1) {
-            const double *p = a.partials + c;
-            unsigned b = wave;
-            for (; b + 28 < gridDim.x; b += 32) {
-                const double v0 = p[(size_t)(b + 0) * NP], v1 = p[(size_t)(b + 4) * NP], v2 = p[(size_t)(b + 8) * NP], v3 = p[(size_t)(b + 12) * NP];
-                const double v4 = p[(size_t)(b + 16) * NP], v5 = p[(size_t)(b + 20) * NP], v6 = p[(size_t)(b + 24) * NP], v7 = p[(size_t)(b + 28) * NP];
-                s += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+        // after the acquire (this CU's L1 invalidated) + barrier, plain loads see every record.  The records
+        // come from memory (other XCDs wrote them), so the sum is latency-bound: a record is 28 16-byte
+        // chunks; thread (g, q) adds chunk q of records g, g+9, g+18, ... in that order with 32 loads in
+        // flight, and the nine row groups are then added in group order — a fixed association, so
+        // deterministic — leaving two or three memory round trips where a plain loop had sixteen.
+        struct alignas(16) d2 { double x, y; };
+        __shared__ d2 s_red[9][28];
+        const int q = threadIdx.x % 28, g = threadIdx.x / 28;
+        if (g < 9) {
+            const d2 *p = reinterpret_cast<const d2 *>(a.partials) + q;
+            d2 acc2 = {0.0, 0.0};
+            unsigned b = g;
+            const unsigned nb = gridDim.x;
+            enum { DEPTH = 32 };
+            for (; b + 9 * (DEPTH - 1) < nb; b += 9 * DEPTH) {
+                d2 v[DEPTH];
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) v[k] = p[(size_t)(b + 9 * k) * (NP / 2)];
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) { acc2.x += v[k].x; acc2.y += v[k].y; }
             }
-            for (; b < gridDim.x; b += 4) s += p[(size_t)b * NP];
+            {   // the tail, still issued together
+                d2 v[DEPTH];
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) {
+                    const unsigned bb = b + 9 * k;
+                    v[k] = bb < nb ? p[(size_t)bb * (NP / 2)] : d2{0.0, 0.0};
+                }
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k)
+                    if (b + 9 * k < nb) { acc2.x += v[k].x; acc2.y += v[k].y; }
+            }
+            s_red[g][q] = acc2;
         }
         __syncthreads();
-        if (c < NS + 1) smem[wave][c] = s;
-        __syncthreads();
-        if (threadIdx.x < NS + 1) a.out[threadIdx.x] = ((smem[0][threadIdx.x] + smem[1][threadIdx.x]) + smem[2][threadIdx.x]) + smem[3][threadIdx.x];
+        if (threadIdx.x < 28) {
+            d2 t = s_red[0][threadIdx.x];
+#pragma unroll
+            for (int gg = 1; gg < 9; ++gg) { t.x += s_red[gg][threadIdx.x].x; t.y += s_red[gg][threadIdx.x].y; }
+            a.out[2 * threadIdx.x] = t.x;
+            if (2 * threadIdx.x + 1 < NS + 1) a.out[2 * threadIdx.x + 1] = t.y;
+        }
         if (a.done_flag) {
             // out (and the flag) may live in host-coherent pinned memory: push the sums out, then
             // publish the sequence number the host is spinning on — no copy, no stream sync
