@@ -10,11 +10,14 @@ are resident in HBM before the timed region.  One JSON line on rank 0 with the c
 fields plus
   roofline     : the TSDF-integrate kernel — algorithmic bytes 24*U + 2*W*H per launch (U = voxels
                  written, counted by the kernel) / its mean duration from HIP events recorded on
-                 the launch stream inside the timed region; peak = 8 TB/s HBM3E
+                 the launch stream inside the timed region; peak = 8 TB/s HBM3E; traffic = HBM bytes
+                 per launch from the committed rocprofv3 counter passes (profiles/r01_integrate_pmc_v3.json)
+  roofline_s2  : the same object for scene S2 (SURVEY 8d's frustum-filling placement, the one the
+                 HBM claim is made on: ~0.95 GB per launch instead of S1's ~45 MB, which is over in
+                 the time a launch takes to ramp up)
   cpu_baseline : the CPU oracle (oracle/, a port — not the product path) timed on this host's
                  cores on a bounded sample of the same workload
-  stages_ms, integrate_s2 : extra context (per-stage mean ms; the frustum-filling scene S2 on
-                 which integrate is HBM-bound)
+  stages_ms    : per-stage mean ms
 N > 1 (launched by torch.distributed.run, one rank per GPU): the volume is sharded by z-slab,
 ICP rows by rank, and the 6x6 / 6x1 normal equations are all-reduced over RCCL (see
 x-slam_amd/sharded.py); max-over-ranks timing, "scaling": "strong" (one frame stream, fixed
@@ -98,8 +101,27 @@ def integrate_s2_probe(torch, capi, synth, size=512, reps=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     nbytes = 24.0 * U + 2.0 * W * H
-    return {"scene": f"S2 {size}^3", "U": U, "U_frac": round(U / n ** 3, 4), "ms": round(ms, 4),
-            "achieved_GBs": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return {"kernel": "k_integrate_bricks (TSDF integrate), whole xs_integrate_scaled call: clear + brick classification + integrate + count fold",
+            "scene": f"S2 {size}^3 (frustum-filling placement, SURVEY 8d)", "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic("s2") if size == 512 else None, "algorithmic_bytes_per_launch": round(nbytes), "U": U,
+            "U_frac": round(U / n ** 3, 4), "kernel_ms": round(ms, 4)}
+
+
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_integrate_pmc_v3.json")
+
+
+def pmc_traffic(scene):
+    """HBM bytes per launch of the integrate kernel from the committed rocprofv3 counter passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs, each scaled by the factor a known-bytes kernel with the
+    same access pattern gave: profiles/tools/).  Counters cannot be read from inside this process;
+    None when the file is absent."""
+    try:
+        with open(PMC_FILE) as f:
+            v = json.load(f)[scene].get("traffic_bytes_per_launch")
+        return None if v is None else round(v)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -194,14 +216,15 @@ def main():
                    "volume": f"{N}^3", "voxel_size_m": round(7.68 / N, 6), "frames_resident_in_hbm": True,
                    "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + ICP row shards, RCCL all-reduce of the 6x6|6x1 normal equations"},
         "roofline": {"kernel": "k_integrate_bricks (TSDF integrate)", "bound": "hbm", "achieved": round(nbytes / int_ms / 1e6, 2),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / int_ms / 1e6 / HBM_PEAK_GBS, 5), "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / int_ms / 1e6 / HBM_PEAK_GBS, 5),
+                     "traffic": pmc_traffic("s1") if (world == 1 and N == 512) else None,
                      "algorithmic_bytes_per_launch": round(nbytes), "U_per_frame": round(U, 1), "kernel_ms": round(int_ms, 5)},
         "stages_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in st.items()},
     }
     if rank == 0:
         if world == 1 and not a.no_s2:
             runner.close()
-            out["integrate_s2"] = integrate_s2_probe(torch, capi, synth, 512)
+            out["roofline_s2"] = integrate_s2_probe(torch, capi, synth, 512)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, N)
         elif world == 1:

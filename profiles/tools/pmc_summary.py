@@ -17,20 +17,26 @@ def counters(d, kernel_substr):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 out = sys.argv[1]
-res = {"kernel": "k_integrate_bricks<false>, scene S2 512^3 (scratch/probe_s2.py), per launch"}
 cal_known = 12.0 * (96 << 20)
-s2, n = {}, {}
+res = {"calib_known_bytes_each_way": cal_known}
+fac = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    a, cnt = counters(os.path.join(out, "s2_" + c), "k_integrate_bricks"); s2.update(a); n.update(cnt)
     k, _ = counters(os.path.join(out, "calib_" + c), "k_calib_state_update")
     res["calib_" + c + "_KiB"] = k.get(c)
-    res["calib_factor_" + c] = cal_known / (k[c] * 1024.0) if k.get(c) else None
-a, cnt = counters(os.path.join(out, "s2_SQ"), "k_integrate_bricks"); s2.update(a); n.update(cnt)
-res["counters"] = s2
-res["launches_averaged"] = n
-if s2.get("FETCH_SIZE") and s2.get("WRITE_SIZE") and res["calib_factor_FETCH_SIZE"]:
-    res["traffic_read_bytes"] = s2["FETCH_SIZE"] * 1024.0 * res["calib_factor_FETCH_SIZE"]
-    res["traffic_write_bytes"] = s2["WRITE_SIZE"] * 1024.0 * res["calib_factor_WRITE_SIZE"]
-    res["traffic_bytes_per_launch"] = res["traffic_read_bytes"] + res["traffic_write_bytes"]
-res["calib_known_bytes_each_way"] = cal_known
+    fac[c] = cal_known / (k[c] * 1024.0) if k.get(c) else None
+    res["calib_factor_" + c] = fac[c]
+for scene, what in (("s2", "scene S2 512^3 (scratch/probe_s2.py)"), ("s1", "scene S1 512^3 frame 20 (scratch/probe_s1.py), brick-list launches")):
+    e = {"kernel": "k_integrate_bricks<false>, " + what + ", per launch"}
+    cs, n = {}, {}
+    for sub in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+        d = os.path.join(out, scene + "_" + sub)
+        if os.path.isdir(d):
+            a, cnt = counters(d, "k_integrate_bricks"); cs.update(a); n.update(cnt)
+    e["counters"] = cs
+    e["launches_averaged"] = n
+    if cs.get("FETCH_SIZE") and cs.get("WRITE_SIZE") and fac["FETCH_SIZE"]:
+        e["traffic_read_bytes"] = cs["FETCH_SIZE"] * 1024.0 * fac["FETCH_SIZE"]
+        e["traffic_write_bytes"] = cs["WRITE_SIZE"] * 1024.0 * fac["WRITE_SIZE"]
+        e["traffic_bytes_per_launch"] = e["traffic_read_bytes"] + e["traffic_write_bytes"]
+    res[scene] = e
 print(json.dumps(res, indent=1))
