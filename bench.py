@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s2", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--icp-shard-rows", action="store_true",
+                    help="N > 1: split the ICP pixel rows over the ranks and all-reduce the 6x6|6x1 sums every iteration "
+                         "(default: every rank runs the whole ICP, no collective inside the loop)")
+    ap.add_argument("--no-alt", action="store_true", help="N > 1: skip the short run of the other ICP sharding mode after the timed region")
     ap.add_argument("--icp-solve", choices=["host", "device"], default=None,
                     help="where the pose update between ICP iterations runs (default: the library's default)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: put every rank on cuda:0 (needs --backend gloo)")
@@ -163,7 +167,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(a.backend)
         sharded = importlib.import_module("x-slam_amd.sharded")
-        runner = sharded.ShardedKinectFusion(synth.s1_params(N), rank, world, dist)
+        prm = dict(synth.s1_params(N), icp_shard_rows=bool(a.icp_shard_rows))
+        runner = sharded.ShardedKinectFusion(prm, rank, world, dist)
     else:
         dist = None
         prm = synth.s1_params(N)
@@ -214,13 +219,32 @@ def main():
         "config": {"workload": f"XKinectFusion scene S1 (plane+sphere, ICL intrinsics), {N}^3 TSDF, 640x480, first-order CSFD seed "
                                f"i*1e-7 on world2camera(0,3), 3 pyramid levels x (5,4,3) ICP iterations",
                    "volume": f"{N}^3", "voxel_size_m": round(7.68 / N, 6), "frames_resident_in_hbm": True,
-                   "parallelism": "single GPU" if world == 1 else f"z-slab x{world} + ICP row shards, RCCL all-reduce of the 6x6|6x1 normal equations"},
+                   "parallelism": "single GPU" if world == 1 else (
+                       f"z-slab x{world} (integrate, raycast + RCCL composite: min of first-event keys, sum of owner maps); ICP " +
+                       ("row shards + RCCL all-reduce of the 6x6|6x1 normal equations per iteration" if a.icp_shard_rows
+                        else "replicated on every rank (identical bits, no collective inside the loop)"))},
         "roofline": {"kernel": "k_integrate_bricks (TSDF integrate)", "bound": "hbm", "achieved": round(nbytes / int_ms / 1e6, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / int_ms / 1e6 / HBM_PEAK_GBS, 5),
                      "traffic": pmc_traffic("s1") if (world == 1 and N == 512) else None,
                      "algorithmic_bytes_per_launch": round(nbytes), "U_per_frame": round(U, 1), "kernel_ms": round(int_ms, 5)},
         "stages_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in st.items()},
     }
+    if world > 1 and not a.no_alt:
+        # the other ICP sharding mode on the same node, briefly, so both are on record
+        runner.close()
+        alt = sharded.ShardedKinectFusion(dict(prm, icp_shard_rows=not a.icp_shard_rows), rank, world, dist)
+        ka = max(10, min(K, 60))
+        for i in range(0, 6):
+            assert alt.process_frame(frame(i)) == 1
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(6, 6 + ka):
+            assert alt.process_frame(frame(i)) == 1, "tracking lost (alternative mode)"
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out["alt_mode"] = {"icp_shard_rows": (not a.icp_shard_rows), "frames": ka, "value": round(ka / float(tt.item()), 3), "unit": "frames/s"}
+        alt.close()
     if rank == 0:
         if world == 1 and not a.no_s2:
             runner.close()

@@ -44,11 +44,12 @@ def run_world(torch, sh, prm, world, frames):
     return shards, results
 
 
+@pytest.mark.parametrize("rows_sharded", [False, True], ids=["icp_replicated", "icp_row_shards"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(dev, world):
+def test_sharded_equals_single(dev, world, rows_sharded):
     torch, pl, sh = dev
     n = 96
-    prm = synth.s1_params(n)
+    prm = dict(synth.s1_params(n), icp_shard_rows=rows_sharded)
     frames = [0, 1, 2]
     single = pl.KinectFusion(prm)
     for k in frames:
@@ -59,6 +60,10 @@ def test_sharded_equals_single(dev, world):
     for r in range(world):
         assert np.array_equal(results[r][0], results[0][0])
     assert np.allclose(results[0][0], single.world2camera(), rtol=0, atol=2e-7)
+    if not rows_sharded:
+        # every rank ran the single-GPU ICP on the same maps: same bits, no collective in the loop
+        assert np.array_equal(results[0][0], single.world2camera())
+        assert np.array_equal(results[0][3], single.icp_log())
     assert sum(res[1] for res in results) == single.last_U()
     assert results[0][2] == single.last_hits()
     # ICP: first iteration of the last frame sees identical inputs -> sums agree to double rounding

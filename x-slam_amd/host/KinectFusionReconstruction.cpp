@@ -102,6 +102,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
 
     use_gtPose = config.as<bool>("flag_use_gtPose", false);
     icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
+    icp_shard_rows = config.as<bool>("icp_shard_rows", false);
     gt_poses.resize(0);
     frame_id = 0;
     frame_step = config.as<int>("frame_step", 1);
@@ -209,7 +210,8 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
     auto &device_tprev = device_cast<devComplex3>(tprev);
     int total_iters = 0;
     for (int l = 0; l < num_levels; ++l) total_iters += icp_iterations[l];
-    if (icp_solve_on_device && shard_count == 1 && !profiling_icp_sync && total_iters >= 1 && total_iters <= ICP_LOG_MAX)
+    const bool icp_local = shard_count == 1 || !icp_shard_rows;  // this rank evaluates every pixel row itself
+    if (icp_solve_on_device && icp_local && !profiling_icp_sync && total_iters >= 1 && total_iters <= ICP_LOG_MAX)
         return PoseEstimateOnDevice(Rcurr, tcurr, Rprev_inv, tprev, c2w_curr, total_iters);
     stage_begin(ST_ICP);
     for (int level_index = num_levels - 1; level_index >= 0; --level_index) {
@@ -327,9 +329,11 @@ void KinectFusionReconstruction::icp_normal_equations(const MatS33 &Rcurr, const
     MapArr &vc = vmaps_curr_d[level], &nc = nmaps_curr_d[level], &vp = vmaps_g_prev_d[level], &np_ = nmaps_g_prev_d[level];
     const Intr k = kinect_intrinsic(level);
     const int rows = vc.rows() / 3, cols = vc.cols();
-    const int y0 = (int)((long long)rows * shard_rank / shard_count), y1 = (int)((long long)rows * (shard_rank + 1) / shard_count);
+    const bool icp_local = shard_count == 1 || !icp_shard_rows;
+    const int y0 = icp_local ? 0 : (int)((long long)rows * shard_rank / shard_count);
+    const int y1 = icp_local ? rows : (int)((long long)rows * (shard_rank + 1) / shard_count);
     hipStream_t st = current_stream();
-    if (shard_count == 1 && !profiling_icp_sync) {
+    if (icp_local && !profiling_icp_sync) {
         // single GPU: the kernel writes the sums straight into host-coherent pinned memory and then
         // publishes a sequence number; the host spins on it (no copy kernel, no stream synchronise)
         volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
@@ -350,7 +354,7 @@ void KinectFusionReconstruction::icp_normal_equations(const MatS33 &Rcurr, const
         check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re,
                                    &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,
                                    icp_ws_.ptr(), icp_sums_.ptr(), nullptr, 0, st), "estimateCombined");
-        if (shard_count > 1 && collective) collective(collective_user, 0, icp_sums_.ptr(), 55);  // the 440-byte all-reduce
+        if (!icp_local && collective) collective(collective_user, 0, icp_sums_.ptr(), 55);  // the 440-byte all-reduce
         hipSafeCall(hipMemcpyAsync(pinned_sums_, icp_sums_.ptr(), 55 * sizeof(double), hipMemcpyDeviceToHost, st));
         hipSafeCall(hipStreamSynchronize(st));
     }

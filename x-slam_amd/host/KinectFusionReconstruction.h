@@ -77,6 +77,13 @@ public:
     // per iteration slower on this machine (a serial double-precision Cholesky + substitution is ~9000
     // cycles for one wave), kept for hosts that cannot spin.  YAML key icp_solve_on_device.
     bool icp_solve_on_device = false;
+    // Sharded runs (SetSharding): false (default) — every rank evaluates the whole ICP itself; all ranks hold
+    // the same current-frame maps and the composited previous-frame maps, the reduction is deterministic,
+    // so they reach the same pose bit for bit with no collective inside the ICP loop.  true — pixel rows
+    // are split across ranks and the 55 sums are all-reduced every iteration: 12
+    // latency-bound collectives + host waits per frame to save < 0.1 ms of kernel time.  YAML key
+    // icp_shard_rows.
+    bool icp_shard_rows = false;
 
     // instrumentation
     bool profiling = false;
