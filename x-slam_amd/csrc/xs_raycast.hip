@@ -25,6 +25,7 @@ struct RaycastArgs {
     cfloat *vmap; cfloat *nmap; size_t mstep;
     int zs0, zs1;  // z planes resident behind value/grad: storage starts at plane zs0 (whole volume: 0, Z)
     int z0, z1;    // z planes this launch owns (slab mode): only steps whose sample lands here are evaluated
+    int wshift;    // log2 of the wave's pixel-tile width (tile = 2^wshift x 64/2^wshift pixels)
     float *cross_t; // two-kernel path: per pixel, the march time of the step before the crossing (or < 0)
     int *keys;     // slab mode: per pixel, (step << 1 | no_hit) of the first event among owned steps, INT_MAX if none
     unsigned long long *hits;
@@ -37,23 +38,46 @@ __device__ __forceinline__ int sgn(float v) { return (0.0f < v) - (v < 0.0f); }
 // fl(p / vs) (the reciprocals are 4 ulp either side of 1/vs), so when their floors agree that is the
 // answer; otherwise (the quotient lies within ~8 ulp of an integer, ~1e-4 of the samples) the
 // divide is done.
+__device__ __forceinline__ int cvt_flr(float v) {  // (int)floorf(v) in one instruction
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ int voxel_index(float p, float vs, float r_lo, float r_hi) {
-    const float f_lo = floorf(p * r_lo), f_hi = floorf(p * r_hi);
-    if (f_lo == f_hi) return (int)f_lo;
+    const int f_lo = cvt_flr(p * r_lo), f_hi = cvt_flr(p * r_hi);
+    if (f_lo == f_hi) return f_lo;
     return __float2int_rd(p / vs);
 }
 
+// OFF32: the resident planes of one array span at most 4 GiB, so a voxel's byte offset fits 32 bits
+// (two 24-bit multiply-adds and a shift instead of 64-bit multiplies; the load takes a scalar base +
+// 32-bit lane offset).  The kernels are VALU-bound: the march spends a fifth of its instructions on
+// addresses otherwise.
+template <bool OFF32>
 struct Vol {
     const float *value; const float *grad; size_t vstep; int X, Y, Z; float vs; int zs0, zs1;
-    __device__ __forceinline__ float read_value(int x, int y, int z) const {
-        return row_ptr(value, vstep, Y * (z - zs0) + y)[x] + 1e-5f;  // RayCaster.cu:76
+    __device__ __forceinline__ unsigned offset32(int x, int y, int z) const {
+        const unsigned row = __umul24((unsigned)(z - zs0), (unsigned)Y) + (unsigned)y;  // < 2^24 for every supported volume
+        return (__umul24(row, (unsigned)(vstep >> 2)) + (unsigned)x) << 2;
     }
+    __device__ __forceinline__ float value_at(unsigned off) const { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + off); }
+    __device__ __forceinline__ float load_value(int x, int y, int z) const {
+        if (OFF32) return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + offset32(x, y, z));
+        return row_ptr(value, vstep, Y * (z - zs0) + y)[x];
+    }
+    __device__ __forceinline__ float read_value(int x, int y, int z) const { return load_value(x, y, z) + 1e-5f; }  // RayCaster.cu:76
     __device__ __forceinline__ cfloat read(int x, int y, int z) const {  // readTsdf, :69-78
         // readTsdf wraps its indices with % resolution; every caller here passes 0 <= index < resolution
         // (interp() rejects cells outside [1, N-2] before touching the +1 neighbours), where the wrap is
         // the identity — and an integer modulo by a run-time value costs ~35 VALU ops, 192 of them per hit
         z = min(max(z, zs0), zs1 - 1);  // stay inside the resident planes (a no-op unless a slab's halo were too thin)
-        cfloat r(row_ptr(value, vstep, Y * (z - zs0) + y)[x], row_ptr(grad, vstep, Y * (z - zs0) + y)[x]);
+        cfloat r;
+        if (OFF32) {
+            const unsigned off = offset32(x, y, z);
+            r = cfloat(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + off),
+                       *reinterpret_cast<const float *>(reinterpret_cast<const char *>(grad) + off));
+        } else
+            r = cfloat(row_ptr(value, vstep, Y * (z - zs0) + y)[x], row_ptr(grad, vstep, Y * (z - zs0) + y)[x]);
         r += 1e-5f;
         return r;
     }
@@ -82,7 +106,7 @@ struct Vol {
 
 // MODE 0: whole ray in one kernel; 1: slab (multi-GPU); 2: march only, records the crossing time;
 // 3: crossing only (trilinear samples, vertex, normal) for the pixels MODE 2 marked.
-template <int MODE>
+template <int MODE, bool OFF32>
 __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1;
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
@@ -90,12 +114,13 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     // XCD k marches one contiguous band of image tiles — an eighth of the frustum, which fits its
     // L2 — instead of every XCD pulling every line.  Placement only affects speed.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (a.cols + 15) / 16, tiles_y = (a.rows + 15) / 16, ntiles = tiles_x * tiles_y;
+    const int wx = 1 << a.wshift, wy = 64 >> a.wshift;  // wave tile; the workgroup covers 2 x 2 of them
+    const int tiles_x = (a.cols + 2 * wx - 1) / (2 * wx), tiles_y = (a.rows + 2 * wy - 1) / (2 * wy), ntiles = tiles_x * tiles_y;
     const int per_xcd = (ntiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const bool tile_ok = tile < ntiles;
-    const int x = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int x = (tile % tiles_x) * 2 * wx + (wave & 1) * wx + (lane & (wx - 1));
+    const int y = (tile / tiles_x) * 2 * wy + (wave >> 1) * wy + (lane >> a.wshift);
     unsigned hit = 0;
     if (tile_ok && x < a.cols && y < a.rows) {
         int key = 0x7fffffff, step_index = 0;
@@ -111,7 +136,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
             row_ptr(a.vmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
             row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
         }
-        Vol vol{a.value, a.grad, a.vstep, a.X, a.Y, a.Z, a.voxel_size, a.zs0, a.zs1};
+        Vol<OFF32> vol{a.value, a.grad, a.vstep, a.X, a.Y, a.Z, a.voxel_size, a.zs0, a.zs1};
         const cfloat3 ray_start = a.tc2v;
         cfloat3 rn;
         rn.x = cfloat((x - a.intr.cx) / a.intr.fx);
@@ -221,9 +246,12 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                     const int jx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
                     const int jy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
                     const int jz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
-                    const bool ok = (t < max_time) && jx >= 0 && jy >= 0 && jz >= 0 && jx < a.X && jy < a.Y && jz < a.Z;
+                    // (one unsigned compare per axis; a step outside reads voxel (0, 0, first plane), always resident,
+                    // and its value is never looked at)
+                    const bool ok = (t < max_time) && (unsigned)jx < (unsigned)a.X && (unsigned)jy < (unsigned)a.Y && (unsigned)jz < (unsigned)a.Z;
                     oob |= (ok ? 0u : 1u) << j;
-                    val[j] = vol.read_value(min(max(jx, 0), a.X - 1), min(max(jy, 0), a.Y - 1), min(max(jz, 0), a.Z - 1));
+                    if (OFF32) val[j] = vol.value_at(ok ? vol.offset32(jx, jy, jz) : 0u) + 1e-5f;
+                    else val[j] = vol.read_value(ok ? jx : 0, ok ? jy : 0, ok ? jz : a.zs0);
                     t += time_step;
                 }
                 unsigned down = 0, up = 0;  // + to -, - to +
@@ -266,6 +294,11 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     }
 }
 
+// do the resident planes of one volume array span at most 4 GiB (and the 24-bit products hold)?
+static bool fits32(const RaycastArgs &a) {
+    const unsigned long long rows = (unsigned long long)(a.zs1 - a.zs0) * (unsigned long long)a.Y;
+    return (a.vstep % 4) == 0 && rows < (1ull << 24) && (a.vstep >> 2) < (1ull << 24) && rows * a.vstep <= (1ull << 32);
+}
 static void set_inv_vs(RaycastArgs &a) {
     float lo = 1.0f / a.voxel_size, hi = lo;
     for (int i = 0; i < 4; ++i) { lo = nextafterf(lo, 0.f); hi = nextafterf(hi, INFINITY); }
@@ -307,15 +340,22 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
     a.hits = hits_dev; a.cross_t = workspace;
-    dim3 block(256), grid(div_up(div_up(cols, 16) * div_up(rows, 16), 8) * 8);
+    static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
+    a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
+    dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
+    const bool off32 = fits32(a);
     if (workspace) {
-        // march (few registers, many waves, four gathers in flight per lane) then the crossings
+        // march (few registers, many waves, eight gathers in flight per lane) then the crossings
         a.hits = nullptr;
-        hipLaunchKernelGGL(k_raycast<2>, grid, block, 0, (hipStream_t)stream, a);
+        if (off32) hipLaunchKernelGGL((k_raycast<2, true>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_raycast<2, false>), grid, block, 0, (hipStream_t)stream, a);
         a.hits = hits_dev;
-        hipLaunchKernelGGL(k_raycast<3>, grid, block, 0, (hipStream_t)stream, a);
-    } else
-        hipLaunchKernelGGL(k_raycast<0>, grid, block, 0, (hipStream_t)stream, a);
+        if (off32) hipLaunchKernelGGL((k_raycast<3, true>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_raycast<3, false>), grid, block, 0, (hipStream_t)stream, a);
+    } else if (off32)
+        hipLaunchKernelGGL((k_raycast<0, true>), grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((k_raycast<0, false>), grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -347,8 +387,11 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
     a.hits = nullptr; a.cross_t = nullptr;
-    dim3 block(256), grid(div_up(div_up(cols, 16) * div_up(rows, 16), 8) * 8);
-    hipLaunchKernelGGL(k_raycast<1>, grid, block, 0, (hipStream_t)stream, a);
+    static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
+    a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
+    dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
+    if (fits32(a)) hipLaunchKernelGGL((k_raycast<1, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_raycast<1, false>), grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }
