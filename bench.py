@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--icp-shard-rows", action="store_true",
                     help="N > 1: split the ICP pixel rows over the ranks and all-reduce the 6x6|6x1 sums every iteration "
                          "(default: every rank runs the whole ICP, no collective inside the loop)")
+    ap.add_argument("--force-composite", action="store_true",
+                    help="rehearsal on one GPU: run the sharded raycast composite and its RCCL collectives with a single rank")
     ap.add_argument("--no-alt", action="store_true", help="N > 1: skip the short run of the other ICP sharding mode after the timed region")
     ap.add_argument("--icp-solve", choices=["host", "device"], default=None,
                     help="where the pose update between ICP iterations runs (default: the library's default)")
@@ -163,11 +165,13 @@ def main():
     stream = torch.cuda.current_stream()
     pl.set_stream(stream)
 
-    if world > 1:
+    if world > 1 or a.force_composite:
         import torch.distributed as dist
-        dist.init_process_group(a.backend)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
         sharded = importlib.import_module("x-slam_amd.sharded")
-        prm = dict(synth.s1_params(N), icp_shard_rows=bool(a.icp_shard_rows))
+        prm = dict(synth.s1_params(N), icp_shard_rows=bool(a.icp_shard_rows), force_shard_composite=bool(a.force_composite))
         runner = sharded.ShardedKinectFusion(prm, rank, world, dist)
     else:
         dist = None

@@ -117,3 +117,36 @@ def test_sharded_first_frame_bit_exact(dev):
     for s in shards:
         s.close()
     single.close()
+
+
+def test_single_rank_composite_path(dev):
+    """force_shard_composite: the slab raycast + key / map composite with one rank (collectives are
+    identities) must reproduce the ordinary raycast bit for bit — the path bench.py --gpus N takes,
+    exercised without a second GPU."""
+    torch, pl, sh = dev
+    n = 96
+    prm = synth.s1_params(n)
+    frames = [0, 1, 2]
+    single = pl.KinectFusion(prm)
+    calls = []
+
+    def ident(_user, op, ptr, count):
+        calls.append((op, count))
+    forced = sh.ShardedKinectFusion(dict(prm, force_shard_composite=True), 0, 1, collective=ident)
+    for k in frames:
+        d = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
+        assert single.process_frame(d) == 1 and forced.process_frame(d) == 1
+    assert np.array_equal(single.world2camera(), forced.world2camera())
+    assert single.last_hits() == forced.last_hits() and single.last_U() == forced.last_U()
+    for which in ("vmaps_g_prev", "nmaps_g_prev"):
+        for level in range(3):
+            a, b = single.map(which, level), forced.map(which, level)
+            rows = 480 >> level   # the sentinel lives in the x plane; y / z planes are only defined where it is absent
+            na, nb = np.isnan(a[:rows, :, 0]), np.isnan(b[:rows, :, 0])
+            assert np.array_equal(na, nb)
+            for p in range(3):
+                assert np.array_equal(a[p * rows:(p + 1) * rows][~na], b[p * rows:(p + 1) * rows][~nb])
+    # per frame: one min over W*H keys, one sum over both level-0 model maps (contiguous allocation)
+    per_frame = calls[-2:]
+    assert per_frame[0] == (1, 640 * 480) and per_frame[1][0] == 2 and per_frame[1][1] == 2 * 3 * 480 * (640 * 8 // 4)
+    single.close(); forced.close()

@@ -97,12 +97,13 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     zo1 = (int)((long long)resolutionZ * (shard_rank + 1) / shard_count);
     zs0 = shard_count > 1 ? std::max(0, zo0 - HALO) : 0;
     zs1 = shard_count > 1 ? std::min(resolutionZ, zo1 + HALO) : resolutionZ;
+    icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
+    icp_shard_rows = config.as<bool>("icp_shard_rows", false);
+    force_shard_composite = config.as<bool>("force_shard_composite", false);
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
 
     use_gtPose = config.as<bool>("flag_use_gtPose", false);
-    icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
-    icp_shard_rows = config.as<bool>("icp_shard_rows", false);
     gt_poses.resize(0);
     frame_id = 0;
     frame_step = config.as<int>("frame_step", 1);
@@ -120,8 +121,17 @@ void KinectFusionReconstruction::AllocateBuffers() {
         depths_curr_d[i].create(pyr_rows, pyr_cols);
         vmaps_curr_d[i].create(pyr_rows * 3, pyr_cols);
         nmaps_curr_d[i].create(pyr_rows * 3, pyr_cols);
-        vmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
-        nmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
+        if (i == 0) {
+            // the level-0 model maps share one allocation, vertex planes then normal planes: the sharded
+            // raycast composite adds both with a single all-reduce
+            const size_t step = ((size_t)pyr_cols * sizeof(devComplex) + 255) / 256 * 256;
+            maps_prev0_block_.create(2 * (size_t)pyr_rows * 3 * step);
+            vmaps_g_prev_d[0] = MapArr(pyr_rows * 3, pyr_cols, maps_prev0_block_.ptr(), step);
+            nmaps_g_prev_d[0] = MapArr(pyr_rows * 3, pyr_cols, maps_prev0_block_.ptr() + (size_t)pyr_rows * 3 * step, step);
+        } else {
+            vmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
+            nmaps_g_prev_d[i].create(pyr_rows * 3, pyr_cols);
+        }
     }
     depthRawScaled_d.create(depth_height, depth_width);
     {
@@ -132,7 +142,7 @@ void KinectFusionReconstruction::AllocateBuffers() {
         icp_sums_.create(64);
         icp_pose_.create(xs_icp_pose_state_bytes());
         ray_ws_.create((size_t)depth_width * depth_height);
-        if (shard_count > 1) {
+        if (shard_count > 1 || force_shard_composite) {
             ray_keys_.create((size_t)depth_width * depth_height);
             ray_min_keys_.create((size_t)depth_width * depth_height);
         }
@@ -151,6 +161,7 @@ void KinectFusionReconstruction::ReleaseBuffers() {
         vmaps_g_prev_d[i].release();
         nmaps_g_prev_d[i].release();
     }
+    maps_prev0_block_.release();
     g_buf.release();
     sum_buf.release();
     depthRawScaled_d.release();
@@ -480,7 +491,7 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.x = volume_resolution.x();
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
-    if (shard_count == 1) {
+    if (shard_count == 1 && !force_shard_composite) {
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
                 voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1, ray_ws_.ptr());
         return 0;
@@ -497,8 +508,14 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     if (collective) collective(collective_user, 1, ray_min_keys_.ptr(), (long)rows * cols);
     check_rc(xs_raycast_compose_mask(ray_keys_.ptr(), ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, st), "raycast");
     if (collective) {
-        collective(collective_user, 2, xyz_g_d.ptr(), (long)(xyz_g_d.step() / 4) * xyz_g_d.rows());
-        collective(collective_user, 2, normal_g_d.ptr(), (long)(normal_g_d.step() / 4) * normal_g_d.rows());
+        const long words = (long)(xyz_g_d.step() / 4) * xyz_g_d.rows();
+        const bool adjacent = normal_g_d.step() == xyz_g_d.step() && normal_g_d.rows() == xyz_g_d.rows() &&
+                              (const char *)normal_g_d.ptr() == (const char *)xyz_g_d.ptr() + xyz_g_d.step() * (size_t)xyz_g_d.rows();
+        if (adjacent) collective(collective_user, 2, xyz_g_d.ptr(), 2 * words);  // 14.7 MB, one collective
+        else {
+            collective(collective_user, 2, xyz_g_d.ptr(), words);
+            collective(collective_user, 2, normal_g_d.ptr(), words);
+        }
     }
     check_rc(xs_raycast_compose_finish(ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols,
                                        counters_.ptr() + 1, st), "raycast");

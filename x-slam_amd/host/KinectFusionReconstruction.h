@@ -84,6 +84,8 @@ public:
     // latency-bound collectives + host waits per frame to save < 0.1 ms of kernel time.  YAML key
     // icp_shard_rows.
     bool icp_shard_rows = false;
+    // test aid: take the slab raycast + composite (and its collectives) even with a single rank
+    bool force_shard_composite = false;
 
     // instrumentation
     bool profiling = false;
@@ -132,6 +134,7 @@ private:
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
     DeviceArray<unsigned char> icp_pose_;      // device-resident pose of the ICP loop (xs_icp_iterate)
+    DeviceArray<unsigned char> maps_prev0_block_;  // level-0 model vertex + normal maps, one allocation
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
     // host-coherent: [0..54] sums + count, [56] completion sequence word, [64..80) pose state of the
