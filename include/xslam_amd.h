@@ -107,6 +107,11 @@ int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, int rows, in
  *                                                                            Map.cu:105-152, 233-259 */
 int xs_resize_vmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream);
 int xs_resize_nmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream);
+/* Levels 1 and 2 of both model maps in one launch (what the orchestrator does with two resizeVMap and
+ * two resizeNMap calls per frame, KinectFusionReconstruction.cpp:272-277); same values as the four
+ * separate calls.  rows0 / cols0: one plane of the level-0 maps. */
+int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
+                      size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *stream);
 
 /* ---- Raycast ------------------------------------------------------------------------------ */
 /* raycast(const Intr&, const MatS33& Rc2v, const devComplex3& tc2v, const MatS33& Rv2w,

@@ -111,6 +111,36 @@ def test_resize_maps(dev, oracle):
         cmap_close(out.cpu().numpy(), oracle.resize_map(src, normalize), H // 2)
 
 
+@pytest.mark.parametrize("rows,cols", [(480, 640), (122, 90), (36, 70)])
+def test_resize_pyramid_equals_four_resizes(dev, rows, cols):
+    """xs_resize_pyramid (levels 1 and 2 of both model maps in one launch) against resizeVMap / resizeNMap
+    applied twice: identical bits wherever a pixel is defined, identical sentinels, odd sizes included."""
+    torch, capi = dev
+    g = torch.Generator(device="cpu").manual_seed(7)
+    def rnd_map():
+        m = torch.randn((3 * rows, cols, 2), generator=g, dtype=torch.float32)
+        m[..., 1] *= 1e-7
+        holes = torch.rand((rows, cols), generator=g) < 0.03
+        m[:rows][holes] = float("nan")   # sentinel in the x plane only
+        return m.cuda()
+    v0, n0 = rnd_map(), rnd_map()
+    r1, c1, r2, c2 = rows // 2, cols // 2, rows // 4, cols // 4
+    def empty(r, c):
+        return torch.full((3 * r, c, 2), 123.0, dtype=torch.float32, device="cuda")
+    a = [empty(r1, c1), empty(r1, c1), empty(r2, c2), empty(r2, c2)]
+    b = [empty(r1, c1), empty(r1, c1), empty(r2, c2), empty(r2, c2)]
+    capi.resize_vmap(v0, cols * 8, rows, cols, a[0], c1 * 8)
+    capi.resize_nmap(n0, cols * 8, rows, cols, a[1], c1 * 8)
+    capi.resize_vmap(a[0], c1 * 8, r1, c1, a[2], c2 * 8)
+    capi.resize_nmap(a[1], c1 * 8, r1, c1, a[3], c2 * 8)
+    capi.resize_pyramid(v0, n0, cols * 8, rows, cols, b[0], b[1], c1 * 8, b[2], b[3], c2 * 8)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y))
+        assert np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)])   # untouched entries keep the fill value on both sides
+
+
 # ---- raycast ----------------------------------------------------------------------------
 def build_volume(oracle, prm, n, frames):
     res = [n, n, n]

@@ -63,6 +63,7 @@ _SIGS = {
                                   C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "xs_resize_pyramid": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "xs_icp_workspace_bytes": (_sz, []),
     "xs_icp_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -203,6 +204,11 @@ def pyr_down(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
 def create_vmap(intr, depth, depth_step, rows, cols, vmap, vmap_step, stream=None):
     k = _fa(intr, 4)
     check(_lib.xs_create_vmap(k.ctypes.data_as(_f32p), _ptr(depth), depth_step, rows, cols, _ptr(vmap), vmap_step, _stream(stream)))
+
+
+def resize_pyramid(vmap0, nmap0, in_step, rows0, cols0, vmap1, nmap1, mid_step, vmap2, nmap2, out_step, stream=None):
+    check(_lib.xs_resize_pyramid(_ptr(vmap0), _ptr(nmap0), in_step, rows0, cols0, _ptr(vmap1), _ptr(nmap1), mid_step, _ptr(vmap2), _ptr(nmap2),
+                                 out_step, _stream(stream)))
 
 
 def create_nmap(vmap, nmap, map_step, rows, cols, stream=None):

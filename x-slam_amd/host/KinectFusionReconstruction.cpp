@@ -431,12 +431,33 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
     stage_end(ST_RAYCAST);
     stage_begin(ST_RESIZE);
+    ModelMapPyramid();
+    stage_end(ST_RESIZE);
+    return 1;
+}
+
+// reference :272-277: resizeVMap / resizeNMap per level.  With three levels both halvings of both maps
+// are one launch (xs_resize_pyramid: same values).
+void KinectFusionReconstruction::ModelMapPyramid() {
+    if (num_levels == 3) {
+        const int rows0 = vmaps_g_prev_d[0].rows() / 3, cols0 = vmaps_g_prev_d[0].cols();
+        for (int i = 1; i < 3; ++i) {
+            vmaps_g_prev_d[i].create((rows0 >> i) * 3, cols0 >> i);
+            nmaps_g_prev_d[i].create((rows0 >> i) * 3, cols0 >> i);
+        }
+        if (vmaps_g_prev_d[0].step() == nmaps_g_prev_d[0].step() && vmaps_g_prev_d[1].step() == nmaps_g_prev_d[1].step() &&
+            vmaps_g_prev_d[2].step() == nmaps_g_prev_d[2].step()) {
+            check_rc(xs_resize_pyramid(&vmaps_g_prev_d[0].ptr()->re, &nmaps_g_prev_d[0].ptr()->re, vmaps_g_prev_d[0].step(), rows0, cols0,
+                                       &vmaps_g_prev_d[1].ptr()->re, &nmaps_g_prev_d[1].ptr()->re, vmaps_g_prev_d[1].step(),
+                                       &vmaps_g_prev_d[2].ptr()->re, &nmaps_g_prev_d[2].ptr()->re, vmaps_g_prev_d[2].step(), current_stream()),
+                     "resizeMap");
+            return;
+        }
+    }
     for (int i = 1; i < num_levels; ++i) {
         resizeVMap(vmaps_g_prev_d[i - 1], vmaps_g_prev_d[i], false);
         resizeNMap(nmaps_g_prev_d[i - 1], nmaps_g_prev_d[i], false);
     }
-    stage_end(ST_RESIZE);
-    return 1;
 }
 
 // reference :280-299
@@ -588,10 +609,7 @@ bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
     tsdf_volume_d_ptr->weight().upload(w.data(), X * 4, rows, X);
     // previous-frame maps are derived state: regenerate them from the restored volume and pose
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
-    for (int i = 1; i < num_levels; ++i) {
-        resizeVMap(vmaps_g_prev_d[i - 1], vmaps_g_prev_d[i], false);
-        resizeNMap(nmaps_g_prev_d[i - 1], nmaps_g_prev_d[i], false);
-    }
+    ModelMapPyramid();
     synchronize();
     return true;
 }

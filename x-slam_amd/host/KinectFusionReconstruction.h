@@ -111,6 +111,7 @@ public:
     int IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d);
     static int SmoothDepthFrame(MapArr &dst_d, const DeviceArray2D<ushort> &src_d);
     int CalculatePointCloud(MapArr &xyz_g_d, MapArr &normal_g_d);
+    void ModelMapPyramid();
 
     static inline Vector3cf GetTranslation(Matrix4cf &trans_mat) { return xs_host::GetTranslation(trans_mat); }
     static inline Matrix3frm GetRotation(Matrix4cf &trans_mat) { return xs_host::GetRotation(trans_mat); }
