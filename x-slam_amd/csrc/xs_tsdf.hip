@@ -341,9 +341,19 @@ __device__ __forceinline__ void block_count_add(unsigned n_upd, unsigned long lo
 }
 enum { COUNT_SLOTS = 16 };  // in the workspace header, after the brick count (8-byte words 1..16)
 __global__ void k_fold_count(unsigned long long *slots, unsigned long long *updated) {
-    unsigned long long t = 0;
-    for (int i = 0; i < COUNT_SLOTS; ++i) { t += slots[i]; slots[i] = 0; }
-    if (t) atomicAdd(updated, t);
+    // one lane per slot, device-scope exchanges: the slots were written by atomics from every XCD, and a
+    // plain load here can be served from this XCD's L2 copy of the line (every workgroup of the integrate
+    // kernel pulled it in when it read the brick count next to them) — observed as lost counts when the
+    // clear in front of the classification was removed
+    __shared__ unsigned long long s_v[COUNT_SLOTS];
+    const int i = threadIdx.x;
+    if (i < COUNT_SLOTS) s_v[i] = atomicExch(&slots[i], 0ull);
+    __syncthreads();
+    if (i == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < COUNT_SLOTS; ++k) t += s_v[k];
+        if (t) atomicAdd(updated, t);
+    }
 }
 
 // ---- path 1: column walk (no workspace): thread (x, y) walks its clipped z interval ---------
@@ -520,7 +530,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         else
             hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
         if (g_int_ev1) XS_CHECK(hipEventRecord(g_int_ev1, st));
-        if (updated_dev) hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
+        if (updated_dev) hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
     } else {
         int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
         while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
