@@ -36,6 +36,16 @@ __device__ __forceinline__ cfloat3 operator*(const MatS33 &m, const cfloat3 &v) 
 __device__ __forceinline__ dcfloat dot(const dcfloat3 &a, const dcfloat3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ dcfloat norm(const dcfloat3 &v) { return sqrt(dot(v, v)); }
 
+// TsdfFusion.h:7-25: a voxel's complex TSDF is stored as value (real part) and grad (imaginary part)
+// in two float arrays, its weight in a third
+__device__ __forceinline__ void pack_tsdf(cfloat tsdf, int weight, float &save_value, int &save_weight, float &save_grad) {
+    save_value = tsdf.re; save_weight = weight; save_grad = tsdf.im;
+}
+__device__ __forceinline__ void unpack_tsdf(float save_value, int save_weight, float save_grad, cfloat &tsdf, int &weight) {
+    weight = save_weight; tsdf = cfloat(save_value, save_grad);
+}
+__device__ __forceinline__ cfloat unpack_tsdf(float save_value, float save_grad) { return cfloat(save_value, save_grad); }
+
 __host__ __device__ __forceinline__ float qnan_f() {  // cx.h:158: __int_as_float(0x7fffffff)
 #if defined(__HIP_DEVICE_COMPILE__)
     return __int_as_float(0x7fffffff);

@@ -74,10 +74,10 @@ struct Vol {
         cfloat r;
         if (OFF32) {
             const unsigned off = offset32(x, y, z);
-            r = cfloat(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + off),
-                       *reinterpret_cast<const float *>(reinterpret_cast<const char *>(grad) + off));
+            r = unpack_tsdf(*reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + off),
+                            *reinterpret_cast<const float *>(reinterpret_cast<const char *>(grad) + off));
         } else
-            r = cfloat(row_ptr(value, vstep, Y * (z - zs0) + y)[x], row_ptr(grad, vstep, Y * (z - zs0) + y)[x]);
+            r = unpack_tsdf(row_ptr(value, vstep, Y * (z - zs0) + y)[x], row_ptr(grad, vstep, Y * (z - zs0) + y)[x]);
         r += 1e-5f;
         return r;
     }

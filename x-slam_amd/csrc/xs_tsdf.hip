@@ -267,7 +267,7 @@ __device__ __forceinline__ bool update_voxel(const IntegrateArgs &a, const Voxel
     // divisor.  x / x is exactly 1 and 0 / x is exactly 0 (sign kept) in IEEE arithmetic, so the two
     // divides are skipped where the numerator equals the divisor or is zero — the steady state of
     // free space (value 1, derivative 0), i.e. most written voxels.
-    const cfloat tsdf_prev(pre_v, pre_g);
+    const cfloat tsdf_prev = unpack_tsdf(pre_v, pre_g);
     const cfloat num = tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf;
     const float den = __int2float_rn(pre_w + 1);
     const bool div_v = !(num.re == den), div_g = !(num.im == 0.0f);
