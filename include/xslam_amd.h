@@ -103,6 +103,11 @@ int xs_create_vmap(const float *intr4, const float *depth, size_t depth_step, in
                    void *stream);
 /* createNMap(const MapArr& vmap, MapArr& nmap); rows = rows of one plane     Map.cu:32-70, 89-102 */
 int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, int rows, int cols, void *stream);
+/* createVMap + createNMap of every pyramid level (1..3) in one launch — the six calls SurfaceMeasure makes
+ * per frame (KinectFusionReconstruction.cpp:290-296); same values.  intr4s: levels x {fx, fy, cx, cy}
+ * (already divided per level); level l is (rows0 >> l) x (cols0 >> l); pointer / pitch arrays per level. */
+int xs_create_vnmaps(int levels, const float *intr4s, const float *const *depths, const size_t *depth_steps, int rows0, int cols0,
+                     float *const *vmaps, float *const *nmaps, const size_t *map_steps, void *stream);
 /* resizeVMap / resizeNMap(const MapArr& in, MapArr& out); src_rows = rows of one input plane
  *                                                                            Map.cu:105-152, 233-259 */
 int xs_resize_vmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream);

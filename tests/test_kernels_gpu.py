@@ -111,6 +111,34 @@ def test_resize_maps(dev, oracle):
         cmap_close(out.cpu().numpy(), oracle.resize_map(src, normalize), H // 2)
 
 
+def test_vnmaps_all_levels_equal_separate_calls(dev, oracle):
+    """xs_create_vnmaps (vertex + normal maps of three levels, one launch) against createVMap + createNMap per
+    level: same bits, same sentinels."""
+    torch, capi = dev
+    prm = synth.s1_params(64)
+    d = oracle.bilateral(noisy_depth())
+    d[50:60, 100:130] = 0
+    ds = [d]
+    for _ in range(2):
+        ds.append(oracle.pyr_down(ds[-1]))
+    dd = [to_dev(torch, x) for x in ds]
+    intrs = [intr_of(prm, l) for l in range(3)]
+    sep_v, sep_n, fus_v, fus_n = [], [], [], []
+    for l in range(3):
+        r, c = H >> l, W >> l
+        for lst in (sep_v, sep_n, fus_v, fus_n):
+            lst.append(torch.full((3 * r, c, 2), 77.0, dtype=torch.float32, device="cuda"))
+        capi.create_vmap(intrs[l], dd[l], c * 8, r, c, sep_v[l], c * 8)
+        capi.create_nmap(sep_v[l], sep_n[l], c * 8, r, c)
+    capi.create_vnmaps(intrs, dd, [(W >> l) * 8 for l in range(3)], H, W, fus_v, fus_n, [(W >> l) * 8 for l in range(3)])
+    torch.cuda.synchronize()
+    for a, b in zip(sep_v + sep_n, fus_v + fus_n):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    assert np.isnan(sep_n[0].cpu().numpy()[:H, :, 0]).any() and not np.isnan(sep_n[0].cpu().numpy()[:H, :, 0]).all()
+
+
 @pytest.mark.parametrize("rows,cols", [(480, 640), (122, 90), (36, 70)])
 def test_resize_pyramid_equals_four_resizes(dev, rows, cols):
     """xs_resize_pyramid (levels 1 and 2 of both model maps in one launch) against resizeVMap / resizeNMap

@@ -55,6 +55,8 @@ _SIGS = {
     "xs_pyr_down": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_create_vmap": (C.c_int, [_f32p, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_create_nmap": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp]),
+    "xs_create_vnmaps": (C.c_int, [C.c_int, _f32p, C.POINTER(_vp), C.POINTER(_sz), C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
+                                   C.POINTER(_sz), _vp]),
     "xs_resize_vmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_resize_nmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_raycast": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
@@ -204,6 +206,17 @@ def pyr_down(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
 def create_vmap(intr, depth, depth_step, rows, cols, vmap, vmap_step, stream=None):
     k = _fa(intr, 4)
     check(_lib.xs_create_vmap(k.ctypes.data_as(_f32p), _ptr(depth), depth_step, rows, cols, _ptr(vmap), vmap_step, _stream(stream)))
+
+
+def create_vnmaps(intrs, depths, depth_steps, rows0, cols0, vmaps, nmaps, map_steps, stream=None):
+    """Vertex + normal maps of all pyramid levels in one launch.  intrs: per-level [fx, fy, cx, cy]."""
+    n = len(depths)
+    k = np.ascontiguousarray(intrs, dtype=np.float32).reshape(-1)
+    assert k.size == 4 * n
+    P = lambda ts: (_vp * n)(*[_ptr(t) for t in ts])
+    S = lambda xs: (_sz * n)(*[int(x) for x in xs])
+    check(_lib.xs_create_vnmaps(n, k.ctypes.data_as(_f32p), P(depths), S(depth_steps), rows0, cols0, P(vmaps), P(nmaps), S(map_steps),
+                                _stream(stream)))
 
 
 def resize_pyramid(vmap0, nmap0, in_step, rows0, cols0, vmap1, nmap1, mid_step, vmap2, nmap2, out_step, stream=None):

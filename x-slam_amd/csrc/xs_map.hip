@@ -166,6 +166,76 @@ extern "C" int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, i
 }
 
 // ------------------------------------------------------------------------------------------
+// createVMap + createNMap for every pyramid level in one launch (SurfaceMeasure,
+// KinectFusionReconstruction.cpp:290-296).  A vertex is a function of its own depth pixel, so the
+// normal's two neighbour vertices are recomputed from depth(u+1, v) and depth(u, v+1) with the same
+// three operations instead of being read back from the vertex map: same values, no dependency between
+// the two maps, one kernel.  blockIdx.z = level.
+struct VnLevel {
+    const cfloat *depth; size_t dstep; cfloat *vmap; cfloat *nmap; size_t mstep;
+    int rows, cols; float fx_inv, fy_inv, cx, cy;
+};
+struct VnArgs { VnLevel lv[3]; int levels; };
+__device__ __forceinline__ bool vertex_of(const VnLevel &L, int u, int v, cfloat3 &p) {
+    cfloat z = row_ptr(L.depth, L.dstep, v)[u];
+    z /= 1000.f;
+    if (z.re == 0) return false;
+    p.x = z * (float(u) - L.cx) * L.fx_inv;
+    p.y = z * (float(v) - L.cy) * L.fy_inv;
+    p.z = z;
+    return true;
+}
+__global__ void __launch_bounds__(256) k_vnmaps(const VnArgs a) {
+    const VnLevel &L = a.lv[blockIdx.z];
+    const int u = threadIdx.x + blockIdx.x * blockDim.x;
+    const int v = threadIdx.y + blockIdx.y * blockDim.y;
+    if (u >= L.cols || v >= L.rows) return;
+    cfloat3 v00;
+    const bool ok00 = vertex_of(L, u, v, v00);
+    if (ok00) {
+        row_ptr(L.vmap, L.mstep, v)[u] = v00.x;
+        row_ptr(L.vmap, L.mstep, v + L.rows)[u] = v00.y;
+        row_ptr(L.vmap, L.mstep, v + L.rows * 2)[u] = v00.z;
+    } else
+        row_ptr(L.vmap, L.mstep, v)[u] = cfloat(qnan_f(), 0.f);
+    const cfloat nan_c(qnan_f(), 0.f);
+    if (u == L.cols - 1 || v == L.rows - 1) { row_ptr(L.nmap, L.mstep, v)[u] = nan_c; return; }
+    cfloat3 v01, v10;
+    if (ok00 && vertex_of(L, u + 1, v, v01) && vertex_of(L, u, v + 1, v10)) {
+        const cfloat3 r = normalized(cross(v01 - v00, v10 - v00));
+        row_ptr(L.nmap, L.mstep, v)[u] = r.x;
+        row_ptr(L.nmap, L.mstep, v + L.rows)[u] = r.y;
+        row_ptr(L.nmap, L.mstep, v + 2 * L.rows)[u] = r.z;
+    } else
+        row_ptr(L.nmap, L.mstep, v)[u] = nan_c;
+}
+/* Vertex and normal maps of all pyramid levels (1..3) in one launch: what createVMap(intr(level), depth[level],
+ * vmap[level]) followed by createNMap(vmap[level], nmap[level]) produce for level = 0 .. levels-1 (Map.h:31-44).
+ * intr4s: levels x {fx, fy, cx, cy} already divided per level; rows0 / cols0: level-0 size, level l is
+ * (rows0 >> l) x (cols0 >> l); steps in bytes per level. */
+extern "C" int xs_create_vnmaps(int levels, const float *intr4s, const float *const *depths, const size_t *depth_steps, int rows0, int cols0,
+                                float *const *vmaps, float *const *nmaps, const size_t *map_steps, void *stream) {
+    if (levels < 1 || levels > 3 || !intr4s || !depths || !depth_steps || !vmaps || !nmaps || !map_steps)
+        return xs_set_error(hipErrorInvalidValue, "xs_create_vnmaps: bad arguments");
+    if (rows0 <= 0 || cols0 <= 0) return 0;
+    VnArgs a;
+    a.levels = levels;
+    for (int l = 0; l < levels; ++l) {
+        if (!depths[l] || !vmaps[l] || !nmaps[l]) return xs_set_error(hipErrorInvalidValue, "xs_create_vnmaps: null pointer");
+        VnLevel &L = a.lv[l];
+        L.depth = (const cfloat *)depths[l]; L.dstep = depth_steps[l];
+        L.vmap = (cfloat *)vmaps[l]; L.nmap = (cfloat *)nmaps[l]; L.mstep = map_steps[l];
+        L.rows = rows0 >> l; L.cols = cols0 >> l;
+        L.fx_inv = 1.f / intr4s[4 * l]; L.fy_inv = 1.f / intr4s[4 * l + 1]; L.cx = intr4s[4 * l + 2]; L.cy = intr4s[4 * l + 3];
+    }
+    for (int l = levels; l < 3; ++l) a.lv[l] = a.lv[0];
+    dim3 block(64, 4), grid(div_up(cols0, 64), div_up(rows0, 4), levels);
+    hipLaunchKernelGGL(k_vnmaps, grid, block, 0, (hipStream_t)stream, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 template <bool NORMALIZE>
 __global__ void __launch_bounds__(256) k_resize(int drows, int dcols, int srows, const cfloat *in, size_t istep, cfloat *out, size_t ostep) {
     const int x = threadIdx.x + blockIdx.x * blockDim.x;

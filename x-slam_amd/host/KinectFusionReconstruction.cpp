@@ -475,9 +475,27 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     stage_begin(ST_SURFACE);
     SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
     for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
-    for (int i = 0; i < num_levels; ++i) {
-        createVMap(kinect_intrinsic(i), depths_curr_d[i], vmaps_curr_d[i]);  // camera frame, +z forward
-        createNMap(vmaps_curr_d[i], nmaps_curr_d[i]);
+    {   // createVMap + createNMap per level (camera frame, +z forward), all levels in one launch
+        Intr ks[3];
+        const float *dp[3]; size_t ds[3], ms[3];
+        float *vp[3], *np_[3];
+        bool uniform = num_levels <= 3;
+        for (int i = 0; i < num_levels && uniform; ++i) {
+            ks[i] = kinect_intrinsic(i);
+            vmaps_curr_d[i].create(depths_curr_d[i].rows() * 3, depths_curr_d[i].cols());
+            nmaps_curr_d[i].create(depths_curr_d[i].rows() * 3, depths_curr_d[i].cols());
+            dp[i] = &depths_curr_d[i].ptr()->re; ds[i] = depths_curr_d[i].step();
+            vp[i] = &vmaps_curr_d[i].ptr()->re; np_[i] = &nmaps_curr_d[i].ptr()->re; ms[i] = vmaps_curr_d[i].step();
+            uniform = depths_curr_d[i].rows() == (depth_height >> i) && depths_curr_d[i].cols() == (depth_width >> i) &&
+                      nmaps_curr_d[i].step() == ms[i];
+        }
+        if (uniform)
+            check_rc(xs_create_vnmaps(num_levels, &ks[0].fx, dp, ds, depth_height, depth_width, vp, np_, ms, current_stream()), "createVMap");
+        else
+            for (int i = 0; i < num_levels; ++i) {
+                createVMap(kinect_intrinsic(i), depths_curr_d[i], vmaps_curr_d[i]);
+                createNMap(vmaps_curr_d[i], nmaps_curr_d[i]);
+            }
     }
     stage_end(ST_SURFACE);
     // scaleDepthKernal of integrateTsdfVolume (TsdfFusion.cu:182-187) also depends on the depth image
