@@ -47,8 +47,14 @@ void xs_kf_set_gt_poses(void *kf, int n, const float *c2w32);
  * depth_dev: u16 millimetres resident in device memory, row pitch step_bytes.  Returns 1, or 0
  * when the alignment failed (frame_id is then not advanced, as in the reference). */
 int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes);
-/* the reference demo's upload + ProcessFrame (main.cpp:50-58): host buffer, dense rows */
+/* the reference demo's upload + ProcessFrame (main.cpp:50-58): host buffer, dense rows.  The frame is copied
+ * asynchronously on the pipeline's second stream (through a pinned staging buffer unless depth_host is
+ * itself pinned), where the map preparation follows it without a host wait. */
 int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host);
+/* the next of two host-pinned staging buffers (depth_width x depth_height u16): decode a frame straight into
+ * it and pass it to xs_kf_process_frame_host — no staging copy.  Blocks only if the copy out of that buffer
+ * two frames ago has not finished. */
+uint16_t *xs_kf_ingest_buffer(void *kf);
 void xs_kf_synchronize(void *kf);
 
 int xs_kf_frame_id(void *kf);

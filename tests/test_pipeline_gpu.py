@@ -211,6 +211,26 @@ def test_host_and_device_depth_entry_points_agree(dev):
     a.close(); b.close()
 
 
+def test_pinned_ingest_buffers(dev):
+    """Frames written into the pipeline's own pinned staging buffers (no staging copy, asynchronous upload on
+    the second stream, two buffers alternating) give the same poses and volume as device-resident frames."""
+    torch, pl = dev
+    prm = synth.s1_params(64)
+    a, b = pl.KinectFusion(prm), pl.KinectFusion(prm)
+    seen = set()
+    for k in range(5):
+        d = synth.s1_frame(k)
+        buf = b.ingest_buffer()
+        seen.add(buf.ctypes.data)
+        buf[...] = d
+        assert a.process_frame(upload(torch, d)) == 1 and b.process_frame_host(buf) == 1
+    assert len(seen) == 2
+    assert np.array_equal(a.world2camera(), b.world2camera())
+    for x, y in zip(a.volume(), b.volume()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_alignment_failure_does_not_advance(dev):
     """A frame with no valid depth gives a singular 6x6 system: ProcessFrame returns 0 and frame_id
     stays (KinectFusionReconstruction.cpp:151-157, :203-210); the next good frame still tracks."""

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -32,6 +33,9 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
+    for (int i = 0; i < 2; ++i) {
+        if (ingest_pinned_[i]) { (void)hipEventSynchronize(ingest_done_[i]); (void)hipHostFree(ingest_pinned_[i]); (void)hipEventDestroy(ingest_done_[i]); }
+    }
     if (tsdf_volume_d_ptr) ReleaseBuffers();
     for (auto &slot : prof_ring_)
         for (int s = 0; s < ST_COUNT; ++s) { (void)hipEventDestroy(slot.ev[s][0]); (void)hipEventDestroy(slot.ev[s][1]); }
@@ -196,6 +200,47 @@ int KinectFusionReconstruction::ProcessFrame(const DeviceArray2D<ushort> &depth_
     frame_id += frame_step;
     if (profiling) end_profiled_frame();
     return 1;
+}
+
+// Depth ingest (main.cpp:50-58: imread -> upload -> ProcessFrame).  The frame goes through one of two
+// host-pinned staging buffers and an asynchronous copy on the second stream — the stream the map
+// preparation and the depth scaling run on, so they follow the copy with no host wait, and all of it
+// runs under the previous frame's tail.  A caller that decodes straight into IngestBuffer() (or passes
+// any pinned pointer) skips the staging copy.
+ushort *KinectFusionReconstruction::IngestBuffer() {
+    const int slot = ingest_seq_ & 1;
+    const size_t bytes = (size_t)depth_width * depth_height * sizeof(ushort);
+    if (!ingest_pinned_[slot]) {
+        hipSafeCall(hipHostMalloc((void **)&ingest_pinned_[slot], bytes));
+        hipSafeCall(hipEventCreateWithFlags(&ingest_done_[slot], hipEventDisableTiming));
+    } else
+        hipSafeCall(hipEventSynchronize(ingest_done_[slot]));  // the copy out of this slot two frames ago
+    return ingest_pinned_[slot];
+}
+int KinectFusionReconstruction::ProcessFrameHost(const ushort *depth_host) {
+    if (depth_width <= 0 || depth_height <= 0 || !depth_host) return 0;
+    const size_t row = (size_t)depth_width * sizeof(ushort);
+    const ushort *src = depth_host;
+    int slot = -1;
+    if (depth_host == ingest_pinned_[0] || depth_host == ingest_pinned_[1]) slot = depth_host == ingest_pinned_[0] ? 0 : 1;
+    else {
+        hipPointerAttribute_t attr;
+        const bool pinned = hipPointerGetAttributes(&attr, depth_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!pinned) {
+            (void)hipGetLastError();  // a pageable pointer is reported as an error: not one
+            ushort *stage = IngestBuffer();
+            slot = ingest_seq_ & 1;
+            std::memcpy(stage, depth_host, row * depth_height);
+            src = stage;
+        }
+    }
+    depth_ingest_d_.create(depth_height, depth_width);
+    hipSafeCall(hipMemcpy2DAsync(depth_ingest_d_.ptr(), depth_ingest_d_.step(), src, row, row, depth_height, hipMemcpyHostToDevice, aux_stream_));
+    if (slot >= 0) {
+        hipSafeCall(hipEventRecord(ingest_done_[slot], aux_stream_));
+        if (slot == (ingest_seq_ & 1)) ++ingest_seq_;
+    }
+    return ProcessFrame(depth_ingest_d_);
 }
 
 // reference :161-175

@@ -105,6 +105,8 @@ public:
     void ReleaseBuffers();
     void SetYamlParameters(const xs_host::FlatYaml &config_);
     int ProcessFrame(const DeviceArray2D<ushort> &depth_frame_d);
+    int ProcessFrameHost(const ushort *depth_host);  // dense rows of depth_width u16; pinned or pageable
+    ushort *IngestBuffer();                          // next host-pinned staging buffer (decode into it, then ProcessFrameHost(it))
     void SurfaceMeasure(const DeviceArray2D<ushort> &depth_frame_d);
     int PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, Matrix3frm Rprev_inv, Vector3cf tprev);
     int AlignDepthToReconstruction(const DeviceArray2D<ushort> &depth_frame_d, bool use_LM = false);
@@ -135,6 +137,10 @@ private:
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
     DeviceArray<unsigned char> icp_pose_;      // device-resident pose of the ICP loop (xs_icp_iterate)
+    DeviceArray2D<ushort> depth_ingest_d_;     // device copy of a host frame (ProcessFrameHost)
+    ushort *ingest_pinned_[2] = {nullptr, nullptr};
+    hipEvent_t ingest_done_[2] = {nullptr, nullptr};
+    int ingest_seq_ = 0;
     DeviceArray<unsigned char> maps_prev0_block_;  // level-0 model vertex + normal maps, one allocation
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)

@@ -93,12 +93,8 @@ int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) 
     DeviceArray2D<ushort> view(k->depth_height, k->depth_width, (void *)depth_dev, step_bytes);  // borrowed, not counted
     return k->ProcessFrame(view);
 }
-int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host) {
-    KF *k = (KF *)kf;
-    static thread_local DeviceArray2D<ushort> frame;
-    frame.upload(depth_host, k->depth_width * sizeof(ushort), k->depth_height, k->depth_width);
-    return k->ProcessFrame(frame);
-}
+int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host) { return ((KF *)kf)->ProcessFrameHost(depth_host); }
+uint16_t *xs_kf_ingest_buffer(void *kf) { return ((KF *)kf)->IngestBuffer(); }
 void xs_kf_synchronize(void *kf) { ((KF *)kf)->synchronize(); }
 
 int xs_kf_frame_id(void *kf) { return ((KF *)kf)->frame_id; }

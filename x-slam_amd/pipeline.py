@@ -30,6 +30,7 @@ _SIGS = {
     "xs_kf_set_gt_poses": (None, [_vp, C.c_int, _f32p]),
     "xs_kf_process_frame": (C.c_int, [_vp, _vp, _sz]),
     "xs_kf_process_frame_host": (C.c_int, [_vp, _vp]),
+    "xs_kf_ingest_buffer": (_vp, [_vp]),
     "xs_kf_synchronize": (None, [_vp]),
     "xs_kf_frame_id": (C.c_int, [_vp]),
     "xs_kf_num_poses": (C.c_int, [_vp]),
@@ -128,8 +129,16 @@ class KinectFusion:
         return _lib.xs_kf_process_frame(self.h, ptr, step)
 
     def process_frame_host(self, depth_u16):
+        """Host frame [H, W] u16: staged through pinned memory and copied asynchronously on the second stream
+        (an array returned by ingest_buffer() is used in place)."""
         d = np.ascontiguousarray(depth_u16, dtype=np.uint16)
         return _lib.xs_kf_process_frame_host(self.h, d.ctypes.data)
+
+    def ingest_buffer(self):
+        """The next host-pinned staging buffer as a [H, W] uint16 array: fill it, then process_frame_host(it)."""
+        ptr = _lib.xs_kf_ingest_buffer(self.h)
+        n = self.width * self.height
+        return np.ctypeslib.as_array((C.c_uint16 * n).from_address(ptr)).reshape(self.height, self.width)
 
     def synchronize(self):
         _lib.xs_kf_synchronize(self.h)
