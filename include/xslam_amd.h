@@ -146,6 +146,27 @@ int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_keys_dev, fl
 int xs_raycast_compose_finish(const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows, int cols,
                               unsigned long long *hits_dev, void *stream);
 
+/* ---- surface extraction (export; real-valued) ------------------------------------------------ */
+size_t xs_extract_workspace_bytes(const int *res);
+/* size_t extractPoints(value_volume, weight_volume, grad_volume, volume_resolution, voxel_size,
+ * PtrSz<float3> output)                       ExtractPointCloud.h:19-20, ExtractPointCloud.cu:25-211
+ * Zero crossings of the TSDF between axis neighbours (+x, +y, +z; both samples < 0.99, opposite signs),
+ * linearly interpolated, for the voxels of planes [z0, z1), z1 <= res[2] - 1 (whole volume: 0, res[2] - 1).
+ * value points at stored plane zs0 (0 for the whole volume) and holds planes up to z1 inclusive.  The weight
+ * and grad volumes of the reference signature are not read there either.  points_dev: capacity x 3 floats,
+ * filled in a deterministic order (workgroup, z, y, x, direction; the reference's order depends on its
+ * atomics).  *count_host = min(found, capacity), the reference's return value; *found_host (optional) =
+ * found.  workspace: xs_extract_workspace_bytes(res).  Synchronises the stream, as the reference does. */
+int xs_extract_points(const float *value, size_t vol_step, const int *res, float voxel_size, int zs0, int z0, int z1, float *points_dev,
+                      size_t capacity, void *workspace, size_t *count_host, size_t *found_host, void *stream);
+/* void extractNormals(value_volume, weight_volume, grad_volume, volume_resolution, voxel_size,
+ * PtrSz<float3> points, PtrSz<float3> normal)            ExtractPointCloud.h:22-23, .cu:214-362
+ * Central differences of the trilinearly interpolated TSDF one voxel either side of each point, divided by
+ * their squared length as in the reference; (0, 0, 0) within two voxels of the border.  value holds stored
+ * planes [zs0, zs1) (whole volume: 0, res[2]).  No synchronisation. */
+int xs_extract_normals(const float *value, size_t vol_step, const int *res, float voxel_size, int zs0, int zs1, const float *points_dev,
+                       size_t n, float *normals_dev, void *stream);
+
 /* ---- ICP normal equations ----------------------------------------------------------------- */
 size_t xs_icp_workspace_bytes(void);
 /* zero the workspace's arrival ticket once after allocation; every launch leaves it zero */

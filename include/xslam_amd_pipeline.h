@@ -55,6 +55,12 @@ int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host);
  * it and pass it to xs_kf_process_frame_host — no staging copy.  Blocks only if the copy out of that buffer
  * two frames ago has not finished. */
 uint16_t *xs_kf_ingest_buffer(void *kf);
+/* ExportPointCloud(max_buffer)  .cpp:334-372 (+ CPointCloud::exportPly, main.cpp:78-80): zero-crossing points of
+ * the TSDF with normals, at most max_buffer; xyz triples into the host arrays (either may be NULL); returns
+ * the number of points.  A sharded rank exports the planes it owns.  export_ply writes the reference's
+ * ascii format (x y z nx ny nz) and returns the number of points, -1 if the file cannot be opened. */
+long long xs_kf_export_point_cloud(void *kf, int max_buffer, float *points_host, float *normals_host);
+long long xs_kf_export_ply(void *kf, int max_buffer, const char *filename);
 void xs_kf_synchronize(void *kf);
 
 int xs_kf_frame_id(void *kf);

@@ -234,6 +234,14 @@ void ORC(resize_map)(int normalize, int srows, int scols, const float *in, size_
     resize_map<CF>(normalize != 0, srows, scols, in, istep, out, ostep);
 }
 
+long long ORC(extract_points)(const float *value, size_t vstep, const int *res, float voxel_size, int zs0, int z0, int z1, float *out,
+                              long long capacity) {
+    return (long long)extract_points(value, vstep, res[0], res[1], res[2], voxel_size, zs0, z0, z1, out, (size_t)capacity);
+}
+void ORC(extract_normals)(const float *value, size_t vstep, const int *res, float voxel_size, const float *points, long long n, float *normals) {
+    extract_normals(value, vstep, res[0], res[1], res[2], voxel_size, points, (size_t)n, normals);
+}
+
 // sums54: 27 x (re, im) doubles in the reference's gbuf row order; A72/b12 the
 // symmetric unpack of ICP.cu:419-428 (either may be null)
 long long ORC(icp_combined)(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,

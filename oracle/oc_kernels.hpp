@@ -755,4 +755,59 @@ inline void tsdf_loss(const float *depthScaled, size_t dstep, int drows, int dco
     out2[0] = sl; out2[1] = (double)sc;
 }
 
+// ---- ExtractPointCloud.cu:25-185 Scanner (points), :214-341 ExtractNormals -----------------
+// Real-valued export of the zero level set.  Points are appended in (z, y, x, direction) order; the
+// reference's order depends on atomics, so comparisons sort both sides.  Returns the number found;
+// at most `capacity` are stored.
+inline size_t extract_points(const float *value, size_t vstep, int X, int Y, int Z, float voxel_size, int zs0, int z0, int z1, float *out,
+                             size_t capacity) {
+    auto F_ = [&](int x, int y, int z) { return row_ptr(value, vstep, Y * (z - zs0) + y)[x]; };
+    size_t n = 0;
+    auto put = [&](float px, float py, float pz) {
+        if (n < capacity) { out[3 * n] = px; out[3 * n + 1] = py; out[3 * n + 2] = pz; }
+        ++n;
+    };
+    for (int z = z0; z < z1; ++z)
+        for (int y = 0; y < Y - 1; ++y)
+            for (int x = 0; x < X - 1; ++x) {
+                const float F = F_(x, y, z);
+                if (!(F < 0.99f)) continue;
+                const float Vx = (x + 0.5f) * voxel_size, Vy = (y + 0.5f) * voxel_size, Vz = (z + 0.5f) * voxel_size;
+                float Fn = F_(x + 1, y, z);
+                if (Fn < 0.99f && ((F > 0 && Fn < 0) || (F < 0 && Fn > 0))) put(Vx - (F / (Fn - F)) * voxel_size, Vy, Vz);
+                Fn = F_(x, y + 1, z);
+                if (Fn < 0.99f && ((F > 0 && Fn < 0) || (F < 0 && Fn > 0))) put(Vx, Vy - (F / (Fn - F)) * voxel_size, Vz);
+                Fn = F_(x, y, z + 1);
+                if (Fn < 0.99f && ((F > 0 && Fn < 0) || (F < 0 && Fn > 0))) put(Vx, Vy, Vz - (F / (Fn - F)) * voxel_size);
+            }
+    return n;
+}
+inline void extract_normals(const float *value, size_t vstep, int X, int Y, int Z, float vs, const float *points, size_t n, float *normals) {
+    auto rd = [&](int x, int y, int z) { return row_ptr(value, vstep, Y * z + y)[x]; };
+    auto interp = [&](float px, float py, float pz) {
+        int gx = (int)std::floor(px / vs), gy = (int)std::floor(py / vs), gz = (int)std::floor(pz / vs);
+        const float vx = (gx + 0.5f) * vs, vy = (gy + 0.5f) * vs, vz = (gz + 0.5f) * vs;
+        gx = (px < vx) ? (gx - 1) : gx; gy = (py < vy) ? (gy - 1) : gy; gz = (pz < vz) ? (gz - 1) : gz;
+        const float a = (px - (gx + 0.5f) * vs) / vs, b = (py - (gy + 0.5f) * vs) / vs, c = (pz - (gz + 0.5f) * vs) / vs;
+        return rd(gx + 0, gy + 0, gz + 0) * (1 - a) * (1 - b) * (1 - c) + rd(gx + 0, gy + 0, gz + 1) * (1 - a) * (1 - b) * c +
+               rd(gx + 0, gy + 1, gz + 0) * (1 - a) * b * (1 - c) + rd(gx + 0, gy + 1, gz + 1) * (1 - a) * b * c +
+               rd(gx + 1, gy + 0, gz + 0) * a * (1 - b) * (1 - c) + rd(gx + 1, gy + 0, gz + 1) * a * (1 - b) * c +
+               rd(gx + 1, gy + 1, gz + 0) * a * b * (1 - c) + rd(gx + 1, gy + 1, gz + 1) * a * b * c;
+    };
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; ++i) {
+        const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        const int gx = (int)std::floor(px / vs), gy = (int)std::floor(py / vs), gz = (int)std::floor(pz / vs);
+        if (gx > 1 && gy > 1 && gz > 1 && gx < X - 2 && gy < Y - 2 && gz < Z - 2) {
+            nx = interp(px + vs, py, pz) - interp(px - vs, py, pz);
+            ny = interp(px, py + vs, pz) - interp(px, py - vs, pz);
+            nz = interp(px, py, pz + vs) - interp(px, py, pz - vs);
+            const float norm = nx * nx + ny * ny + nz * nz;
+            nx = nx / norm; ny = ny / norm; nz = nz / norm;
+        }
+        normals[3 * i] = nx; normals[3 * i + 1] = ny; normals[3 * i + 2] = nz;
+    }
+}
+
 }  // namespace oc

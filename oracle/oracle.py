@@ -80,6 +80,8 @@ class Oracle:
         self._fn("create_vmap", None, [_f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t])
         self._fn("create_nmap", None, [C.c_int, C.c_int, _f32p, _f32p, C.c_size_t])
         self._fn("resize_map", None, [C.c_int, C.c_int, C.c_int, _f32p, C.c_size_t, _f32p, C.c_size_t])
+        self._fn("extract_points", C.c_longlong, [_f32p, C.c_size_t, _i32p, C.c_float, C.c_int, C.c_int, C.c_int, _f32p, C.c_longlong])
+        self._fn("extract_normals", None, [_f32p, C.c_size_t, _i32p, C.c_float, _f32p, C.c_longlong, _f32p])
         self._fn("icp_combined", C.c_longlong, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t,
                                                  C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _f64p, _f64p, _f64p])
         self._fn("tsdf_hessian", None, [_f32p, C.c_size_t, C.c_int, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p,
@@ -249,6 +251,25 @@ class Oracle:
         srows, scols = m.shape[0] // 3, m.shape[1]
         out = np.zeros((3 * (srows // 2), scols // 2, 2), np.float32)
         self._resize_map(1 if normalize else 0, srows, scols, _p(m, _f32p), scols * 8, _p(out, _f32p), (scols // 2) * 8)
+        return out
+
+    def extract_points(self, value, res, voxel_size, z0=0, z1=None, capacity=None, zs0=0):
+        """ExtractPointCloud.cu extractPoints on a dense value volume [(Z-zs0)*Y, X]: (points [n, 3], found)."""
+        res = self._res(res)
+        X = int(res[0])
+        value = np.ascontiguousarray(value, dtype=np.float32)
+        z1 = int(res[2]) - 1 if z1 is None else z1
+        cap = int(capacity) if capacity is not None else 3 * value.size
+        out = np.zeros((max(cap, 1), 3), np.float32)
+        n = self._extract_points(_p(value, _f32p), X * 4, _p(res, _i32p), voxel_size, zs0, z0, z1, _p(out, _f32p), cap)
+        return out[:min(n, cap)], int(n)
+
+    def extract_normals(self, value, res, voxel_size, points):
+        res = self._res(res)
+        value = np.ascontiguousarray(value, dtype=np.float32)
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        out = np.zeros_like(points)
+        self._extract_normals(_p(value, _f32p), int(res[0]) * 4, _p(res, _i32p), voxel_size, _p(points, _f32p), points.shape[0], _p(out, _f32p))
         return out
 
     def icp_combined(self, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, distThres,

@@ -102,3 +102,23 @@ def test_host_algebra_restatement(oracle):
     # Rinc at small complex angles ~ I + [w]x
     r = oracle.rinc([1e-3, 1e-9], [2e-3, 0], [-1e-3, 0])
     assert abs(r[0, 1, 0] - 1e-3) < 1e-5 and abs(r[2, 1, 0] - 1e-3) < 1e-5 and abs(r[2, 1, 1] - 1e-9) < 1e-11
+
+
+def test_oracle_extract_points_on_a_sphere(oracle):
+    """ExtractPointCloud restatement: crossings of an analytic sphere TSDF lie on the sphere; normals (divided by
+    their squared length, as the reference does) point outwards."""
+    n, vs, R = 40, 0.05, 0.6
+    c = np.array([1.0, 0.95, 1.05])
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    d = np.sqrt(((x + 0.5) * vs - c[0]) ** 2 + ((y + 0.5) * vs - c[1]) ** 2 + ((z + 0.5) * vs - c[2]) ** 2) - R
+    v = np.clip(d / 0.15, -1, 1).astype(np.float32).reshape(n * n, n)
+    pts, found = oracle.extract_points(v, [n, n, n], vs)
+    assert found == len(pts) > 500
+    r = np.linalg.norm(pts - c, axis=1)
+    assert np.all(np.abs(r - R) < 0.1 * vs)
+    nr = oracle.extract_normals(v, [n, n, n], vs, pts)
+    out = (pts - c) / r[:, None]
+    cosang = np.sum(nr * out, axis=1) / np.linalg.norm(nr, axis=1)
+    assert np.all(cosang > 0.97)
+    few, f2 = oracle.extract_points(v, [n, n, n], vs, capacity=10)
+    assert len(few) == 10 and f2 == found and np.array_equal(few, pts[:10])

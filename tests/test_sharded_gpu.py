@@ -80,6 +80,15 @@ def test_sharded_equals_single(dev, world, rows_sharded):
         o, st = shards[0].owned, shards[0].stored
         plane = n * n
         assert np.array_equal(v0[(o[1] - st[0]) * plane:], sv[o[1] * plane: st[1] * plane])
+        # surface export: every rank reports the crossings of the planes it owns; together they are the single-GPU cloud
+        sp, sn = single.export_point_cloud(1000000)
+        parts = [s.export_point_cloud(1000000) for s in shards]
+        allp = np.concatenate([p for p, _ in parts]); alln = np.concatenate([q for _, q in parts])
+        assert len(allp) == len(sp) > 0
+        o1, o2 = np.lexsort((sp[:, 2], sp[:, 1], sp[:, 0])), np.lexsort((allp[:, 2], allp[:, 1], allp[:, 0]))
+        assert np.array_equal(sp[o1], allp[o2])
+        ok = ~np.isnan(sn[o1]) & ~np.isnan(alln[o2])
+        assert np.array_equal(sn[o1][ok], alln[o2][ok])
     # composed previous-frame maps identical on every rank, and to the single-GPU maps when the poses are
     for which in ("vmaps_g_prev", "nmaps_g_prev"):
         m0 = shards[0].map(which, 0)

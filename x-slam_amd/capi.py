@@ -66,6 +66,9 @@ _SIGS = {
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_resize_pyramid": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "xs_extract_workspace_bytes": (_sz, [_i32p]),
+    "xs_extract_points": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp]),
+    "xs_extract_normals": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "xs_icp_workspace_bytes": (_sz, []),
     "xs_icp_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -217,6 +220,28 @@ def create_vnmaps(intrs, depths, depth_steps, rows0, cols0, vmaps, nmaps, map_st
     S = lambda xs: (_sz * n)(*[int(x) for x in xs])
     check(_lib.xs_create_vnmaps(n, k.ctypes.data_as(_f32p), P(depths), S(depth_steps), rows0, cols0, P(vmaps), P(nmaps), S(map_steps),
                                 _stream(stream)))
+
+
+def extract_workspace_bytes(res):
+    r = _ia(res, 3)
+    return _lib.xs_extract_workspace_bytes(r.ctypes.data_as(_i32p))
+
+
+def extract_points(value, vol_step, res, voxel_size, points, capacity, workspace, zs0=0, z0=0, z1=None, stream=None):
+    """extractPoints: fills points[capacity, 3] (CUDA float32); returns (stored, found).  Synchronises."""
+    r = _ia(res, 3)
+    z1 = int(r[2]) - 1 if z1 is None else z1
+    cnt, found = _sz(0), _sz(0)
+    check(_lib.xs_extract_points(_ptr(value), vol_step, r.ctypes.data_as(_i32p), voxel_size, zs0, z0, z1, _ptr(points), capacity,
+                                 _ptr(workspace), C.byref(cnt), C.byref(found), _stream(stream)))
+    return int(cnt.value), int(found.value)
+
+
+def extract_normals(value, vol_step, res, voxel_size, points, n, normals, zs0=0, zs1=None, stream=None):
+    r = _ia(res, 3)
+    zs1 = int(r[2]) if zs1 is None else zs1
+    check(_lib.xs_extract_normals(_ptr(value), vol_step, r.ctypes.data_as(_i32p), voxel_size, zs0, zs1, _ptr(points), n, _ptr(normals),
+                                  _stream(stream)))
 
 
 def resize_pyramid(vmap0, nmap0, in_step, rows0, cols0, vmap1, nmap1, mid_step, vmap2, nmap2, out_step, stream=None):

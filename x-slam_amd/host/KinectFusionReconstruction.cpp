@@ -606,6 +606,45 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     return 0;
 }
 
+// reference :334-372
+KinectFusionReconstruction::CPointCloud KinectFusionReconstruction::ExportPointCloud(int max_buffer) {
+    CPointCloud res;
+    if (max_buffer <= 0 || !tsdf_volume_d_ptr) return res;
+    DeviceArray<float3> cloud_buffer, normal_buffer;
+    cloud_buffer.create(max_buffer);
+    normal_buffer.create(max_buffer);
+    int3 volume_res;
+    volume_res.x = volume_resolution.x();
+    volume_res.y = volume_resolution.y();
+    volume_res.z = volume_resolution.z();
+    // a rank of a sharded run reports the crossings of the planes it owns (the +z neighbour of its last
+    // plane is in its halo); the single-GPU case is the whole volume
+    const int z1 = std::min(zo1, volume_res.z - 1);
+    PtrSz<float3> cloud; cloud.data = cloud_buffer.ptr(); cloud.size = (size_t)max_buffer;
+    const size_t num_points = extractPoints(tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->weight(), tsdf_volume_d_ptr->grad(), volume_res,
+                                            voxel_size, cloud, zs0, zo0, std::max(z1, zo0));
+    if (num_points == 0) return res;
+    cloud.size = num_points;
+    PtrSz<float3> normal; normal.data = normal_buffer.ptr(); normal.size = num_points;
+    extractNormals(tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->weight(), tsdf_volume_d_ptr->grad(), volume_res, voxel_size, cloud, normal,
+                   zs0, zs1);
+    res.positions.resize(3 * num_points);
+    res.normals.resize(3 * num_points);
+    hipSafeCall(hipMemcpy(res.positions.data(), cloud_buffer.ptr(), num_points * sizeof(float3), hipMemcpyDeviceToHost));
+    hipSafeCall(hipMemcpy(res.normals.data(), normal_buffer.ptr(), num_points * sizeof(float3), hipMemcpyDeviceToHost));
+    return res;
+}
+bool KinectFusionReconstruction::CPointCloud::exportPly(const std::string &filename) const {
+    std::ofstream file_out{filename};
+    if (!file_out.is_open()) return false;
+    file_out << "ply\nformat ascii 1.0\ncomment Created by myself\nelement vertex " << size() << "\n";
+    file_out << "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\nend_header\n";
+    for (size_t i = 0; i < size(); ++i)
+        file_out << positions[3 * i] << " " << positions[3 * i + 1] << " " << positions[3 * i + 2] << " " << normals[3 * i] << " "
+                 << normals[3 * i + 1] << " " << normals[3 * i + 2] << "\n";
+    return true;
+}
+
 void KinectFusionReconstruction::synchronize() { hipSafeCall(hipStreamSynchronize(current_stream())); }
 
 long long KinectFusionReconstruction::lastUpdatedVoxels() {

@@ -118,6 +118,15 @@ public:
     static inline Vector3cf GetTranslation(Matrix4cf &trans_mat) { return xs_host::GetTranslation(trans_mat); }
     static inline Matrix3frm GetRotation(Matrix4cf &trans_mat) { return xs_host::GetRotation(trans_mat); }
 
+    // ExportPointCloud (reference :334-372, main.cpp:78-80): zero-crossing points of the TSDF with
+    // normals, at most max_buffer of them; a sharded rank exports the planes it owns.
+    struct CPointCloud {
+        std::vector<float> positions, normals;   // xyz triples
+        size_t size() const { return positions.size() / 3; }
+        bool exportPly(const std::string &filename) const;  // CPointCloud.cpp:42-67: ascii, x y z nx ny nz
+    };
+    CPointCloud ExportPointCloud(int max_buffer);
+
     // volume checkpoint: raw float32 value (+ grad, + int32 weight), X*Y*Z each, dense
     // (the reference's saveTSDFVolume writes value only and res[0]*res[2]*res[2] floats,
     // KinectFusionReconstruction.cpp:438-447)

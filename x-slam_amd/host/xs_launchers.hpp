@@ -187,3 +187,26 @@ inline float2 ComputeLocalTsdf_loss(const PtrStepSz<ushort> &depth, const Intr &
     xs_host::sync();
     return float2{(float)h[0], (float)h[1]};
 }
+
+// --- ExtractPointCloud.h:19-23 (surface export; real-valued) ---------------------------------------
+// extractPoints returns the number of points stored (at most output.size), extractNormals fills one
+// normal per point.  Both return after the stream has drained, as the reference.
+inline size_t extractPoints(const PtrStep<float> &value_volume, const PtrStep<int> & /*weight_volume*/, const PtrStep<float> & /*grad_volume*/,
+                            const int3 &volume_resolution, float voxel_size, PtrSz<float3> output, int zs0 = 0, int z0 = 0, int z1 = -1) {
+    const int res[3] = {volume_resolution.x, volume_resolution.y, volume_resolution.z};
+    static thread_local DeviceArray<unsigned char> ws;
+    if (ws.size() < xs_extract_workspace_bytes(res)) ws.create(xs_extract_workspace_bytes(res));
+    size_t count = 0;
+    xs_host::check_rc(xs_extract_points(value_volume.data, value_volume.step, res, voxel_size, zs0, z0, z1 < 0 ? res[2] - 1 : z1,
+                                        reinterpret_cast<float *>(output.data), output.size, ws.ptr(), &count, nullptr, xs_host::current_stream()),
+                      "extractPoints");
+    return count;
+}
+inline void extractNormals(const PtrStep<float> &value_volume, const PtrStep<int> & /*weight_volume*/, const PtrStep<float> & /*grad_volume*/,
+                           const int3 &volume_resolution, float voxel_size, PtrSz<float3> points, PtrSz<float3> normal, int zs0 = 0, int zs1 = -1) {
+    const int res[3] = {volume_resolution.x, volume_resolution.y, volume_resolution.z};
+    xs_host::check_rc(xs_extract_normals(value_volume.data, value_volume.step, res, voxel_size, zs0, zs1 < 0 ? res[2] : zs1,
+                                         reinterpret_cast<const float *>(points.data), points.size, reinterpret_cast<float *>(normal.data),
+                                         xs_host::current_stream()), "extractNormals");
+    xs_host::sync();
+}

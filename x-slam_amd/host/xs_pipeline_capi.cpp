@@ -95,6 +95,16 @@ int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) 
 }
 int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host) { return ((KF *)kf)->ProcessFrameHost(depth_host); }
 uint16_t *xs_kf_ingest_buffer(void *kf) { return ((KF *)kf)->IngestBuffer(); }
+long long xs_kf_export_point_cloud(void *kf, int max_buffer, float *points_host, float *normals_host) {
+    const auto pc = ((KF *)kf)->ExportPointCloud(max_buffer);
+    if (points_host && pc.size()) std::memcpy(points_host, pc.positions.data(), pc.positions.size() * sizeof(float));
+    if (normals_host && pc.size()) std::memcpy(normals_host, pc.normals.data(), pc.normals.size() * sizeof(float));
+    return (long long)pc.size();
+}
+long long xs_kf_export_ply(void *kf, int max_buffer, const char *filename) {
+    const auto pc = ((KF *)kf)->ExportPointCloud(max_buffer);
+    return pc.exportPly(filename) ? (long long)pc.size() : -1;
+}
 void xs_kf_synchronize(void *kf) { ((KF *)kf)->synchronize(); }
 
 int xs_kf_frame_id(void *kf) { return ((KF *)kf)->frame_id; }

@@ -31,6 +31,8 @@ _SIGS = {
     "xs_kf_process_frame": (C.c_int, [_vp, _vp, _sz]),
     "xs_kf_process_frame_host": (C.c_int, [_vp, _vp]),
     "xs_kf_ingest_buffer": (_vp, [_vp]),
+    "xs_kf_export_point_cloud": (C.c_longlong, [_vp, C.c_int, _f32p, _f32p]),
+    "xs_kf_export_ply": (C.c_longlong, [_vp, C.c_int, C.c_char_p]),
     "xs_kf_synchronize": (None, [_vp]),
     "xs_kf_frame_id": (C.c_int, [_vp]),
     "xs_kf_num_poses": (C.c_int, [_vp]),
@@ -139,6 +141,16 @@ class KinectFusion:
         ptr = _lib.xs_kf_ingest_buffer(self.h)
         n = self.width * self.height
         return np.ctypeslib.as_array((C.c_uint16 * n).from_address(ptr)).reshape(self.height, self.width)
+
+    def export_point_cloud(self, max_buffer=1000000):
+        """ExportPointCloud: (points [n, 3], normals [n, 3]) float32 on the host."""
+        p = np.zeros((max_buffer, 3), np.float32)
+        nr = np.zeros((max_buffer, 3), np.float32)
+        n = _lib.xs_kf_export_point_cloud(self.h, max_buffer, p.ctypes.data_as(_f32p), nr.ctypes.data_as(_f32p))
+        return p[:n], nr[:n]
+
+    def export_ply(self, filename, max_buffer=1000000):
+        return _lib.xs_kf_export_ply(self.h, max_buffer, str(filename).encode())
 
     def synchronize(self):
         _lib.xs_kf_synchronize(self.h)
