@@ -146,6 +146,16 @@ int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_keys_dev, fl
 int xs_raycast_compose_finish(const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows, int cols,
                               unsigned long long *hits_dev, void *stream);
 
+/* First-order CSFD Gauss-Newton terms of ComputeLocalTsdfHessianKernel's residual for six seeded poses in one
+ * pass over the volume (BASELINE config 5; the reference has only the single-direction kernels above).
+ * Rv2c108 / tv2c36: six MatS33 / devComplex3, pose k carrying i*h on degree of freedom k (equal real parts).
+ * out29_dev: sum d_j d_k for j <= k (21, row-major upper triangle), sum d_k r (6), sum r^2, count, with
+ * d_k = Im(error_k) = h * dr/dtheta_k and r = Re(error_0), over voxels with gt != 0, |gt| <= 0.95 that pass the
+ * kernel's gates for all six poses.  Other arguments as xs_compute_local_tsdf_hessian.  No synchronisation. */
+int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
+                               float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0, int z1,
+                               void *workspace, double *out29_dev, void *stream);
+
 /* ---- surface extraction (export; real-valued) ------------------------------------------------ */
 size_t xs_extract_workspace_bytes(const int *res);
 /* size_t extractPoints(value_volume, weight_volume, grad_volume, volume_resolution, voxel_size,

@@ -55,6 +55,17 @@ int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host);
  * it and pass it to xs_kf_process_frame_host — no staging copy.  Blocks only if the copy out of that buffer
  * two frames ago has not finished. */
 uint16_t *xs_kf_ingest_buffer(void *kf);
+/* getCamera2Volume()  .h:137: world2volume * world2camera^-1 of the latest pose, 32 floats */
+void xs_kf_get_camera2volume(void *kf, float *out32);
+/* Pose refinement against the map (BASELINE config 5): Gauss-Newton on the residual of ComputeLocalTsdf_hessian
+ * with the Jacobian from first-order CSFD — six poses seeded with i*1e-7 along the generators of
+ * camera2volume <- se3Exp(xi) * camera2volume, one pass over the volume (xs_tsdf_gauss_newton_terms); a sharded
+ * rank evaluates its slab and the sums are all-reduced.  gauss_newton_terms: out29 = J^T J upper triangle (21),
+ * J^T r (6), sum r^2, count.  relocalize: `iterations` steps of (J^T J + damping * diag) delta = -J^T r from c2v32
+ * (updated in place); loss_out (optional, iterations + 1 doubles): mean squared residual before each step and at
+ * the end.  Both return 1, or 0 when there is nothing to align to. */
+int xs_kf_gauss_newton_terms(void *kf, const uint16_t *depth_dev, size_t step_bytes, const float *c2v32, double *out29);
+int xs_kf_relocalize(void *kf, const uint16_t *depth_dev, size_t step_bytes, float *c2v32, int iterations, float damping, double *loss_out);
 /* ExportPointCloud(max_buffer)  .cpp:334-372 (+ CPointCloud::exportPly, main.cpp:78-80): zero-crossing points of
  * the TSDF with normals, at most max_buffer; xyz triples into the host arrays (either may be NULL); returns
  * the number of points.  A sharded rank exports the planes it owns.  export_ply writes the reference's

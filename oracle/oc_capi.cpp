@@ -234,6 +234,11 @@ void ORC(resize_map)(int normalize, int srows, int scols, const float *in, size_
     resize_map<CF>(normalize != 0, srows, scols, in, istep, out, ostep);
 }
 
+void ORC(tsdf_gn_terms)(const float *depthScaled, size_t dstep, int drows, int dcols, const int *res, float voxel_size, const float *Rv2c108,
+                        const float *tv2c36, float tranc_dist, const float *intr4, const float *gt, int z0, int z1, double *out29) {
+    tsdf_gn_terms<CF>(depthScaled, dstep, drows, dcols, res, voxel_size, Rv2c108, tv2c36, tranc_dist, Intr{intr4[0], intr4[1], intr4[2], intr4[3]},
+                      gt, z0, z1, out29);
+}
 long long ORC(extract_points)(const float *value, size_t vstep, const int *res, float voxel_size, int zs0, int z0, int z1, float *out,
                               long long capacity) {
     return (long long)extract_points(value, vstep, res[0], res[1], res[2], voxel_size, zs0, z0, z1, out, (size_t)capacity);

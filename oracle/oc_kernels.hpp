@@ -701,6 +701,79 @@ void tsdf_hessian(const float *depthScaled, size_t dstep, int drows, int dcols, 
     out4[0] = sl; out4[1] = sg; out4[2] = sh; out4[3] = (double)sc;
 }
 
+// ---- Gauss-Newton terms of the same residual in first-order CSFD (BASELINE config 5) -----------
+// The residual of the kernel above in complex<float> for six poses (pose k seeded with i*h on degree of
+// freedom k): out29 = sum d_j d_k (j <= k, 21), sum d_k r (6), sum r^2, count, with d_k = Im(error_k),
+// r = Re(error_0), over the voxels every seeded evaluation keeps.  gt indexed from plane z0 (slab-relative).
+template <class C>
+bool tsdf_error_c(const float *depthScaled, size_t dstep, int drows, int dcols, float tranc_dist, float tranc_dist_inv, Intr intr,
+                  const mat33<C> &R, const vec3<C> &t, float vgx, float vgy, float vgz, float gt, C &error) {
+    vec3<C> v_g = mk3<C>(C(vgx), C(vgy), C(vgz));
+    vec3<C> v_c = mk3<C>(dot(R.data[0], v_g) + t.x, dot(R.data[1], v_g) + t.y, dot(R.data[2], v_g) + t.z);
+    C inv_z = C(1.0f) / v_c.z;
+    if (inv_z.real() < 0) return false;
+    C image_x = v_c.x * inv_z * intr.fx + intr.cx;
+    C image_y = v_c.y * inv_z * intr.fy + intr.cy;
+    int coo_x = f2i_rd(image_x.real() - 0.5f), coo_y = f2i_rd(image_y.real() - 0.5f);
+    if (!(coo_x > 1 && coo_y > 1 && coo_x < dcols - 1 && coo_y < drows - 1)) return false;
+    int near_x = f2i_rn(image_x.real()), near_y = f2i_rn(image_y.real());
+    C Dp(row_ptr(depthScaled, dstep, near_y)[near_x]);
+    float d00 = row_ptr(depthScaled, dstep, coo_y)[coo_x], d10 = row_ptr(depthScaled, dstep, coo_y)[coo_x + 1];
+    float d01 = row_ptr(depthScaled, dstep, coo_y + 1)[coo_x], d11 = row_ptr(depthScaled, dstep, coo_y + 1)[coo_x + 1];
+    if (d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+        C one(1.0f);
+        C fa = image_x - C(float(coo_x) + 0.5f);
+        C fb = image_y - C(float(coo_y) + 0.5f);
+        Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+    }
+    if (Dp.real() > 5 || Dp.real() < 0.2) return false;
+    C xl = (image_x - intr.cx) / intr.fx;
+    C yl = (image_y - intr.cy) / intr.fy;
+    vec3<C> v_c_1 = mk3<C>(Dp * xl, Dp * yl, Dp);
+    C distance = norm3(v_c_1) - norm3(v_c);
+    C gt_distance = C(gt) * tranc_dist;
+    error = (distance - gt_distance) * tranc_dist_inv;
+    return !(std::fabs(error.real()) > 1);
+}
+template <class C>
+void tsdf_gn_terms(const float *depthScaled, size_t dstep, int drows, int dcols, const int res[3], float voxel_size, const float *Rv2c108,
+                   const float *tv2c36, float tranc_dist, Intr intr, const float *gt, int z0, int z1, double out29[29]) {
+    mat33<C> R[6]; vec3<C> t[6];
+    for (int k = 0; k < 6; ++k) { R[k] = load_mat33<C>(Rv2c108 + 18 * k); t[k] = load_vec3<C>(tv2c36 + 6 * k); }
+    const float tranc_dist_inv = 1.0f / tranc_dist;
+    double acc[29];
+    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+#pragma omp parallel
+    {
+        double loc[29];
+        for (int k = 0; k < 29; ++k) loc[k] = 0.0;
+#pragma omp for schedule(dynamic, 4) nowait
+        for (int y = 0; y < res[1]; ++y)
+            for (int x = 0; x < res[0]; ++x)
+                for (int z = z0; z < z1; ++z) {
+                    const size_t index = (size_t)(z - z0) * res[1] * res[0] + (size_t)y * res[0] + x;
+                    const float g = gt[index];
+                    if (g == 0 || std::fabs(g) > 0.95) continue;
+                    const float vgx = (float(x) + 0.5f) * voxel_size, vgy = (float(y) + 0.5f) * voxel_size, vgz = (float(z) + 0.5f) * voxel_size;
+                    C e[6];
+                    bool ok = true;
+                    for (int k = 0; k < 6; ++k)
+                        ok = ok && tsdf_error_c<C>(depthScaled, dstep, drows, dcols, tranc_dist, tranc_dist_inv, intr, R[k], t[k], vgx, vgy, vgz, g, e[k]);
+                    if (!ok) continue;
+                    const double r = (double)e[0].real();
+                    int s = 0;
+                    for (int j = 0; j < 6; ++j)
+                        for (int k = j; k < 6; ++k) loc[s++] += (double)e[j].imag() * (double)e[k].imag();
+                    for (int k = 0; k < 6; ++k) loc[21 + k] += (double)e[k].imag() * r;
+                    loc[27] += r * r;
+                    loc[28] += 1.0;
+                }
+#pragma omp critical
+        for (int k = 0; k < 29; ++k) acc[k] += loc[k];
+    }
+    for (int k = 0; k < 29; ++k) out29[k] = acc[k];
+}
+
 // ---- TsdfFusion.cu:335-410 ComputeLocalTsdfLossKernel + :412-447 ----------
 inline void tsdf_loss(const float *depthScaled, size_t dstep, int drows, int dcols, const int res[3], float voxel_size,
                       const float *Rv2c9, const float *tv2c3, float tranc_dist, Intr intr, const float *gt,

@@ -80,6 +80,8 @@ class Oracle:
         self._fn("create_vmap", None, [_f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, C.c_size_t])
         self._fn("create_nmap", None, [C.c_int, C.c_int, _f32p, _f32p, C.c_size_t])
         self._fn("resize_map", None, [C.c_int, C.c_int, C.c_int, _f32p, C.c_size_t, _f32p, C.c_size_t])
+        self._fn("tsdf_gn_terms", None, [_f32p, C.c_size_t, C.c_int, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p,
+                                         C.c_int, C.c_int, _f64p])
         self._fn("extract_points", C.c_longlong, [_f32p, C.c_size_t, _i32p, C.c_float, C.c_int, C.c_int, C.c_int, _f32p, C.c_longlong])
         self._fn("extract_normals", None, [_f32p, C.c_size_t, _i32p, C.c_float, _f32p, C.c_longlong, _f32p])
         self._fn("icp_combined", C.c_longlong, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t,
@@ -251,6 +253,20 @@ class Oracle:
         srows, scols = m.shape[0] // 3, m.shape[1]
         out = np.zeros((3 * (srows // 2), scols // 2, 2), np.float32)
         self._resize_map(1 if normalize else 0, srows, scols, _p(m, _f32p), scols * 8, _p(out, _f32p), (scols // 2) * 8)
+        return out
+
+    def tsdf_gn_terms(self, depth_scaled, res, voxel_size, Rv2c6, tv2c6, tranc_dist, intr, gt, z0=0, z1=None):
+        """29 Gauss-Newton sums for six seeded complex poses (Rv2c6: [6, 3, 3, 2], tv2c6: [6, 3, 2]); gt holds planes [z0, z1)."""
+        res = self._res(res)
+        ds = np.ascontiguousarray(depth_scaled, dtype=np.float32)
+        R = np.ascontiguousarray(Rv2c6, dtype=np.float32).reshape(108)
+        t = np.ascontiguousarray(tv2c6, dtype=np.float32).reshape(36)
+        k = np.ascontiguousarray(intr, dtype=np.float32).reshape(4)
+        gt = np.ascontiguousarray(gt, dtype=np.float32)
+        z1 = int(res[2]) if z1 is None else z1
+        out = np.zeros(29, np.float64)
+        self._tsdf_gn_terms(_p(ds, _f32p), ds.shape[1] * 4, ds.shape[0], ds.shape[1], _p(res, _i32p), voxel_size, _p(R, _f32p), _p(t, _f32p),
+                            tranc_dist, _p(k, _f32p), _p(gt, _f32p), z0, z1, _p(out, _f64p))
         return out
 
     def extract_points(self, value, res, voxel_size, z0=0, z1=None, capacity=None, zs0=0):

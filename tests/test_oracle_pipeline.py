@@ -122,3 +122,47 @@ def test_oracle_extract_points_on_a_sphere(oracle):
     assert np.all(cosang > 0.97)
     few, f2 = oracle.extract_points(v, [n, n, n], vs, capacity=10)
     assert len(few) == 10 and f2 == found and np.array_equal(few, pts[:10])
+
+
+def test_oracle_gn_terms_agree_with_dual_complex_hessian(oracle):
+    """First-order CSFD Gauss-Newton sums (six complex poses, one pass) against the dual-complex Hessian kernel
+    seeded along the same generator: same voxel count, same sum of squared residuals, gradient 2*sum(d_k r)/h."""
+    from helpers import intr_of, s1_transforms, synth, tranc_dist
+    n = 48
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    v, w, g = oracle.new_volume(res)
+    for k in (0, 1):
+        T = s1_transforms(k, prm)
+        oracle.integrate(oracle.scale_depth(synth.s1_frame(k)), v, w, g, res, tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm),
+                         prm["tsdf_voxel_size"])
+    T2 = s1_transforms(2, prm)
+    v2c = np.eye(4); v2c[:3, :3] = np.asarray(T2["Rv2c"])[..., 0]; v2c[:3, 3] = np.asarray(T2["tv2c"])[..., 0]
+    h1, h2 = np.float32(1e-7), np.float32(1e-6)
+    Rs = np.zeros((6, 3, 3, 2), np.float32); ts = np.zeros((6, 3, 2), np.float32)
+    D = []
+    for k in range(6):
+        G = np.zeros((4, 4))
+        if k < 3:
+            G[k, 3] = 1
+        else:
+            wv = np.zeros(3); wv[k - 3] = 1
+            G[:3, :3] = np.array([[0, -wv[2], wv[1]], [wv[2], 0, -wv[0]], [-wv[1], wv[0], 0]])
+        d = -v2c @ G
+        D.append(d)
+        Rs[k, :, :, 0] = v2c[:3, :3]; Rs[k, :, :, 1] = h1 * d[:3, :3]
+        ts[k, :, 0] = v2c[:3, 3]; ts[k, :, 1] = h1 * d[:3, 3]
+    ds = oracle.scale_depth(synth.s1_frame(2))
+    gn = oracle.tsdf_gn_terms(ds, res, prm["tsdf_voxel_size"], Rs, ts, tranc_dist(prm), intr_of(prm), v)
+    assert gn[28] > 300
+    for k in (1, 3, 5):
+        Rd = np.zeros((3, 3, 4), np.float32); td = np.zeros((3, 4), np.float32)
+        Rd[..., 0] = v2c[:3, :3]; Rd[..., 1] = h2 * D[k][:3, :3]; Rd[..., 2] = h2 * D[k][:3, :3]
+        td[..., 0] = v2c[:3, 3]; td[..., 1] = h2 * D[k][:3, 3]; td[..., 2] = h2 * D[k][:3, 3]
+        out4 = oracle.tsdf_hessian(ds, res, prm["tsdf_voxel_size"], Rd, td, tranc_dist(prm), intr_of(prm), v)
+        out4 = out4[0] if isinstance(out4, tuple) else out4
+        assert out4[3] == gn[28]
+        assert abs(out4[0] - gn[27]) <= 1e-5 * gn[27]
+        grad = 2.0 * gn[21 + k] / float(h1)
+        # the dual-complex kernel reports the raw first-derivative part: h2 * dL/dtheta
+        assert abs(out4[1] / float(h2) - grad) <= 1e-4 * max(abs(grad), 1e-2 * np.abs(gn[21:27]).max() * 2 / float(h1))

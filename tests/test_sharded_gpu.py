@@ -80,6 +80,17 @@ def test_sharded_equals_single(dev, world, rows_sharded):
         o, st = shards[0].owned, shards[0].stored
         plane = n * n
         assert np.array_equal(v0[(o[1] - st[0]) * plane:], sv[o[1] * plane: st[1] * plane])
+        # Gauss-Newton terms of the last frame against the map: every rank's slab, all-reduced, equals the single-GPU sums
+        d_last = torch.from_numpy(synth.s1_frame(frames[-1]).view(np.int16)).cuda()
+        want = single.gauss_newton_terms(d_last, single.camera2volume())
+        gots = [None] * world
+        def gn(r):
+            gots[r] = shards[r].gauss_newton_terms(d_last, shards[r].camera2volume())
+        th = [threading.Thread(target=gn, args=(r,)) for r in range(world)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert want is not None and want[28] > 100
+        for r in range(world):
+            assert gots[r][28] == want[28] and np.allclose(gots[r][:28], want[:28], rtol=1e-9, atol=1e-12 * np.abs(want[:28]).max())
         # surface export: every rank reports the crossings of the planes it owns; together they are the single-GPU cloud
         sp, sn = single.export_point_cloud(1000000)
         parts = [s.export_point_cloud(1000000) for s in shards]

@@ -66,6 +66,8 @@ _SIGS = {
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_resize_pyramid": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "xs_tsdf_gauss_newton_terms": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, C.c_int,
+                                             C.c_int, _vp, _vp, _vp]),
     "xs_extract_workspace_bytes": (_sz, [_i32p]),
     "xs_extract_points": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp]),
     "xs_extract_normals": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
@@ -220,6 +222,16 @@ def create_vnmaps(intrs, depths, depth_steps, rows0, cols0, vmaps, nmaps, map_st
     S = lambda xs: (_sz * n)(*[int(x) for x in xs])
     check(_lib.xs_create_vnmaps(n, k.ctypes.data_as(_f32p), P(depths), S(depth_steps), rows0, cols0, P(vmaps), P(nmaps), S(map_steps),
                                 _stream(stream)))
+
+
+def tsdf_gauss_newton_terms(depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c6, tv2c6, tranc_dist, gt, workspace, out29,
+                            z0=0, z1=None, stream=None):
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c6, 108), _fa(tv2c6, 36)
+    z1 = int(r[2]) if z1 is None else z1
+    check(_lib.xs_tsdf_gauss_newton_terms(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p),
+                                          voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist, _ptr(gt), z0, z1,
+                                          _ptr(workspace), _ptr(out29), _stream(stream)))
 
 
 def extract_workspace_bytes(res):

@@ -580,12 +580,15 @@ struct HessArgs {
     unsigned *ticket;
     double *out;          // hessian: {loss, grad, hessian, count}; loss: {loss, count}
     float *real_out, *grad_out, *hess_out; int *count_out;  // optional per-voxel volumes (same indexing as gt)
+    int vec;              // columns per lane (host side: picks the kernel instance)
+    int tiles_x, tiles_y, tiles_z;  // (64*vec x 4 x zchunk) tiles; workgroups stride over them
 };
 struct HessPoseD { MatD33 R; dcfloat3 t; };
 struct HessPoseF { float R[9]; float t[3]; };
 
 template <int NV>
 __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *partials, unsigned *ticket, double *out) {
+    constexpr int STRIDE = NV <= 8 ? 8 : 32;  // doubles per workgroup record
     __shared__ double sm[4][NV];
     __shared__ unsigned s_last;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -600,7 +603,7 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
     __syncthreads();
     if (tid < NV) {
         const double s = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
-        __hip_atomic_store(&partials[(size_t)bid * 8 + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[(size_t)bid * STRIDE + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -614,32 +617,88 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
     }
     __syncthreads();
     if (s_last) {
-        // 64 lanes stride over the records, then a wave fold: fixed association, deterministic
-        if (wave == 0) {
+        // After the acquire + barrier plain loads see every record.  All 256 threads take part: thread (g, c)
+        // adds column c of records g, g + G, g + 2G, ... in that order with 16 loads in flight, and the G row
+        // groups are then added in group order — fixed association, deterministic.  (One wave reading the
+        // records one dependent load at a time took longer than the rest of the kernel.)
+        constexpr int G = 256 / STRIDE;
+        __shared__ double s_red[G][STRIDE];
+        const int c = tid % STRIDE, g = tid / STRIDE;
+        const double *p = partials + c;
+        double s = 0.0;
+        unsigned b = g;
+        for (; b + G * 15 < nblocks; b += G * 16) {
+            double v[16];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                double s = 0.0;
-                for (unsigned b = lane; b < nblocks; b += 64)
-                    s += __hip_atomic_load(&partials[(size_t)b * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s = wave_sum_f64(s);
-                if (lane == 0) out[k] = s;
-            }
+            for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(b + G * k) * STRIDE];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += v[k];
+        }
+        for (; b < nblocks; b += G) s += p[(size_t)b * STRIDE];
+        s_red[g][c] = s;
+        __syncthreads();
+        if (tid < NV) {
+            double t = s_red[0][tid];
+#pragma unroll
+            for (int gg = 1; gg < G; ++gg) t += s_red[gg][tid];
+            out[tid] = t;
         }
     }
 }
 
+// The dense ground-truth read is the kernels' only N^3 traffic, and a plain z loop keeps one 4-byte load
+// per lane in flight (measured: 0.85 TB/s for the Hessian kernel at 512^3).  Here a lane requests sixteen
+// planes at once, keeps a bit per plane whose voxel is in the band (gt != 0, |gt| <= 0.95: a few per
+// column), and then visits its band voxels one after the other — the k-th band voxel of every lane of the
+// wave together, whatever their z, so the expensive body runs with full lanes instead of once per plane any
+// lane needs.  Each lane still meets its voxels in ascending z: the per-lane double sums are unchanged.
+template <int VEC, class F>
+__device__ __forceinline__ void for_band_voxels(const HessArgs &a, int x, int y, int zb, int ze, F &&body) {
+    // VEC = 4: the lane owns four consecutive x and reads them as one 16-byte load (a wave-instruction moves
+    // 1 KiB instead of 256 B: the one-dword form streams at 2.3 TB/s); VEC = 1 for volumes whose X is not a
+    // multiple of four or whose base is not 16-byte aligned.
+    constexpr int ZB = 16;
+    const size_t plane = (size_t)a.Y * a.X;
+    const size_t first = (size_t)(zb - a.z0) * plane + (size_t)y * a.X + x;
+    for (int zc = zb; zc < ze; zc += ZB) {
+        const float *col = a.gt + first + (size_t)(zc - zb) * plane;
+        unsigned long long mask = 0;
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) {
+            float g[VEC];
+            if (VEC == 4) {
+                const float4 v = (zc + j < ze) ? *reinterpret_cast<const float4 *>(col + (size_t)j * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g[0] = v.x; g[1 % VEC] = v.y; g[2 % VEC] = v.z; g[3 % VEC] = v.w;
+            } else
+                g[0] = (zc + j < ze) ? col[(size_t)j * plane] : 0.f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+                if (!(g[q] == 0 || fabsf(g[q]) > 0.95)) mask |= 1ull << (j * VEC + q);
+        }
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int j = b / VEC, q = b % VEC;
+            const size_t index = first + (size_t)(zc - zb + j) * plane + q;
+            body(x + q, zc + j, index, a.gt[index]);  // (re-read: a cache hit, instead of 16 x VEC live registers)
+        }
+    }
+}
+
+template <int VEC>
 __global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const HessPoseD P) {
-    const int x = threadIdx.x + blockIdx.x * 64;
-    const int y = threadIdx.y + blockIdx.y * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // a bounded number of workgroups (each pays an L2 write-back and a ticket when it retires) stride over the tiles
+    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int x = (threadIdx.x + (tile % a.tiles_x) * 64) * VEC;
+    const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
     if (x < a.X && y < a.Y) {
-        const int zb = a.z0 + blockIdx.z * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        const dcfloat vgx((float(x) + 0.5f) * a.voxel_size), vgy((float(y) + 0.5f) * a.voxel_size);
-        for (int z = zb; z < ze; ++z) {
-            const size_t index = (size_t)(z - a.z0) * a.Y * a.X + (size_t)y * a.X + x;
-            const float gt = a.gt[index];
-            if (gt == 0 || fabsf(gt) > 0.95) continue;
+        const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
+        const dcfloat vgy((float(y) + 0.5f) * a.voxel_size);
+        for_band_voxels<VEC>(a, x, y, zb, ze, [&](int xq, int z, size_t index, float gt) {
             const dcfloat gt_tsdf(gt);
+            const dcfloat vgx((float(xq) + 0.5f) * a.voxel_size);
             const dcfloat vgz((float(z) + 0.5f) * a.voxel_size);
             dcfloat3 v_g; v_g.x = vgx; v_g.y = vgy; v_g.z = vgz;
             dcfloat3 v_c;
@@ -647,11 +706,11 @@ __global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const He
             v_c.y = dot(P.R.data[1], v_g) + P.t.y;
             v_c.z = dot(P.R.data[2], v_g) + P.t.z;
             const dcfloat inv_z = dcfloat(1.0f) / v_c.z;
-            if (inv_z.value() < 0) continue;
+            if (inv_z.value() < 0) return;
             const dcfloat image_x = v_c.x * inv_z * a.intr.fx + a.intr.cx;
             const dcfloat image_y = v_c.y * inv_z * a.intr.fy + a.intr.cy;
             const int coo_x = __float2int_rd(image_x.value() - 0.5f), coo_y = __float2int_rd(image_y.value() - 0.5f);
-            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
+            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return;
             const int near_x = __float2int_rn(image_x.value()), near_y = __float2int_rn(image_y.value());
             dcfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x]);
             const dcfloat d00(row_ptr(a.depth, a.dstep, coo_y)[coo_x]), d10(row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1]);
@@ -662,46 +721,48 @@ __global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const He
                 const dcfloat fb = image_y - dcfloat(float(coo_y) + 0.5f);
                 Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
             }
-            if (Dp.value() > 5 || Dp.value() < 0.2) continue;
+            if (Dp.value() > 5 || Dp.value() < 0.2) return;
             const dcfloat xl = (image_x - a.intr.cx) / a.intr.fx;
             const dcfloat yl = (image_y - a.intr.cy) / a.intr.fy;
             dcfloat3 v_c_1; v_c_1.x = Dp * xl; v_c_1.y = Dp * yl; v_c_1.z = Dp;
             const dcfloat distance = norm(v_c_1) - norm(v_c);
             const dcfloat gt_distance = gt_tsdf * a.tranc_dist;
             const dcfloat error = (distance - gt_distance) * a.tranc_dist_inv;
-            if (fabsf(error.value()) > 1) continue;
+            if (fabsf(error.value()) > 1) return;
             const dcfloat loss = error * error;
             if (a.real_out) {
                 a.real_out[index] = loss.value(); a.grad_out[index] = loss.grad();
                 a.hess_out[index] = loss.hessian(); a.count_out[index] = 1;
             }
             acc[0] += loss.value(); acc[1] += loss.grad(); acc[2] += loss.hessian(); acc[3] += 1.0;
-        }
+        });
+    }
     }
     block_fold_and_finish<4>(acc, a.partials, a.ticket, a.out);
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(256) k_tsdf_loss(const HessArgs a, const HessPoseF P) {
-    const int x = threadIdx.x + blockIdx.x * 64;
-    const int y = threadIdx.y + blockIdx.y * 4;
     double acc[2] = {0.0, 0.0};
+    // a bounded number of workgroups (each pays an L2 write-back and a ticket when it retires) stride over the tiles
+    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int x = (threadIdx.x + (tile % a.tiles_x) * 64) * VEC;
+    const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
     if (x < a.X && y < a.Y) {
-        const int zb = a.z0 + blockIdx.z * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        const float vgx = (float(x) + 0.5f) * a.voxel_size, vgy = (float(y) + 0.5f) * a.voxel_size;
-        for (int z = zb; z < ze; ++z) {
-            const size_t index = (size_t)(z - a.z0) * a.Y * a.X + (size_t)y * a.X + x;
-            const float gt_tsdf = a.gt[index];
-            if (gt_tsdf == 0 || fabsf(gt_tsdf) > 0.95) continue;
-            const float vgz = (float(z) + 0.5f) * a.voxel_size;
+        const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
+        const float vgy = (float(y) + 0.5f) * a.voxel_size;
+        for_band_voxels<VEC>(a, x, y, zb, ze, [&](int xq, int z, size_t index, float gt_tsdf) {
+            const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
             const float vcx = (P.R[0] * vgx + P.R[1] * vgy + P.R[2] * vgz) + P.t[0];
             const float vcy = (P.R[3] * vgx + P.R[4] * vgy + P.R[5] * vgz) + P.t[1];
             const float vcz = (P.R[6] * vgx + P.R[7] * vgy + P.R[8] * vgz) + P.t[2];
             const float inv_z = 1.0f / vcz;
-            if (inv_z < 0) continue;
+            if (inv_z < 0) return;
             const float image_x = vcx * inv_z * a.intr.fx + a.intr.cx;
             const float image_y = vcy * inv_z * a.intr.fy + a.intr.cy;
             const int coo_x = __float2int_rd(image_x - 0.5f), coo_y = __float2int_rd(image_y - 0.5f);
-            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) continue;
+            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return;
             const int near_x = __float2int_rn(image_x), near_y = __float2int_rn(image_y);
             float Dp = row_ptr(a.depth, a.dstep, near_y)[near_x];
             const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x], d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
@@ -711,23 +772,103 @@ __global__ void __launch_bounds__(256) k_tsdf_loss(const HessArgs a, const HessP
                 const float fa = image_x - (float(coo_x) + 0.5f), fb = image_y - (float(coo_y) + 0.5f);
                 Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
             }
-            if (Dp > 5 || Dp < 0.2) continue;
+            if (Dp > 5 || Dp < 0.2) return;
             const float xl = (image_x - a.intr.cx) / a.intr.fx, yl = (image_y - a.intr.cy) / a.intr.fy;
             const float v1x = Dp * xl, v1y = Dp * yl, v1z = Dp;
             const float distance = sqrtf(v1x * v1x + v1y * v1y + v1z * v1z) - sqrtf(vcx * vcx + vcy * vcy + vcz * vcz);
             const float gt_distance = gt_tsdf * a.tranc_dist;
             const float error = (distance - gt_distance) * a.tranc_dist_inv;
-            if (fabsf(error) > 1) continue;
+            if (fabsf(error) > 1) return;
             const float loss = error * error;
             if (a.real_out) { a.real_out[index] = loss; a.count_out[index] = 1; }
             acc[0] += loss; acc[1] += 1.0;
-        }
+        });
+    }
     }
     block_fold_and_finish<2>(acc, a.partials, a.ticket, a.out);
 }
 
-enum { XS_TSDF_REDUCE_MAX_BLOCKS = 65536 };
-extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_REDUCE_MAX_BLOCKS * 8 * sizeof(double) + 256; }
+// ---- first-order CSFD Gauss-Newton terms of the same residual (BASELINE config 5) ----------------
+// The residual of ComputeLocalTsdfHessianKernel (TsdfFusion.cu:204-283) evaluated in complex<float>
+// for six poses at once — the pose seeded with i*h along each of its six degrees of freedom — so one
+// pass over the volume yields, per voxel, the residual r = Re(error) and the six derivative parts
+// d_k = Im(error_k) = h * dr/dtheta_k, and on chip the sums a Gauss-Newton step needs:
+//   out[0..20]  sum d_j d_k (upper triangle, rows j <= k),  out[21..26]  sum d_k r,
+//   out[27]     sum r^2,                                    out[28]      voxel count
+// (the caller divides by h^2 / h).  The reference has no such kernel; its commented ComputeTSDF_hessian
+// (KinectFusionReconstruction.cpp:404-434) takes one seeded direction per call and would need 6 passes
+// and 6 N^3 scratch volumes for the same matrix.
+struct GnPoses { MatS33 R[6]; cfloat3 t[6]; };
+__device__ __forceinline__ bool tsdf_error_c(const HessArgs &a, const MatS33 &R, const cfloat3 &t, float vgx, float vgy, float vgz, float gt,
+                                             cfloat &error) {
+    cfloat3 v_g; v_g.x = cfloat(vgx); v_g.y = cfloat(vgy); v_g.z = cfloat(vgz);
+    cfloat3 v_c;
+    v_c.x = dot(R.data[0], v_g) + t.x;
+    v_c.y = dot(R.data[1], v_g) + t.y;
+    v_c.z = dot(R.data[2], v_g) + t.z;
+    const cfloat inv_z = cfloat(1.0f) / v_c.z;
+    if (inv_z.re < 0) return false;
+    const cfloat image_x = v_c.x * inv_z * a.intr.fx + a.intr.cx;
+    const cfloat image_y = v_c.y * inv_z * a.intr.fy + a.intr.cy;
+    const int coo_x = __float2int_rd(image_x.re - 0.5f), coo_y = __float2int_rd(image_y.re - 0.5f);
+    if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return false;
+    const int near_x = __float2int_rn(image_x.re), near_y = __float2int_rn(image_y.re);
+    cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x]);
+    const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x], d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
+    const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x], d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+    if (d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+        const cfloat one(1.0f);
+        const cfloat fa = image_x - cfloat(float(coo_x) + 0.5f);
+        const cfloat fb = image_y - cfloat(float(coo_y) + 0.5f);
+        Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+    }
+    if (Dp.re > 5 || Dp.re < 0.2) return false;
+    const cfloat xl = (image_x - a.intr.cx) / a.intr.fx;
+    const cfloat yl = (image_y - a.intr.cy) / a.intr.fy;
+    const cfloat3 v_c_1 = mk3(Dp * xl, Dp * yl, Dp);
+    const cfloat distance = norm(v_c_1) - norm(v_c);
+    const cfloat gt_distance = cfloat(gt) * a.tranc_dist;
+    error = (distance - gt_distance) * a.tranc_dist_inv;
+    return !(fabsf(error.re) > 1);
+}
+template <int VEC>
+__global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, const GnPoses P) {
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+    // a bounded number of workgroups (each pays an L2 write-back and a ticket when it retires) stride over the tiles
+    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int x = (threadIdx.x + (tile % a.tiles_x) * 64) * VEC;
+    const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
+    if (x < a.X && y < a.Y) {
+        const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
+        const float vgy = (float(y) + 0.5f) * a.voxel_size;
+        for_band_voxels<VEC>(a, x, y, zb, ze, [&](int xq, int z, size_t index, float gt) {
+            const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
+            cfloat e[6];
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ok = ok && tsdf_error_c(a, P.R[k], P.t[k], vgx, vgy, vgz, gt, e[k]);
+            if (!ok) return;  // a voxel counts only if every seeded evaluation keeps it (they share their real parts)
+            const double r = (double)e[0].re;
+            int s = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int k = j; k < 6; ++k) acc[s++] += (double)e[j].im * (double)e[k].im;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[21 + k] += (double)e[k].im * r;
+            acc[27] += r * r;
+            acc[28] += 1.0;
+        });
+    }
+    }
+    block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out);
+}
+
+enum { XS_TSDF_REDUCE_MAX_BLOCKS = 1024 };  // workgroups per launch (they stride over the tiles); records of up to 32 doubles
+extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_REDUCE_MAX_BLOCKS * 32 * sizeof(double) + 256; }
 
 static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
                        float voxel_size, float tranc_dist, const float *gt, int z0, int z1, void *workspace, double *out_dev, dim3 &grid,
@@ -739,10 +880,17 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     a.voxel_size = voxel_size; a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist;
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.gt = gt; a.ticket = (unsigned *)workspace; a.partials = (double *)((char *)workspace + 256); a.out = out_dev;
-    int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
-    while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
+    // One column per lane.  (Four columns per lane with 16-byte reads streamed no faster and made the Hessian
+    // kernel slower: four times the band voxels per lane, worse balance.)  Tiles of 64 x 4 columns x zchunk
+    // planes; at most 1024 workgroups stride over them — with 4096 workgroups the per-workgroup L2 write-back
+    // of the release fence halved the streaming rate (2.3 instead of 4.6 TB/s at 512^3).
+    a.vec = 1;
+    int gx = div_up(a.X, 64 * a.vec), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
+    while ((long long)gx * gy * zsplit < 1024 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
     a.zchunk = div_up(nz, zsplit);
-    grid = dim3(gx, gy, div_up(nz, a.zchunk));
+    a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = div_up(nz, a.zchunk);
+    const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.tiles_z;
+    grid = dim3((unsigned)(ntiles < 1024 ? ntiles : 1024));
     if ((long long)grid.x * grid.y * grid.z > XS_TSDF_REDUCE_MAX_BLOCKS) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: volume too large for the reduce workspace");
     XS_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
     return 0;
@@ -778,7 +926,8 @@ extern "C" int xs_compute_local_tsdf_hessian(const float *depth_scaled, size_t s
     P.t.x = dcfloat(tv2c12[0], tv2c12[1], tv2c12[2], tv2c12[3]);
     P.t.y = dcfloat(tv2c12[4], tv2c12[5], tv2c12[6], tv2c12[7]);
     P.t.z = dcfloat(tv2c12[8], tv2c12[9], tv2c12[10], tv2c12[11]);
-    hipLaunchKernelGGL(k_tsdf_hessian, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    if (a.vec == 4) hipLaunchKernelGGL(k_tsdf_hessian<4>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    else hipLaunchKernelGGL(k_tsdf_hessian<1>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -799,7 +948,30 @@ extern "C" int xs_compute_local_tsdf_loss(const float *depth_scaled, size_t scal
     HessPoseF P;
     for (int i = 0; i < 9; ++i) P.R[i] = Rv2c9[i];
     for (int i = 0; i < 3; ++i) P.t[i] = tv2c3[i];
-    hipLaunchKernelGGL(k_tsdf_loss, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    if (a.vec == 4) hipLaunchKernelGGL(k_tsdf_loss<4>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    else hipLaunchKernelGGL(k_tsdf_loss<1>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* First-order CSFD Gauss-Newton terms of the Hessian kernel's residual for six seeded poses in one pass
+ * (BASELINE config 5; no counterpart launcher in the reference).  Rv2c108 / tv2c36: six MatS33 / devComplex3
+ * (pose k carries i*h on degree of freedom k; real parts equal).  out29_dev: 29 doubles — sum d_j d_k for
+ * j <= k (21, row-major upper triangle), sum d_k r (6), sum r^2, count — with d_k = Im(error_k), r =
+ * Re(error_0); voxels are those with gt != 0, |gt| <= 0.95 that pass the kernel's gates for all six poses.
+ * gt / depth_scaled / slab arguments as xs_compute_local_tsdf_hessian.  No synchronisation. */
+extern "C" int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
+                                          float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0,
+                                          int z1, void *workspace, double *out29_dev, void *stream) {
+    HessArgs a; dim3 grid;
+    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out29_dev, grid, stream);
+    if (rc) return rc;
+    if (!Rv2c108 || !tv2c36) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_gauss_newton_terms: null pose");
+    a.real_out = nullptr; a.grad_out = nullptr; a.hess_out = nullptr; a.count_out = nullptr;
+    GnPoses P;
+    for (int k = 0; k < 6; ++k) { load_mat(Rv2c108 + 18 * k, P.R[k]); load_vec(tv2c36 + 6 * k, P.t[k]); }
+    if (a.vec == 4) hipLaunchKernelGGL(k_tsdf_gauss_newton<4>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    else hipLaunchKernelGGL(k_tsdf_gauss_newton<1>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
     XS_CHECK(hipGetLastError());
     return 0;
 }

@@ -606,6 +606,74 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     return 0;
 }
 
+// BASELINE config 5 (see the header): one pass of xs_tsdf_gauss_newton_terms for the six seeded poses
+int KinectFusionReconstruction::GaussNewtonTerms(const DeviceArray2D<ushort> &depth_frame_d, const Matrix4cf &camera2volume, double out29[29]) {
+    if (!tsdf_volume_d_ptr) return 0;
+    DeviceArray2D<float> value = tsdf_volume_d_ptr->value();
+    hipStream_t st = current_stream();
+    depthRawScaled_d.create(depth_frame_d.rows(), depth_frame_d.cols());
+    check_rc(xs_scale_depth(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                            depthRawScaled_d.step(), st), "scaleDepth");
+    float R[6][18], t[6][6];
+    for (int k = 0; k < 6; ++k) {
+        hostComplex xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = hostComplex(0.f, i == k ? (float)H_ : 0.f);
+        const Matrix4cf v2c = inverse(se3Exp(xi) * camera2volume);
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) { R[k][(i * 3 + j) * 2] = v2c.m[i][j].real(); R[k][(i * 3 + j) * 2 + 1] = v2c.m[i][j].imag(); }
+            t[k][2 * i] = v2c.m[i][3].real(); t[k][2 * i + 1] = v2c.m[i][3].imag();
+        }
+    }
+    if (gn_sums_.size() < 32) gn_sums_.create(32);
+    if (gn_ws_.size() < xs_tsdf_reduce_workspace_bytes()) gn_ws_.create(xs_tsdf_reduce_workspace_bytes());
+    const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
+    // this rank's owned planes, as the dense array the kernel indexes (a pitched volume is packed first)
+    const size_t row_bytes = (size_t)res[0] * sizeof(float), plane_rows = (size_t)res[1];
+    const float *gt = reinterpret_cast<const float *>(reinterpret_cast<const char *>(value.ptr()) + (size_t)(zo0 - zs0) * plane_rows * value.step());
+    if (value.step() != row_bytes) {
+        const size_t rows = (size_t)(zo1 - zo0) * plane_rows;
+        if (gn_dense_.size() < rows * res[0]) gn_dense_.create(rows * res[0]);
+        hipSafeCall(hipMemcpy2DAsync(gn_dense_.ptr(), row_bytes, gt, value.step(), row_bytes, rows, hipMemcpyDeviceToDevice, st));
+        gt = gn_dense_.ptr();
+    }
+    check_rc(xs_tsdf_gauss_newton_terms(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
+                                        &kinect_intrinsic.fx, res, voxel_size, &R[0][0], &t[0][0], tsdf_volume_d_ptr->getTsdfTruncDist(), gt,
+                                        zo0, zo1, gn_ws_.ptr(), gn_sums_.ptr(), st), "GaussNewtonTerms");
+    if (shard_count > 1 && collective) collective(collective_user, 0, gn_sums_.ptr(), 29);
+    double h[29];
+    hipSafeCall(hipMemcpyAsync(h, gn_sums_.ptr(), sizeof(h), hipMemcpyDeviceToHost, st));
+    hipSafeCall(hipStreamSynchronize(st));
+    const double ih = 1.0 / (double)(float)H_;
+    for (int i = 0; i < 21; ++i) out29[i] = h[i] * ih * ih;
+    for (int i = 21; i < 27; ++i) out29[i] = h[i] * ih;
+    out29[27] = h[27]; out29[28] = h[28];
+    return 1;
+}
+
+int KinectFusionReconstruction::RelocalizeGaussNewton(const DeviceArray2D<ushort> &depth_frame_d, Matrix4cf &camera2volume, int iterations,
+                                                      float damping, std::vector<double> *loss_history) {
+    for (int it = 0; it < iterations; ++it) {
+        double s[29];
+        if (!GaussNewtonTerms(depth_frame_d, camera2volume, s)) return 0;
+        if (loss_history) loss_history->push_back(s[28] > 0 ? s[27] / s[28] : 0.0);
+        if (s[28] < 6) return 0;  // nothing to align to
+        double A[36], b[6], x[6];
+        int q = 0;
+        for (int j = 0; j < 6; ++j)
+            for (int k = j; k < 6; ++k, ++q) { A[j * 6 + k] = s[q]; A[k * 6 + j] = s[q]; }
+        for (int k = 0; k < 6; ++k) { A[k * 6 + k] *= 1.0 + (double)damping; b[k] = -s[21 + k]; }
+        if (!solve_spd6(A, b, x)) return 0;
+        hostComplex xi[6];
+        for (int k = 0; k < 6; ++k) xi[k] = hostComplex((float)x[k], 0.f);
+        camera2volume = se3Exp(xi) * camera2volume;
+    }
+    if (loss_history) {
+        double s[29];
+        if (GaussNewtonTerms(depth_frame_d, camera2volume, s)) loss_history->push_back(s[28] > 0 ? s[27] / s[28] : 0.0);
+    }
+    return 1;
+}
+
 // reference :334-372
 KinectFusionReconstruction::CPointCloud KinectFusionReconstruction::ExportPointCloud(int max_buffer) {
     CPointCloud res;

@@ -118,6 +118,16 @@ public:
     static inline Vector3cf GetTranslation(Matrix4cf &trans_mat) { return xs_host::GetTranslation(trans_mat); }
     static inline Matrix3frm GetRotation(Matrix4cf &trans_mat) { return xs_host::GetRotation(trans_mat); }
 
+    // Pose refinement against the map by Gauss-Newton on the TSDF residual of ComputeLocalTsdf_hessian, with the
+    // Jacobian from first-order CSFD: six poses seeded with i*h along the generators of a left perturbation
+    // camera2volume <- se3Exp(xi) * camera2volume, all evaluated in one pass over the volume
+    // (xs_tsdf_gauss_newton_terms).  BASELINE config 5; the reference only has the commented single-direction
+    // ComputeTSDF_loss / ComputeTSDF_hessian (:374-434).  A sharded rank evaluates its slab and the 29 sums are
+    // all-reduced.  GaussNewtonTerms fills {JtJ upper triangle (21), Jtr (6), sum r^2, count}, already divided by h.
+    int GaussNewtonTerms(const DeviceArray2D<ushort> &depth_frame_d, const Matrix4cf &camera2volume, double out29[29]);
+    int RelocalizeGaussNewton(const DeviceArray2D<ushort> &depth_frame_d, Matrix4cf &camera2volume, int iterations, float damping,
+                              std::vector<double> *loss_history = nullptr);
+
     // ExportPointCloud (reference :334-372, main.cpp:78-80): zero-crossing points of the TSDF with
     // normals, at most max_buffer of them; a sharded rank exports the planes it owns.
     struct CPointCloud {
@@ -146,6 +156,9 @@ private:
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
     DeviceArray<unsigned char> icp_pose_;      // device-resident pose of the ICP loop (xs_icp_iterate)
+    DeviceArray<double> gn_sums_;              // 29 Gauss-Newton sums (+ pad)
+    DeviceArray<float> gn_dense_;              // packed copy of the owned planes when the volume is pitched
+    DeviceArray<unsigned char> gn_ws_;         // reduce workspace of the Gauss-Newton / Hessian kernels
     DeviceArray2D<ushort> depth_ingest_d_;     // device copy of a host frame (ProcessFrameHost)
     ushort *ingest_pinned_[2] = {nullptr, nullptr};
     hipEvent_t ingest_done_[2] = {nullptr, nullptr};

@@ -156,6 +156,62 @@ inline Matrix3cf angle_axis(hostComplex angle, int axis) {
     return r;
 }
 
+// se3Exp(const Eigen::VectorXcf& xi), KinectFusionReconstruction.h:176-219: xi = (v, omega); Rodrigues
+// with complex scalars; below |omega| = 1e-6 the first-order form R = I + omega^, V = I + omega^
+// (|omega| is the Euclidean norm of the complex vector, as Eigen's norm()).
+inline Matrix4cf se3Exp(const hostComplex xi[6]) {
+    const hostComplex *v = xi, *omega = xi + 3;
+    Matrix3cf omegaHat;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) omegaHat.m[i][j] = hostComplex(0.f, 0.f);
+    omegaHat.m[0][1] = -omega[2]; omegaHat.m[0][2] = omega[1]; omegaHat.m[1][2] = -omega[0];
+    omegaHat.m[1][0] = omega[2]; omegaHat.m[2][0] = -omega[1]; omegaHat.m[2][1] = omega[0];
+    Matrix3cf R = Matrix3cf::Identity(), V = Matrix3cf::Identity();
+    const float nrm = std::sqrt(std::norm(omega[0]) + std::norm(omega[1]) + std::norm(omega[2]));
+    if (nrm < 1e-6f) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { R.m[i][j] += omegaHat.m[i][j]; V.m[i][j] += omegaHat.m[i][j]; }
+    } else {
+        const hostComplex sum = (omega[0] * omega[0] + omega[1] * omega[1]) + omega[2] * omega[2];
+        const hostComplex theta = std::sqrt(sum);
+        const hostComplex s = std::sin(theta), c = std::cos(theta);
+        const Matrix3cf sq = omegaHat * omegaHat;
+        const hostComplex A = s / theta;
+        const hostComplex B = (1.0f - c) / std::pow(theta, 2.0f);
+        const hostComplex C = (theta - s) / std::pow(theta, 3.0f);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                R.m[i][j] = (R.m[i][j] + A * omegaHat.m[i][j]) + B * sq.m[i][j];
+                V.m[i][j] = (V.m[i][j] + B * omegaHat.m[i][j]) + C * sq.m[i][j];
+            }
+    }
+    Vector3cf vv; vv.v[0] = v[0]; vv.v[1] = v[1]; vv.v[2] = v[2];
+    const Vector3cf t = V * vv;
+    Matrix4cf out;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out.m[i][j] = hostComplex(0.f, 0.f);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) out.m[i][j] = R.m[i][j]; out.m[i][3] = t.v[i]; }
+    out.m[3][3] = hostComplex(1.f, 0.f);
+    return out;
+}
+
+// x = A^-1 b for a symmetric positive definite real 6x6 (row-major), plain Cholesky; false if a pivot fails
+inline bool solve_spd6(const double *A, const double *b, double *x) {
+    double L[6][6] = {};
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0)) return false;
+        L[j][j] = std::sqrt(d);
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s / L[j][j];
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * y[k]; y[i] = s / L[i][i]; }
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+    return true;
+}
+
 inline Matrix3cf GetRotation(const Matrix4cf &t) { Matrix3cf r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = t.m[i][j]; return r; }
 inline Vector3cf GetTranslation(const Matrix4cf &t) { Vector3cf v; for (int i = 0; i < 3; ++i) v.v[i] = t.m[i][3]; return v; }
 

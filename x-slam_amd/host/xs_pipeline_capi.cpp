@@ -95,6 +95,29 @@ int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) 
 }
 int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host) { return ((KF *)kf)->ProcessFrameHost(depth_host); }
 uint16_t *xs_kf_ingest_buffer(void *kf) { return ((KF *)kf)->IngestBuffer(); }
+void xs_kf_get_camera2volume(void *kf, float *out32) {
+    const auto m = ((KF *)kf)->getCamera2Volume();
+    std::memcpy(out32, &m, 32 * sizeof(float));
+}
+static DeviceArray2D<ushort> wrap_depth(KF *k, const uint16_t *depth_dev, size_t step_bytes) {
+    return DeviceArray2D<ushort>(k->depth_height, k->depth_width, const_cast<uint16_t *>(depth_dev), step_bytes);
+}
+int xs_kf_gauss_newton_terms(void *kf, const uint16_t *depth_dev, size_t step_bytes, const float *c2v32, double *out29) {
+    KF *k = (KF *)kf;
+    xs_host::Matrix4cf m;
+    std::memcpy(static_cast<void *>(&m), c2v32, 32 * sizeof(float));
+    return k->GaussNewtonTerms(wrap_depth(k, depth_dev, step_bytes), m, out29);
+}
+int xs_kf_relocalize(void *kf, const uint16_t *depth_dev, size_t step_bytes, float *c2v32, int iterations, float damping, double *loss_out) {
+    KF *k = (KF *)kf;
+    xs_host::Matrix4cf m;
+    std::memcpy(static_cast<void *>(&m), c2v32, 32 * sizeof(float));
+    std::vector<double> hist;
+    const int rc = k->RelocalizeGaussNewton(wrap_depth(k, depth_dev, step_bytes), m, iterations, damping, loss_out ? &hist : nullptr);
+    std::memcpy(c2v32, &m, 32 * sizeof(float));
+    if (loss_out) for (size_t i = 0; i < hist.size() && i <= (size_t)iterations; ++i) loss_out[i] = hist[i];
+    return rc;
+}
 long long xs_kf_export_point_cloud(void *kf, int max_buffer, float *points_host, float *normals_host) {
     const auto pc = ((KF *)kf)->ExportPointCloud(max_buffer);
     if (points_host && pc.size()) std::memcpy(points_host, pc.positions.data(), pc.positions.size() * sizeof(float));

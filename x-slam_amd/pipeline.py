@@ -31,6 +31,9 @@ _SIGS = {
     "xs_kf_process_frame": (C.c_int, [_vp, _vp, _sz]),
     "xs_kf_process_frame_host": (C.c_int, [_vp, _vp]),
     "xs_kf_ingest_buffer": (_vp, [_vp]),
+    "xs_kf_get_camera2volume": (None, [_vp, _f32p]),
+    "xs_kf_gauss_newton_terms": (C.c_int, [_vp, _vp, _sz, _f32p, _f64p]),
+    "xs_kf_relocalize": (C.c_int, [_vp, _vp, _sz, _f32p, C.c_int, C.c_float, _f64p]),
     "xs_kf_export_point_cloud": (C.c_longlong, [_vp, C.c_int, _f32p, _f32p]),
     "xs_kf_export_ply": (C.c_longlong, [_vp, C.c_int, C.c_char_p]),
     "xs_kf_synchronize": (None, [_vp]),
@@ -141,6 +144,27 @@ class KinectFusion:
         ptr = _lib.xs_kf_ingest_buffer(self.h)
         n = self.width * self.height
         return np.ctypeslib.as_array((C.c_uint16 * n).from_address(ptr)).reshape(self.height, self.width)
+
+    def camera2volume(self):
+        out = np.zeros(32, np.float32)
+        _lib.xs_kf_get_camera2volume(self.h, out.ctypes.data_as(_f32p))
+        return out.reshape(4, 4, 2)
+
+    def gauss_newton_terms(self, depth_dev, c2v):
+        """29 doubles: J^T J upper triangle (21), J^T r (6), sum r^2, count, for the residual of the depth frame
+        against the map at camera2volume c2v [4, 4, 2]."""
+        m = np.ascontiguousarray(c2v, dtype=np.float32).reshape(32)
+        out = np.zeros(29, np.float64)
+        ok = _lib.xs_kf_gauss_newton_terms(self.h, depth_dev.data_ptr(), self.width * 2, m.ctypes.data_as(_f32p), out.ctypes.data_as(_f64p))
+        return out if ok == 1 else None
+
+    def relocalize(self, depth_dev, c2v, iterations=5, damping=1e-3):
+        """Gauss-Newton refinement of camera2volume against the map: (ok, refined c2v [4, 4, 2], loss history)."""
+        m = np.ascontiguousarray(c2v, dtype=np.float32).reshape(32).copy()
+        hist = np.zeros(iterations + 1, np.float64)
+        ok = _lib.xs_kf_relocalize(self.h, depth_dev.data_ptr(), self.width * 2, m.ctypes.data_as(_f32p), iterations, damping,
+                                   hist.ctypes.data_as(_f64p))
+        return ok == 1, m.reshape(4, 4, 2), hist
 
     def export_point_cloud(self, max_buffer=1000000):
         """ExportPointCloud: (points [n, 3], normals [n, 3]) float32 on the host."""
