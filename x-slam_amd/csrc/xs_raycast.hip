@@ -409,19 +409,31 @@ __global__ void __launch_bounds__(256) k_compose_mask(const int *own_keys, const
 }
 __global__ void __launch_bounds__(256) k_compose_finish(const int *min_keys, cfloat *vmap, cfloat *nmap, size_t mstep, int rows, int cols,
                                                         unsigned long long *hits) {
-    const int x = threadIdx.x + blockIdx.x * 64, y = threadIdx.y + blockIdx.y * 4;
+    // a few hundred workgroups stride over the 64x4 pixel tiles and add their hit count with ONE atomic each
+    // (one per wave to the same word — 4800 of them at ~12 ns — made this the second longest kernel of the frame)
+    const int tiles_x = (cols + 63) / 64, tiles_y = (rows + 3) / 4;
     unsigned hit = 0;
-    if (x < cols && y < rows) {
-        const int m = min_keys[y * cols + x];
-        if ((m & 1) || m == 0x7fffffff) {  // no vertex on this ray: the NaN sentinel of RayCaster.cu:204-205
-            row_ptr(vmap, mstep, y)[x] = cfloat(qnan_f(), 0.f);
-            row_ptr(nmap, mstep, y)[x] = cfloat(qnan_f(), 0.f);
-        } else
-            hit = 1;
+    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
+        const int x = threadIdx.x + (tile % tiles_x) * 64, y = threadIdx.y + (tile / tiles_x) * 4;
+        if (x < cols && y < rows) {
+            const int m = min_keys[y * cols + x];
+            if ((m & 1) || m == 0x7fffffff) {  // no vertex on this ray: the NaN sentinel of RayCaster.cu:204-205
+                row_ptr(vmap, mstep, y)[x] = cfloat(qnan_f(), 0.f);
+                row_ptr(nmap, mstep, y)[x] = cfloat(qnan_f(), 0.f);
+            } else
+                ++hit;
+        }
     }
     if (hits) {
-        unsigned s = wave_sum_u32(hit);
-        if (((threadIdx.y * 64 + threadIdx.x) & 63) == 0 && s) atomicAdd(hits, (unsigned long long)s);
+        __shared__ unsigned s_hits[4];
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        const unsigned s = wave_sum_u32(hit);
+        if ((tid & 63) == 0) s_hits[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = (s_hits[0] + s_hits[1]) + (s_hits[2] + s_hits[3]);
+            if (t) atomicAdd(hits, (unsigned long long)t);
+        }
     }
 }
 /* keep this rank's vertex / normal only where it owns the ray's first event (own key == min key) */
@@ -437,7 +449,8 @@ extern "C" int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_k
 extern "C" int xs_raycast_compose_finish(const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows, int cols,
                                          unsigned long long *hits_dev, void *stream) {
     if (!min_keys_dev || !vmap || !nmap) return xs_set_error(hipErrorInvalidValue, "xs_raycast_compose_finish: null pointer");
-    dim3 block(64, 4), grid(div_up(cols, 64), div_up(rows, 4));
+    const int ntiles = div_up(cols, 64) * div_up(rows, 4);
+    dim3 block(64, 4), grid(ntiles < 256 ? ntiles : 256);
     hipLaunchKernelGGL(k_compose_finish, grid, block, 0, (hipStream_t)stream, min_keys_dev, (cfloat *)vmap, (cfloat *)nmap, map_step, rows, cols, hits_dev);
     XS_CHECK(hipGetLastError());
     return 0;
