@@ -204,9 +204,9 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
             int pgx = gx, pgy = gy, pgz = gz;
             for (; time_curr < max_time; time_curr += time_step, ++step_index) {
                 const float tn = time_curr + time_step;
-                gx = __float2int_rd((sx + dx * tn) / vs);
-                gy = __float2int_rd((sy + dy * tn) / vs);
-                gz = __float2int_rd((sz + dz * tn) / vs);
+                gx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);  // floor(p / vs) without the divide
+                gy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                gz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
                 if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < a.X && gy < a.Y && gz < a.Z)) break;
                 const bool owned = gz >= a.z0 && gz < a.z1;
                 const int qx = pgx, qy = pgy, qz = pgz;
@@ -381,6 +381,7 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.X = res[0]; a.Y = res[1]; a.Z = res[2];
     a.voxel_size = voxel_size;
     a.time_step = tranc_dist * 0.8f;
+    set_inv_vs(a);
     a.cols = cols; a.rows = rows;
     a.value = value; a.grad = grad; a.vstep = vol_step;
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
