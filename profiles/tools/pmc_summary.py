@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res["calib_" + c + "_KiB"] = k.get(c)
     fac[c] = cal_known / (k[c] * 1024.0) if k.get(c) else None
     res["calib_factor_" + c] = fac[c]
-for scene, what in (("s2", "scene S2 512^3 (scratch/probe_s2.py)"), ("s1", "scene S1 512^3 frame 20 (scratch/probe_s1.py), brick-list launches")):
+for scene, what in (("s2", "scene S2 512^3 (profiles/tools/probe_s2.py)"), ("s1", "scene S1 512^3 frame 20 (profiles/tools/probe_s1.py), brick-list launches")):
     e = {"kernel": "k_integrate_bricks<false>, " + what + ", per launch"}
     cs, n = {}, {}
     for sub in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):

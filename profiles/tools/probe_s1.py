@@ -1,0 +1,32 @@
+import importlib, sys, json
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')  # run from the repository root
+import numpy as np, torch
+capi = importlib.import_module('x-slam_amd.capi'); synth = importlib.import_module('x-slam_amd.synth')
+from helpers import intr_of, s1_transforms, tranc_dist
+n = 512; prm = synth.s1_params(n); res = [n, n, n]
+W, H = 640, 480
+value = torch.zeros((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.zeros((n * n, n), dtype=torch.int32, device="cuda"); grad = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+scaled = torch.empty((H, W), dtype=torch.float32, device="cuda"); dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
+T = s1_transforms(k, prm)
+capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+s = torch.cuda.current_stream()
+def run(use_ws, use_max, reps=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    counter.zero_()
+    capi.integrate_scaled(scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), value, weight, grad, n * 4, updated=counter, depth_max=dmax if use_max else None, workspace=ws if use_ws else None, stream=s)
+    torch.cuda.synchronize()
+    U = int(counter.item())
+    e0.record(s)
+    for _ in range(reps):
+        capi.integrate_scaled(scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), value, weight, grad, n * 4, depth_max=dmax if use_max else None, workspace=ws if use_ws else None, stream=s)
+    e1.record(s); torch.cuda.synchronize()
+    nb = int(ws[:4].view(torch.int32).item()) if use_ws else -1
+    return dict(ws=use_ws, far=use_max, U=U, bricks=nb, ms=e0.elapsed_time(e1) / reps)
+print('dmax', float(dmax.item()))
+cfgs = ((True, True),) if len(sys.argv) > 2 and sys.argv[2] == 'only' else ((False, False), (False, True), (True, False), (True, True))
+for cfg in cfgs:
+    print(run(*cfg, reps=4 if len(cfgs) == 1 else 20))

@@ -236,3 +236,52 @@ def test_integrate_size_independent_properties_512(dev):
     assert np.array_equal(w2, 2 * w)
     free = v == 1.0
     assert np.all(v2[free] == 1.0)
+
+
+def test_full_size_properties_512(dev):
+    """Size-independent properties at the benchmark's full size (512^3, scene S1): z-slab launches tile the
+    whole-volume launch bit for bit and count the same voxels; integrating the same frame again leaves every
+    written voxel's value within an ulp (running mean of equal samples) and raises its weight by one; the count
+    of written voxels equals the figure recorded from the reference kernel body."""
+    torch, capi = dev
+    import json, os
+    n = 512
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    T = s1_transforms(0, prm)
+    depth = torch.from_numpy(synth.s1_frame(0).view(np.int16)).cuda()
+    scaled = torch.empty((synth.HEIGHT, synth.WIDTH), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    capi.scale_depth_max(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, scaled, synth.WIDTH * 4, dmax)
+    def volume():
+        return (torch.zeros((n * n, n), dtype=torch.float32, device="cuda"), torch.zeros((n * n, n), dtype=torch.int32, device="cuda"),
+                torch.zeros((n * n, n), dtype=torch.float32, device="cuda"))
+    def run(vol, z0, z1, counter):
+        v, w, g = vol
+        off = z0 * n
+        ws = torch.zeros(capi.integrate_workspace_bytes(res, z1 - z0), dtype=torch.uint8, device="cuda")
+        capi.integrate_scaled(scaled, synth.WIDTH * 4, synth.HEIGHT, synth.WIDTH, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"],
+                              T["tv2c"], tranc_dist(prm), v[off:], w[off:], g[off:], n * 4, z0=z0, z1=z1, updated=counter, depth_max=dmax,
+                              workspace=ws)
+    whole, parts = volume(), volume()
+    c_whole = torch.zeros(1, dtype=torch.int64, device="cuda"); c_parts = torch.zeros(1, dtype=torch.int64, device="cuda")
+    run(whole, 0, n, c_whole)
+    for z0, z1 in ((0, 100), (100, 301), (301, n)):
+        run(parts, z0, z1, c_parts)
+    torch.cuda.synchronize()
+    U = int(c_whole.item())
+    assert U == int(c_parts.item()) == int((whole[1] > 0).sum().item())
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)
+    fig = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_reference_kernel_figures.json")))
+    assert abs(U - fig["integrate_U"]["512"]) <= 2
+    # the same frame again
+    v0, w0, g0 = whole[0].clone(), whole[1].clone(), whole[2].clone()
+    run(whole, 0, n, c_whole)
+    torch.cuda.synchronize()
+    written = w0 > 0
+    assert torch.equal(whole[1][written], w0[written] + 1) and torch.equal(whole[1][~written], w0[~written])
+    dv = (whole[0][written] - v0[written]).abs()
+    assert float(dv.max()) <= 1.2e-7 and float((dv > 0).float().mean()) < 0.5
+    dg = (whole[2][written] - g0[written]).abs()
+    assert float(dg.max()) <= 2.4e-7 * max(float(g0.abs().max()), 1e-30)

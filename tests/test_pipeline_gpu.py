@@ -265,3 +265,28 @@ def test_other_pyramid_depths_and_image_sizes(dev, oracle, levels, width, height
     ov, ow, og = ok_.volume()
     assert mismatch_fraction(w, ow) <= 1e-4
     kf.close()
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_full_size_first_frame_figures(dev, n):
+    """BASELINE configs 2 and 3 at their full sizes: after frame 0 of scene S1 the voxels written and the rays that
+    found a surface equal the figures recorded from the reference's own kernel bodies, and a
+    second pipeline fed the same frames reproduces poses, counters and maps bit for bit (determinism)."""
+    import json, os
+    torch, pl = dev
+    fig = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_reference_kernel_figures.json")))
+    prm = synth.s1_params(n)
+    a, b = pl.KinectFusion(prm), pl.KinectFusion(prm)
+    d0 = upload(torch, synth.s1_frame(0))
+    assert a.process_frame(d0) == 1 and b.process_frame(d0) == 1
+    assert abs(a.last_U() - fig["integrate_U"][str(n)]) <= max(2, 1e-4 * fig["integrate_U"][str(n)])
+    assert abs(a.last_hits() - fig["raycast_hits"][str(n)]) <= 2
+    for k in (1, 2):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+    assert np.array_equal(a.world2camera(), b.world2camera())
+    assert a.last_U() == b.last_U() and a.last_hits() == b.last_hits()
+    ma, mb = a.map("vmaps_g_prev", 0), b.map("vmaps_g_prev", 0)
+    na = np.isnan(ma[:H, :, 0])
+    assert np.array_equal(na, np.isnan(mb[:H, :, 0])) and np.array_equal(ma[:H][~na], mb[:H][~na])
+    a.close(); b.close()
