@@ -647,17 +647,20 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
 }
 
 // The dense ground-truth read is the kernels' only N^3 traffic, and a plain z loop keeps one 4-byte load
-// per lane in flight (measured: 0.85 TB/s for the Hessian kernel at 512^3).  Here a lane requests sixteen
+// per lane in flight (measured: 0.85 TB/s for the Hessian kernel at 512^3).  Here a lane requests thirty-two
 // planes at once, keeps a bit per plane whose voxel is in the band (gt != 0, |gt| <= 0.95: a few per
 // column), and then visits its band voxels one after the other — the k-th band voxel of every lane of the
 // wave together, whatever their z, so the expensive body runs with full lanes instead of once per plane any
 // lane needs.  Each lane still meets its voxels in ascending z: the per-lane double sums are unchanged.
+// (Scanning the slab as one flat array — contiguous 8 KB per wave — streamed only 6 % faster and made the
+// Hessian kernel 1.7x slower: the band is a sheet, so whole waves land inside it with 32 band voxels per lane
+// while most have none; in the column walk every lane crosses the sheet once.)
 template <int VEC, class F>
 __device__ __forceinline__ void for_band_voxels(const HessArgs &a, int x, int y, int zb, int ze, F &&body) {
     // VEC = 4: the lane owns four consecutive x and reads them as one 16-byte load (a wave-instruction moves
     // 1 KiB instead of 256 B: the one-dword form streams at 2.3 TB/s); VEC = 1 for volumes whose X is not a
     // multiple of four or whose base is not 16-byte aligned.
-    constexpr int ZB = 16;
+    constexpr int ZB = 32;
     const size_t plane = (size_t)a.Y * a.X;
     const size_t first = (size_t)(zb - a.z0) * plane + (size_t)y * a.X + x;
     for (int zc = zb; zc < ze; zc += ZB) {
