@@ -98,8 +98,15 @@ class ShardedKinectFusion(pl.KinectFusion):
                 import torch
             self._torch, self._dist = torch, dist
 
+            views = {}  # (ptr, count, op) -> tensor view: the orchestrator's buffers are persistent, so the
+                        # per-call cost of wrapping a raw pointer (tens of microseconds) is paid once
+
             def collective(_user, op, ptr, count):
-                reduce_tensor(self._dist, op, device_tensor(self._torch, ptr, count, op))
+                key = (int(ptr), int(count), int(op))
+                t = views.get(key)
+                if t is None:
+                    t = views[key] = device_tensor(self._torch, ptr, count, op)
+                reduce_tensor(self._dist, op, t)
         self._cb = _CB(collective)  # keep the trampoline alive as long as the handle
         self.h = pl._lib.xs_kf_create_sharded(text.encode(), rank, world, self._cb, None)
         if not self.h:
