@@ -41,30 +41,31 @@ namespace {
 // ICP.cu:196-244
 __device__ __forceinline__ bool search(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, cfloat3 &n, cfloat3 &d,
                                        cfloat3 &s) {
-    cfloat3 ncurr;
+    // all six current-frame values are requested before the sentinel is looked at (the y / z planes of an
+    // invalid pixel are allocated, merely unused): one memory round trip instead of two — the kernel is
+    // latency-bound at two waves per SIMD
+    cfloat3 ncurr, vcurr;
     ncurr.x = row_ptr(a.nmap_curr, a.mstep, y)[x];
-    if (isnan(ncurr.x.re)) return false;
     ncurr.y = row_ptr(a.nmap_curr, a.mstep, y + a.rows)[x];
     ncurr.z = row_ptr(a.nmap_curr, a.mstep, y + 2 * a.rows)[x];
-    cfloat3 vcurr;
     vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
     vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
     vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
+    if (isnan(ncurr.x.re)) return false;
     const cfloat3 vcurr_g = Rcurr * vcurr + tcurr;
     const cfloat3 vcp = a.Rprev_inv * (vcurr_g - a.tprev);
     const float cpx = vcp.x.re, cpy = vcp.y.re, cpz = vcp.z.re;
     const int ux = __float2int_rn(cpx * a.intr.fx / cpz + a.intr.cx);
     const int uy = __float2int_rn(cpy * a.intr.fy / cpz + a.intr.cy);
     if (ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || cpz < 0) return false;
-    cfloat3 nprev_g;
+    cfloat3 nprev_g, vprev_g;  // likewise: the six model-map values of the matched pixel together
     nprev_g.x = row_ptr(a.nmap_g_prev, a.mstep, uy)[ux];
-    if (isnan(nprev_g.x.re)) return false;
     nprev_g.y = row_ptr(a.nmap_g_prev, a.mstep, uy + a.rows)[ux];
     nprev_g.z = row_ptr(a.nmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
-    cfloat3 vprev_g;
     vprev_g.x = row_ptr(a.vmap_g_prev, a.mstep, uy)[ux];
     vprev_g.y = row_ptr(a.vmap_g_prev, a.mstep, uy + a.rows)[ux];
     vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    if (isnan(nprev_g.x.re)) return false;
     const cfloat dist = norm(vprev_g - vcurr_g);
     if (dist.re > a.distThres) return false;
     const cfloat3 ncurr_g = Rcurr * ncurr;
