@@ -104,11 +104,13 @@ struct Vol {
 };
 }  // namespace
 
-// MODE 0: whole ray in one kernel; 1: slab (multi-GPU); 2: march only, records the crossing time;
-// 3: crossing only (trilinear samples, vertex, normal) for the pixels MODE 2 marked.
+// MODE 0: whole ray in one kernel; 1: slab (multi-GPU), whole ray in one kernel; 2: march only, records the crossing
+// time; 3: crossing only (trilinear samples, vertex, normal) for the pixels MODE 2 marked; 4 / 5: the slab march and
+// the slab crossing as two kernels (what xs_raycast_slab launches: the march then runs at eight waves per SIMD with
+// eight gathers in flight, like MODE 2).
 template <int MODE, bool OFF32>
 __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
-    constexpr bool SLAB = MODE == 1;
+    constexpr bool SLAB = MODE == 1 || MODE == 4 || MODE == 5;
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
     // round-robin over the 8 XCDs (each with its own 4 MB L2): the linear id is remapped so that
     // XCD k marches one contiguous band of image tiles — an eighth of the frustum, which fits its
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
     unsigned hit = 0;
     if (tile_ok && x < a.cols && y < a.rows) {
         int key = 0x7fffffff, step_index = 0;
-        if (SLAB) {
+        if (MODE == 1 || MODE == 4) {
             // contributions of the ranks are added (as int32 bit patterns) after the first event
             // along each ray has been agreed on: start from all-zero entries
 #pragma unroll
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 row_ptr(a.vmap, a.mstep, y + p * a.rows)[x] = cfloat(0.f, 0.f);
                 row_ptr(a.nmap, a.mstep, y + p * a.rows)[x] = cfloat(0.f, 0.f);
             }
-        } else if (MODE != 3) {
+        } else if (MODE != 3 && MODE != 5) {
             row_ptr(a.vmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
             row_ptr(a.nmap, a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
         }
@@ -197,6 +199,79 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
         if (MODE == 3) {
             const float tc = a.cross_t[y * a.cols + x];
             if (tc >= 0.f) hit = crossing(tc, tc + time_step);
+        } else if (MODE == 5) {
+            // the slab march left (time of the step before the crossing, marker 1) in the vertex map's x plane where
+            // this rank's first event is a + to - crossing, and the provisional key (step << 1 | 1)
+            key = a.keys[y * a.cols + x];
+            const cfloat mark = row_ptr(a.vmap, a.mstep, y)[x];
+            if (mark.im == 1.0f) {
+                row_ptr(a.vmap, a.mstep, y)[x] = cfloat(0.f, 0.f);
+                if (crossing(mark.re, mark.re + time_step)) { key = key & ~1; hit = 1; }
+            }
+        } else if (MODE == 4) {
+            // Slab march, eight steps at a time.  Every rank walks the same steps (the times are a float running sum)
+            // and looks only at those whose sample voxel it owns; the sample before (at most 3 planes away) is in
+            // the halo it also stores.  Per step, in order: a sample outside the volume ends the march without an
+            // event; an owned step whose previous sample is not stored ends it with (step << 1 | 1) (never expected:
+            // halo too thin); - to + ends it with (step << 1 | 1); + to - ends it with a crossing for MODE 5 to
+            // evaluate; any other owned step leaves "no event".
+            int pz = gz;
+            float pval = (gz >= a.zs0 && gz < a.zs1) ? vol.read_value(gx, gy, gz) : 0.f;
+            bool pstored = gz >= a.zs0 && gz < a.zs1;
+            bool done = false;
+            while (!done && time_curr < max_time) {
+                constexpr int NS = 8;
+                float tc[NS], val[NS];
+                unsigned term = 0, own = 0, stored = 0;
+                float t = time_curr;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    tc[j] = t;
+                    const float tn = t + time_step;
+                    const int jx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const int jy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const int jz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const bool inb = (unsigned)jx < (unsigned)a.X && (unsigned)jy < (unsigned)a.Y && (unsigned)jz < (unsigned)a.Z;
+                    const bool st = inb && jz >= a.zs0 && jz < a.zs1;
+                    term |= ((t < max_time) && inb ? 0u : 1u) << j;
+                    own |= ((inb && jz >= a.z0 && jz < a.z1) ? 1u : 0u) << j;
+                    stored |= (st ? 1u : 0u) << j;
+                    if (OFF32) val[j] = vol.value_at(st ? vol.offset32(jx, jy, jz) : 0u) + 1e-5f;
+                    else val[j] = vol.read_value(st ? jx : 0, st ? jy : 0, st ? jz : a.zs0);
+                    t += time_step;
+                }
+                unsigned thin = 0, up = 0, down = 0;
+                float prev = pval;
+                bool prev_st = pstored;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const bool o = (own >> j) & 1u;
+                    thin |= ((o && !prev_st) ? 1u : 0u) << j;
+                    up |= ((o && prev_st && prev < 0.f && val[j] > 0.f) ? 1u : 0u) << j;
+                    down |= ((o && prev_st && prev > 0.f && val[j] < 0.f) ? 1u : 0u) << j;
+                    prev = val[j];
+                    prev_st = (stored >> j) & 1u;
+                }
+                const unsigned ev = term | thin | up | down;
+                if (ev) {
+                    const int e = __ffs(ev) - 1;
+                    if (!((term >> e) & 1u)) {
+                        key = ((step_index + e) << 1) | 1;
+                        if ((down >> e) & 1u) {
+                            float tce = tc[0];
+#pragma unroll
+                            for (int j = 1; j < NS; ++j) tce = (e == j) ? tc[j] : tce;
+                            row_ptr(a.vmap, a.mstep, y)[x] = cfloat(tce, 1.0f);  // for MODE 5
+                        }
+                    }
+                    done = true;
+                }
+                pval = val[NS - 1];
+                pstored = (stored >> (NS - 1)) & 1u;
+                time_curr = t;
+                step_index += NS;
+            }
+            (void)pz;
         } else if (SLAB) {
             // slab mode: every rank walks the same sequence of steps (the times are a float running
             // sum, so all of them must be taken) but evaluates only those whose sample voxel it owns;
@@ -278,7 +353,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
             }
             if (MODE == 2) a.cross_t[y * a.cols + x] = cross;
         }
-        if (SLAB) a.keys[y * a.cols + x] = key;
+        if (SLAB) a.keys[y * a.cols + x] = key;  // (MODE 5 rewrites the key it read: even where the crossing gave a vertex)
     }
     if (a.hits) {
         // one atomic per workgroup: same-address atomics cost ~12 ns each at the memory side, and one
@@ -391,8 +466,13 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
     a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
-    if (fits32(a)) hipLaunchKernelGGL((k_raycast<1, true>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_raycast<1, false>), grid, block, 0, (hipStream_t)stream, a);
+    if (fits32(a)) {
+        hipLaunchKernelGGL((k_raycast<4, true>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<5, true>), grid, block, 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((k_raycast<4, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<5, false>), grid, block, 0, (hipStream_t)stream, a);
+    }
     XS_CHECK(hipGetLastError());
     return 0;
 }
