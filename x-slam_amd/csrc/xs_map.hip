@@ -19,37 +19,89 @@ constexpr int BR = 6, BD = 2 * BR + 1;  // 13x13 window (Map.cu:169-170)
 constexpr int BTX = 64, BTY = 4;        // block = 4 waves, one image row each
 }  // namespace
 
-// The 13x13 window of every pixel of a 64x4 block is staged once in LDS as u16 (76 x 16 tile,
-// 2.4 KB), so the 169 taps per pixel are LDS reads instead of 169 global loads.  The taps are
+// The 13x13 window of every pixel of a 64x4 block is staged once in LDS (76 x 16 tile, 4.9 KB),
+// so the 169 taps per pixel are LDS reads instead of 169 global loads.  The taps are
 // accumulated in the reference's order (rows outer, columns inner): float sums are order
 // dependent and the result is rounded to an integer millimetre.
-__global__ void __launch_bounds__(BTX *BTY) k_bilateral(const uint16_t *src, size_t sstep, int rows, int cols, cfloat *dst, size_t dstep,
-                                                        float sigma_space2_inv_half, float sigma_color2_inv_half) {
-    __shared__ uint16_t tile[BTY + 2 * BR][BTX + 2 * BR + 4];
+//
+// The tile holds floats (the taps are needed as floats anyway) and every position the reference's
+// clipped loops never visit — outside the image, and the last column and row (Map.cu:172-179) —
+// holds kSkip: its colour distance is so large that the weight is exactly 0, and adding 0 leaves
+// both sums bit-identical to skipping the tap.  With that the 169 taps unroll with no bounds
+// logic: the spatial term is a literal per tap, taps go through the pipeline eight at a time
+// (v_pk_* on the element-wise part with independent chains interleaved; the two running sums
+// stay in tap order), and LDS latency hides behind independent reads.  (float)(d*d) of the reference equals fl(d)*fl(d): d is exact in
+// float and both round the exact product once.
+namespace {
+constexpr int TP = 4;  // tap pairs per group: eight independent exp chains in flight per lane
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kSkip = -1048576.f;
+constexpr float kSpaceInvHalf = 0.5f / (kSigmaSpace * kSigmaSpace);
+constexpr float kColorInvHalf = 0.5f / (kSigmaColor * kSigmaColor);
+constexpr int TW = BTX + 2 * BR, TH = BTY + 2 * BR;
+constexpr int NTAPS = BD * BD;
+constexpr int clamp_tap(int tap) { return tap < NTAPS ? tap : 0; }  // the last group is padded; its extras are not summed
+constexpr int tap_offset(int tap) { return (clamp_tap(tap) / BD) * TW + clamp_tap(tap) % BD; }
+constexpr float space_term(int tap) {
+    const int dx = clamp_tap(tap) % BD - BR, dy = clamp_tap(tap) / BD - BR;
+    return (float)(dx * dx + dy * dy) * kSpaceInvHalf;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(BTX *BTY) k_bilateral(const uint16_t *src, size_t sstep, int rows, int cols, cfloat *dst, size_t dstep) {
+    __shared__ float tile[TH][TW];
     const int bx = blockIdx.x * BTX, by = blockIdx.y * BTY;
     const int tid = threadIdx.y * BTX + threadIdx.x;
-    for (int i = tid; i < (BTY + 2 * BR) * (BTX + 2 * BR); i += BTX * BTY) {
-        int ty = i / (BTX + 2 * BR), tx = i % (BTX + 2 * BR);
+    for (int i = tid; i < TH * TW; i += BTX * BTY) {
+        int ty = i / TW, tx = i % TW;
         int gy = by + ty - BR, gx = bx + tx - BR;
-        uint16_t v = 0;
-        if (gy >= 0 && gy < rows && gx >= 0 && gx < cols) v = row_ptr(src, sstep, gy)[gx];
+        float v = kSkip;
+        if (gy >= 0 && gy < rows - 1 && gx >= 0 && gx < cols - 1) v = (float)row_ptr(src, sstep, gy)[gx];
         tile[ty][tx] = v;
     }
     __syncthreads();
     const int x = bx + threadIdx.x, y = by + threadIdx.y;
     if (x >= cols || y >= rows) return;
-    const int value = tile[threadIdx.y + BR][threadIdx.x + BR];
-    const int tx = min(x - BD / 2 + BD, cols - 1);  // exclusive; the last column/row is never read (Map.cu:172-179)
-    const int ty = min(y - BD / 2 + BD, rows - 1);
+    const f32x2 value = f32x2((float)row_ptr(src, sstep, y)[x]);
+    const float *win = &tile[threadIdx.y][threadIdx.x];
     float sum1 = 0, sum2 = 0;
-    for (int cy = max(y - BD / 2, 0); cy < ty; ++cy) {
-        for (int cx = max(x - BD / 2, 0); cx < tx; ++cx) {
-            const int tmp = tile[cy - by + BR][cx - bx + BR];
-            const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
-            const float color2 = (float)((value - tmp) * (value - tmp));
-            const float weight = expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
-            sum1 += tmp * weight;
-            sum2 += weight;
+#pragma unroll
+    for (int g = 0; g < NTAPS; g += 2 * TP) {
+        // Each statement runs over the group's pairs before the next one starts, so the
+        // dependent steps of one chain are separated by the same step of the other chains.
+        // exp(-p), p >= 0, is the device libm's expf sequence (hi/lo product with log2(e),
+        // v_exp_f32 on the fraction, ldexp) without its overflow branch; underflow falls out
+        // of ldexp.
+        f32x2 tmp[TP], p[TP], ph[TP], pl[TP], e[TP], w[TP], tw[TP];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) tmp[k] = f32x2{win[tap_offset(g + 2 * k)], win[tap_offset(g + 2 * k + 1)]};
+#pragma unroll
+        for (int k = 0; k < TP; ++k) p[k] = value - tmp[k];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) p[k] = p[k] * p[k];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) p[k] = f32x2{space_term(g + 2 * k), space_term(g + 2 * k + 1)} + p[k] * kColorInvHalf;
+#pragma unroll
+        for (int k = 0; k < TP; ++k) ph[k] = p[k] * -0x1.715476p+0f;
+#pragma unroll
+        for (int k = 0; k < TP; ++k) pl[k] = __builtin_elementwise_fma(p[k], f32x2(-0x1.715476p+0f), -ph[k]);
+#pragma unroll
+        for (int k = 0; k < TP; ++k) pl[k] = __builtin_elementwise_fma(p[k], f32x2(-0x1.4ae0bep-26f), pl[k]);
+#pragma unroll
+        for (int k = 0; k < TP; ++k) e[k] = __builtin_elementwise_rint(ph[k]);
+#pragma unroll
+        for (int k = 0; k < TP; ++k) ph[k] = (ph[k] - e[k]) + pl[k];
+#pragma unroll
+        for (int k = 0; k < TP; ++k)
+            w[k] = f32x2{__builtin_ldexpf(__builtin_amdgcn_exp2f(ph[k].x), (int)e[k].x), __builtin_ldexpf(__builtin_amdgcn_exp2f(ph[k].y), (int)e[k].y)};
+#pragma unroll
+        for (int k = 0; k < TP; ++k) tw[k] = tmp[k] * w[k];
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            // (the empty asm keeps the two running sums out of the SLP vectoriser: packing them
+            // costs more in register shuffles than the packed add saves)
+            if (g + 2 * k < NTAPS) { sum1 += tw[k].x; sum2 += w[k].x; asm("" : "+v"(sum1)); }
+            if (g + 2 * k + 1 < NTAPS) { sum1 += tw[k].y; sum2 += w[k].y; asm("" : "+v"(sum1)); }
         }
     }
     int round = __float2int_rn(sum1 / sum2);
@@ -63,8 +115,7 @@ extern "C" int xs_bilateral_filter(const uint16_t *src, size_t src_step, int row
     if (!src || !dst) return xs_set_error(hipErrorInvalidValue, "xs_bilateral_filter: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
     dim3 block(BTX, BTY), grid(div_up(cols, BTX), div_up(rows, BTY));
-    hipLaunchKernelGGL(k_bilateral, grid, block, 0, (hipStream_t)stream, src, src_step, rows, cols, (cfloat *)dst, dst_step,
-                       0.5f / (kSigmaSpace * kSigmaSpace), 0.5f / (kSigmaColor * kSigmaColor));
+    hipLaunchKernelGGL(k_bilateral, grid, block, 0, (hipStream_t)stream, src, src_step, rows, cols, (cfloat *)dst, dst_step);
     XS_CHECK(hipGetLastError());
     return 0;
 }
