@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--force-composite", action="store_true",
                     help="rehearsal on one GPU: run the sharded raycast composite and its RCCL collectives with a single rank")
     ap.add_argument("--no-alt", action="store_true", help="N > 1: skip the short run of the other ICP sharding mode after the timed region")
+    ap.add_argument("--no-post-pose", action="store_true",
+                    help="launch every ICP iteration after its solve (the reference's order) instead of posting the pose to an already enqueued launch")
     ap.add_argument("--icp-solve", choices=["host", "device"], default=None,
                     help="where the pose update between ICP iterations runs (default: the library's default)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: put every rank on cuda:0 (needs --backend gloo)")
@@ -204,6 +206,8 @@ def main():
         prm = synth.s1_params(N)
         if a.icp_solve is not None:
             prm["icp_solve_on_device"] = (a.icp_solve == "device")
+        if a.no_post_pose:
+            prm["icp_post_pose"] = False
         runner = pl.KinectFusion(prm)
 
     def frame(i):

@@ -190,6 +190,26 @@ int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vm
                       const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                       const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
                       void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq, void *stream);
+/* estimateCombined with the pose posted AFTER the launch (same reference interface as above; it
+ * replaces the launch latency between two iterations of KinectFusionReconstruction.cpp:187-225).
+ * The call is made while the previous iteration is still running; the launch becomes resident behind
+ * it, polls `mailbox` — xs_icp_mailbox_bytes() (128) bytes, 64-byte aligned, that the host can write and
+ * the device read coherently (xs_icp_mailbox_alloc), zero before first use — and starts on the pixels once xs_icp_post_pose(mailbox, Rcurr18, tcurr6, mailbox_seq, 0)
+ * has been called; cmd = 1 makes the launch return without touching anything (the host left the loop).
+ * A launch whose pose never arrives gives up after about a second and stores done_seq | 1<<63 to
+ * done_flag; call xs_icp_workspace_init again after that.  One mailbox serves one stream: post
+ * sequence numbers in launch order, each only after the previous launch's sums were consumed. */
+size_t xs_icp_mailbox_bytes(void);
+/* a zeroed mailbox where polling is cheapest: fine-grained device memory the CPU writes through the
+ * large PCIe BAR (the workgroups then poll local memory), else host-coherent pinned memory */
+int xs_icp_mailbox_alloc(void **mailbox, int *in_device_memory);
+int xs_icp_mailbox_free(void *mailbox, int in_device_memory);
+int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_seq, const float *vmap_curr, const float *nmap_curr,
+                             const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                             const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0,
+                             int y1, void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq,
+                             void *stream);
+void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const float *tcurr6, unsigned mailbox_seq, int cmd);
 /* One whole ICP iteration without leaving the device: estimateCombined followed by the pose update
  * the reference's host performs before the next launch (KinectFusionReconstruction.cpp:203-224:
  * A.real().determinant() gate, complex<double> llt().solve, cast to complex<float>, AngleAxis

@@ -379,6 +379,93 @@ def test_icp_iterate_device_pose_update(dev, oracle):
         R, t = gR.copy(), gt.copy()   # continue from what the device holds
 
 
+def _coherent_host_bytes(nbytes):
+    """nbytes of zeroed host-coherent pinned memory (hipHostMallocCoherent | hipHostMallocMapped) as (address, free)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    p = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(p), C.c_size_t(nbytes), C.c_uint(0x40000000 | 0x2)) == 0
+    C.memset(p, 0, nbytes)
+    return p.value, lambda: hip.hipHostFree(p)
+
+
+@pytest.mark.parametrize("where", ["alloc", "pinned"])
+def test_icp_posted_pose_mailbox(dev, oracle, where):
+    """xs_icp_accumulate_posted: the launch is resident before its pose exists, starts when
+    xs_icp_post_pose writes the mailbox, and produces the sums of xs_icp_accumulate bit for bit; a
+    stale sequence number does not start it; cmd = 1 makes it return without writing anything.
+    Mailbox from xs_icp_mailbox_alloc (device memory behind the large BAR where there is one) and in
+    host-coherent pinned memory."""
+    import time
+    torch, capi = dev
+    prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
+    k = intr_of(prm)
+    Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    dv = [to_dev(torch, x) for x in (cv, cn, pv, pn)]
+    assert capi.icp_mailbox_bytes() == 128
+    if where == "alloc":
+        mailbox, in_dev = capi.icp_mailbox_alloc()
+        free = lambda: capi.icp_mailbox_free(mailbox, in_dev)
+    else:
+        mailbox, free = _coherent_host_bytes(128)
+    try:
+        R = np.asarray(T0["Rc2w"], np.float32).reshape(3, 3, 2)
+        t = np.asarray(T0["tc2w"], np.float32).reshape(3, 2)
+        for seq, dt in ((5, 0.0), (6, 0.004)):
+            tt = t.copy(); tt[0, 0] += dt
+            ref = torch.zeros(55, dtype=torch.float64, device="cuda")
+            capi.icp_accumulate(R, tt, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, ref)
+            torch.cuda.synchronize()
+            sums = torch.full((55,), 7.0, dtype=torch.float64, device="cuda")
+            done = torch.cuda.Event()
+            capi.icp_accumulate_posted(mailbox, seq, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, sums)
+            done.record()
+            time.sleep(0.02)
+            assert not done.query(), "the launch must wait for its sequence number (the mailbox holds an older one)"
+            capi.icp_post_pose(mailbox, R, tt, seq)
+            torch.cuda.synchronize()
+            assert np.array_equal(sums.cpu().numpy(), ref.cpu().numpy())
+            assert ref.cpu().numpy()[54] > 1000
+        # abandon: nothing written, ticket untouched (the next ordinary launch still works)
+        sums = torch.full((55,), 7.0, dtype=torch.float64, device="cuda")
+        capi.icp_accumulate_posted(mailbox, 9, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, sums)
+        capi.icp_post_pose(mailbox, None, None, 9, cmd=1)
+        torch.cuda.synchronize()
+        assert np.all(sums.cpu().numpy() == 7.0)
+        again = torch.zeros(55, dtype=torch.float64, device="cuda")
+        capi.icp_accumulate(R, tt, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, again)
+        torch.cuda.synchronize()
+        assert np.array_equal(again.cpu().numpy(), ref.cpu().numpy())
+    finally:
+        torch.cuda.synchronize()
+        free()
+
+
+def test_icp_posted_pose_gives_up(dev):
+    """A launch whose pose is never posted must not hold the GPU: it leaves after about a second,
+    writes nothing, and reports done_seq | 1<<63 through the completion word."""
+    import ctypes as C, time
+    torch, capi = dev
+    nanmap = torch.full((3 * 60, 80, 2), float("nan"), dtype=torch.float32, device="cuda")
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    host, free = _coherent_host_bytes(256)
+    try:
+        I = np.zeros((3, 3, 2), np.float32); I[[0, 1, 2], [0, 1, 2], 0] = 1
+        sums = torch.full((55,), 7.0, dtype=torch.float64, device="cuda")
+        t0 = time.time()
+        capi.icp_accumulate_posted(host, 3, nanmap, nanmap, I, np.zeros(6), [100, 100, 40, 30], nanmap, nanmap, 80 * 8, 60, 80, 0.1, 0.2,
+                                   ws, sums, done_flag=host + 128, done_seq=41)
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 20.0
+        assert C.c_ulonglong.from_address(host + 128).value == (41 | (1 << 63))
+        assert np.all(sums.cpu().numpy() == 7.0)
+    finally:
+        torch.cuda.synchronize()
+        free()
+
+
 def test_icp_iterate_singular_system_stops_the_loop(dev):
     """No valid pixel: zero sums, |det| < 1e-15 -> status 1, pose untouched; the next launch returns at
     once (sums buffer not written), as PoseEstimate returns 0 on the host (KinectFusionReconstruction.cpp:203-210)."""

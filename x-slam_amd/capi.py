@@ -76,6 +76,12 @@ _SIGS = {
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                     C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_icp_pose_state_bytes": (_sz, []),
+    "xs_icp_mailbox_bytes": (_sz, []),
+    "xs_icp_mailbox_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "xs_icp_mailbox_free": (C.c_int, [_vp, C.c_int]),
+    "xs_icp_accumulate_posted": (C.c_int, [_vp, C.c_uint, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
+                                           C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
+    "xs_icp_post_pose": (None, [_vp, _f32p, _f32p, C.c_uint, C.c_int]),
     "xs_icp_iterate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                  C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_estimate_combined": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -330,6 +336,43 @@ def icp_iterate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap
     check(_lib.xs_icp_iterate(pa, pb, _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
                               map_step, rows, cols, distThres, angleThres, _ptr(workspace), _ptr(sums), None, _ptr(pose_state), None, None, 0,
                               _stream(stream)))
+
+
+def icp_accumulate_posted(mailbox, mailbox_seq, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows,
+                          cols, distThres, angleThres, workspace, sums, y0=0, y1=None, stream=None, done_flag=None, done_seq=0):
+    """Enqueue an ICP reduction whose pose arrives later through `mailbox` (a 128-byte tensor in pinned
+    host memory, see icp_post_pose).  The launch polls until the sequence number shows up — post it, or
+    the launch gives up after about a second."""
+    c, d, k = _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    check(_lib.xs_icp_accumulate_posted(_ptr(mailbox), mailbox_seq, _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev),
+                                        _ptr(nmap_g_prev), map_step, rows, cols, distThres, angleThres, y0, rows if y1 is None else y1,
+                                        _ptr(workspace), _ptr(sums), _ptr(done_flag), done_seq, _stream(stream)))
+
+
+def icp_post_pose(mailbox, Rcurr, tcurr, mailbox_seq, cmd=0):
+    """Host side of the pose mailbox: cmd 0 = run with this pose, 1 = abandon the launch."""
+    P = lambda x: x.ctypes.data_as(_f32p)
+    if Rcurr is None:
+        _lib.xs_icp_post_pose(_ptr(mailbox), None, None, mailbox_seq, cmd)
+    else:
+        a, b = _fa(Rcurr, 18), _fa(tcurr, 6)
+        _lib.xs_icp_post_pose(_ptr(mailbox), P(a), P(b), mailbox_seq, cmd)
+
+
+def icp_mailbox_bytes():
+    return int(_lib.xs_icp_mailbox_bytes())
+
+
+def icp_mailbox_alloc():
+    """(address, in_device_memory) of a zeroed pose mailbox; release with icp_mailbox_free."""
+    p, dev = C.c_void_p(), C.c_int(0)
+    check(_lib.xs_icp_mailbox_alloc(C.byref(p), C.byref(dev)))
+    return p.value, dev.value
+
+
+def icp_mailbox_free(address, in_device_memory):
+    check(_lib.xs_icp_mailbox_free(address, in_device_memory))
 
 
 def estimate_combined(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,

@@ -35,6 +35,9 @@ struct IcpArgs {
     // optional device-side pose update (xs_icp_iterate): the last workgroup solves for the increment and
     // composes it into *pose, which the next launch reads instead of Rcurr / tcurr above
     IcpPoseState *pose; IcpPoseState *pose_host; int load_pose;
+    // optional posted pose (xs_icp_accumulate_posted): the launch was enqueued before its pose was known and
+    // picks it up from a 128-byte mailbox in host-coherent pinned memory once the host has posted mailbox_seq
+    const unsigned *mailbox; unsigned mailbox_seq;
 };
 
 namespace {
@@ -84,21 +87,33 @@ __device__ __forceinline__ void publish_done(const IcpArgs &a) {
     __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// POSE_IN_MEMORY = false: Rcurr / tcurr are kernel arguments (xs_icp_accumulate, first iteration of
-// xs_icp_iterate).  true: they are what k_icp_solve left in device memory after the previous iteration.
-template <bool POSE_IN_MEMORY>
+// Pose mailbox (xs_icp_post_pose writes it, k_icp<POSE_POSTED> polls it; xs_icp_mailbox_alloc puts it in
+// device memory the CPU reaches through the large BAR, so polling stays off the PCIe link — 512
+// workgroups polling pinned host memory cost 50 us per iteration): two 64-byte lines of 16
+// words, each line starting with the sequence number so that a line read as one unit is known to
+// be complete:   line 0 = {seq, cmd, f[0..13]}   line 1 = {seq, 0, f[14..23], pad}   with f = the 18
+// floats of Rcurr followed by the 6 of tcurr; cmd 0 = run, 1 = abandon the launch.
+enum { POSE_ARGS = 0, POSE_DEVICE = 1, POSE_POSTED = 2 };
+enum { MAILBOX_WORDS = 32, MAILBOX_MAX_POLLS = 400000 };  // ~2 us per poll: gives up after about a second
+constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
+
+// POSE_ARGS: Rcurr / tcurr are kernel arguments (xs_icp_accumulate, first iteration of xs_icp_iterate).
+// POSE_DEVICE: they are what k_icp_solve left in device memory after the previous iteration.
+// POSE_POSTED: the host posts them while this launch is already resident — the launch latency of an
+// iteration (~4 us) overlaps the previous iteration's epilogue and the host's solve.
+template <int POSE_SRC>
 __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
-    if (POSE_IN_MEMORY) {
+    // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel
+    // arguments they replace)
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    if (POSE_SRC == POSE_DEVICE) {
         // the pose left by the previous launch on this stream; a failed solve ends the loop
         if (a.pose->status != 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0 && a.done_flag) publish_done(a);
             return;
         }
-        // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel
-        // arguments they replace)
-        auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
         const float *pr = a.pose->R, *pt = a.pose->t;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -107,6 +122,38 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
             Rcurr.data[r].z = cfloat(uni(pr[6 * r + 4]), uni(pr[6 * r + 5]));
         }
         tcurr.x = cfloat(uni(pt[0]), uni(pt[1])); tcurr.y = cfloat(uni(pt[2]), uni(pt[3])); tcurr.z = cfloat(uni(pt[4]), uni(pt[5]));
+    }
+    if (POSE_SRC == POSE_POSTED) {
+        // One wave per workgroup polls the mailbox (system-scope loads: never cached) until
+        // both lines carry this launch's sequence number, then hands the 32 words to the others through
+        // LDS.  Bounded: after MAILBOX_MAX_POLLS the launch gives up and says so in the completion word.
+        __shared__ unsigned s_mail[MAILBOX_WORDS];
+        if (threadIdx.x < 64) {
+            unsigned v = 0, cmd_override = 0;
+            for (int polls = 0;; ++polls) {
+                v = __hip_atomic_load(a.mailbox + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
+                if (s0 == a.mailbox_seq && s1 == a.mailbox_seq) break;
+                if (polls >= MAILBOX_MAX_POLLS) { cmd_override = 2; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (threadIdx.x < MAILBOX_WORDS) s_mail[threadIdx.x] = threadIdx.x == 1 && cmd_override ? cmd_override : v;
+        }
+        __syncthreads();
+        const unsigned cmd = s_mail[1];
+        if (cmd != 0) {
+            if (cmd == 2 && threadIdx.x == 0 && a.done_flag)
+                __hip_atomic_store(a.done_flag, a.done_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        auto word = [&](int i) { return uni(__uint_as_float(s_mail[i < 14 ? 2 + i : 18 + (i - 14)])); };
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Rcurr.data[r].x = cfloat(word(6 * r + 0), word(6 * r + 1));
+            Rcurr.data[r].y = cfloat(word(6 * r + 2), word(6 * r + 3));
+            Rcurr.data[r].z = cfloat(word(6 * r + 4), word(6 * r + 5));
+        }
+        tcurr.x = cfloat(word(18), word(19)); tcurr.y = cfloat(word(20), word(21)); tcurr.z = cfloat(word(22), word(23));
     }
     double acc[NS];
 #pragma unroll
@@ -358,8 +405,8 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
                       const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev, size_t map_step, int rows,
                       int cols, float distThres, float angleThres, int y0, int y1, void *workspace, double *sums_dev,
                       unsigned long long *done_flag, unsigned long long done_seq, IcpPoseState *pose, IcpPoseState *pose_host, double *sums_host,
-                      void *stream, const char *who) {
-    if ((!pose && (!Rcurr18 || !tcurr6)) || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
+                      void *stream, const char *who, const void *mailbox = nullptr, unsigned mailbox_seq = 0) {
+    if ((!pose && !mailbox && (!Rcurr18 || !tcurr6)) || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
         !workspace || !sums_dev)
         return xs_set_error(hipErrorInvalidValue, who);
     if (y0 < 0 || y1 > rows || y1 < y0) return xs_set_error(hipErrorInvalidValue, "xs_icp: bad row range");
@@ -375,6 +422,7 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
     a.partials = (double *)((char *)workspace + 256);
     a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
     a.pose = pose; a.pose_host = pose_host; a.load_pose = (pose && Rcurr18) ? 1 : 0;
+    a.mailbox = nullptr; a.mailbox_seq = 0;
     const int tiles = div_up(cols, 64) * (y1 - y0);
     int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
     if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
@@ -386,11 +434,14 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
         sa.sums = sums_dev; sa.sums_host = sums_host; sa.Rcurr = a.Rcurr; sa.tcurr = a.tcurr; sa.load_pose = a.load_pose;
         sa.pose = pose; sa.pose_host = pose_host; sa.done_flag = done_flag; sa.done_seq = done_seq;
         a.done_flag = nullptr;
-        if (a.load_pose) hipLaunchKernelGGL(k_icp<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(k_icp<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        if (a.load_pose) hipLaunchKernelGGL(k_icp<POSE_ARGS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_icp<POSE_DEVICE>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(128), 0, (hipStream_t)stream, sa);
+    } else if (mailbox) {
+        a.mailbox = (const unsigned *)mailbox; a.mailbox_seq = mailbox_seq;
+        hipLaunchKernelGGL(k_icp<POSE_POSTED>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     } else
-        hipLaunchKernelGGL(k_icp<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_icp<POSE_ARGS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -415,6 +466,82 @@ extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, cons
     return icp_launch(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
                       distThres, angleThres, y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream,
                       "xs_icp_accumulate: null pointer");
+}
+
+/* estimateCombined with the pose posted after the launch.  The launch is enqueued while the previous
+ * iteration is still running; its workgroups become resident, poll `mailbox` (xs_icp_mailbox_bytes()
+ * bytes of host-coherent pinned memory, zero before first use) and start on the pixels as soon as
+ * xs_icp_post_pose has written Rcurr / tcurr with sequence number mailbox_seq — what is left of an
+ * iteration's turnaround is the host's solve and one PCIe read instead of a kernel launch.
+ * xs_icp_post_pose(..., cmd = 1) makes the launch return without touching anything (the host left
+ * the loop: singular system).  A launch whose pose never arrives gives up after about a second and
+ * stores done_seq | 1<<63 to done_flag; re-initialise the workspace (xs_icp_workspace_init) after that.
+ * Everything else as xs_icp_accumulate. */
+extern "C" size_t xs_icp_mailbox_bytes(void) { return MAILBOX_WORDS * sizeof(unsigned); }
+extern "C" int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_seq, const float *vmap_curr, const float *nmap_curr,
+                                        const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                                        const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
+                                        int y0, int y1, void *workspace, double *sums_dev, unsigned long long *done_flag,
+                                        unsigned long long done_seq, void *stream) {
+    if (!mailbox) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_posted: null pointer");
+    return icp_launch(nullptr, nullptr, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
+                      distThres, angleThres, y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream,
+                      "xs_icp_accumulate_posted: null pointer", mailbox, mailbox_seq);
+}
+/* Host side of the mailbox: the payload first, the two sequence words last (the poller accepts a
+ * line only with its sequence word, and a 64-byte line is read as one unit).  The mailbox may be
+ * device memory mapped through the PCIe BAR (write-combining on the CPU side): the store fences push
+ * the payload out before the sequence words, and the sequence words out before returning. */
+static inline void store_fence() {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+extern "C" void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const float *tcurr6, unsigned mailbox_seq, int cmd) {
+    volatile unsigned *w = (volatile unsigned *)mailbox_host;
+    unsigned f[24] = {0};
+    if (Rcurr18) memcpy(f, Rcurr18, 18 * sizeof(float));
+    if (tcurr6) memcpy(f + 18, tcurr6, 6 * sizeof(float));
+    w[1] = (unsigned)cmd;
+    for (int i = 0; i < 14; ++i) w[2 + i] = f[i];
+    w[17] = 0;
+    for (int i = 0; i < 10; ++i) w[18 + i] = f[14 + i];
+    store_fence();
+    w[0] = mailbox_seq;
+    w[16] = mailbox_seq;
+    store_fence();
+}
+/* A mailbox where polling is cheapest: fine-grained device memory the CPU writes through the large
+ * BAR (512 workgroups then poll local memory, not the PCIe link), or — without a large BAR —
+ * host-coherent pinned memory.  Zeroed.  *in_device_memory (optional) says which one it is. */
+extern "C" int xs_icp_mailbox_alloc(void **mailbox, int *in_device_memory) {
+    if (!mailbox) return xs_set_error(hipErrorInvalidValue, "xs_icp_mailbox_alloc: null pointer");
+    int dev = 0, large_bar = 0;
+    XS_CHECK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
+    const char *force_host = getenv("XS_ICP_MAILBOX_HOST");
+    void *p = nullptr;
+    if (large_bar && !(force_host && force_host[0] == '1') &&
+        hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+        XS_CHECK(hipMemset(p, 0, 4096));
+        XS_CHECK(hipDeviceSynchronize());
+        if (in_device_memory) *in_device_memory = 1;
+    } else {
+        (void)hipGetLastError();
+        XS_CHECK(hipHostMalloc(&p, 4096, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(p, 0, 4096);
+        if (in_device_memory) *in_device_memory = 0;
+    }
+    *mailbox = p;
+    return 0;
+}
+extern "C" int xs_icp_mailbox_free(void *mailbox, int in_device_memory) {
+    if (!mailbox) return 0;
+    if (in_device_memory) XS_CHECK(hipFree(mailbox));
+    else XS_CHECK(hipHostFree(mailbox));
+    return 0;
 }
 
 /* One whole ICP iteration on the device: estimateCombined (ICP.cu:365-429) followed by the pose

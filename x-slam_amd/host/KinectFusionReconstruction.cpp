@@ -33,6 +33,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
+    if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
     for (int i = 0; i < 2; ++i) {
         if (ingest_pinned_[i]) { (void)hipEventSynchronize(ingest_done_[i]); (void)hipHostFree(ingest_pinned_[i]); (void)hipEventDestroy(ingest_done_[i]); }
     }
@@ -103,6 +104,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     zs1 = shard_count > 1 ? std::min(resolutionZ, zo1 + HALO) : resolutionZ;
     icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
     icp_shard_rows = config.as<bool>("icp_shard_rows", false);
+    icp_post_pose = config.as<bool>("icp_post_pose", true);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
@@ -143,6 +145,7 @@ void KinectFusionReconstruction::AllocateBuffers() {
         integrate_ws_.create(xs_integrate_workspace_bytes(res, zs1 - zs0));
         icp_ws_.create(xs_icp_workspace_bytes());
         check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
+        if (!icp_mailbox_) check_rc(xs_icp_mailbox_alloc(&icp_mailbox_, &icp_mailbox_in_device_), "icp mailbox");
         icp_sums_.create(64);
         icp_pose_.create(xs_icp_pose_state_bytes());
         ray_ws_.create((size_t)depth_width * depth_height);
@@ -269,20 +272,72 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
     const bool icp_local = shard_count == 1 || !icp_shard_rows;  // this rank evaluates every pixel row itself
     if (icp_solve_on_device && icp_local && !profiling_icp_sync && total_iters >= 1 && total_iters <= ICP_LOG_MAX)
         return PoseEstimateOnDevice(Rcurr, tcurr, Rprev_inv, tprev, c2w_curr, total_iters);
+    // posted mode: launch n + 1 is enqueued before the host waits for launch n, and gets its pose through
+    // the mailbox after the solve (xs_icp_accumulate_posted)
+    const bool posted = icp_post_pose && icp_local && !profiling_icp_sync && total_iters >= 1;
+    std::vector<int> level_of;
+    for (int level_index = num_levels - 1; level_index >= 0; --level_index)
+        for (int iter = 0; iter < icp_iterations[level_index]; ++iter) level_of.push_back(level_index);
+    if (posted && !icp_mailbox_) check_rc(xs_icp_mailbox_alloc(&icp_mailbox_, &icp_mailbox_in_device_), "icp mailbox");
+    void *mailbox = icp_mailbox_;
+    unsigned long long seq_of_launch = 0;
+    auto launch_local = [&](int level, const MatS33 *R, const devComplex3 *t, unsigned mail_seq) {
+        MapArr &vc = vmaps_curr_d[level], &nc = nmaps_curr_d[level], &vp = vmaps_g_prev_d[level], &np_ = nmaps_g_prev_d[level];
+        const Intr k = kinect_intrinsic(level);
+        const int rows = vc.rows() / 3, cols = vc.cols();
+        unsigned long long *flag = reinterpret_cast<unsigned long long *>(pinned_sums_ + 56);
+        const unsigned long long seq = ++icp_seq_;
+        if (R)
+            check_rc(xs_icp_accumulate(&R->data[0].x.re, &t->x.re, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
+                                       &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres,
+                                       0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq, current_stream()), "estimateCombined");
+        else
+            check_rc(xs_icp_accumulate_posted(mailbox, mail_seq, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
+                                              &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres,
+                                              angleThres, 0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq, current_stream()),
+                     "estimateCombined (posted)");
+        return seq;
+    };
     stage_begin(ST_ICP);
-    for (int level_index = num_levels - 1; level_index >= 0; --level_index) {
-        MapArr &vmap_curr = vmaps_curr_d[level_index];
-        MapArr &nmap_curr = nmaps_curr_d[level_index];
-        MapArr &vmap_g_prev = vmaps_g_prev_d[level_index];
-        MapArr &nmap_g_prev = nmaps_g_prev_d[level_index];
-        const int iter_num = icp_iterations[level_index];
-        for (int iter = 0; iter < iter_num; ++iter) {
+    for (int n = 0; n < total_iters; ++n) {
+        {
+            const int level_index = level_of[n];
             auto &device_Rcurr = device_cast<MatS33>(Rcurr);
             auto &device_tcurr = device_cast<devComplex3>(tcurr);
             hostComplexICP A[36], b[6];
             long long inliers = 0;
-            (void)vmap_curr; (void)nmap_curr; (void)vmap_g_prev; (void)nmap_g_prev;
-            icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
+            bool next_enqueued = false;
+            unsigned next_mail_seq = 0;
+            if (posted) {
+                if (n == 0) seq_of_launch = launch_local(level_index, &device_Rcurr, &device_tcurr, 0);
+                const unsigned long long seq = seq_of_launch;
+                if (n + 1 < total_iters) {
+                    next_mail_seq = (unsigned)(icp_seq_ + 1);
+                    if (next_mail_seq == 0) next_mail_seq = 1u << 31;  // never the mailbox's initial word
+                    seq_of_launch = launch_local(level_of[n + 1], nullptr, nullptr, next_mail_seq);
+                    next_enqueued = true;
+                }
+                volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
+                long spins = 0;
+                unsigned long long seen;
+                while ((seen = *flag) != seq) {
+                    if (seen == (seq | (1ull << 63)) || ++spins > 2000000000L) {  // never expected: the launch gave up on its pose
+                        if (next_enqueued) xs_icp_post_pose(mailbox, nullptr, nullptr, next_mail_seq, 1);
+                        hipSafeCall(hipStreamSynchronize(current_stream()));
+                        check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
+                        stage_end(ST_ICP);
+                        std::cout << "error::KinectFusionReconstruction, ICP launch timed out waiting for its pose" << std::endl;
+                        return 0;
+                    }
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                xs_icp_unpack(pinned_sums_, reinterpret_cast<double *>(A), reinterpret_cast<double *>(b));
+                inliers = (long long)pinned_sums_[54];
+            } else
+                icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
             {   // diagnostics: re-pack the 27 sums in launch order
                 int shift = 0;
                 for (int i = 0; i < 6; ++i)
@@ -295,6 +350,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
             }
             const double det = real_determinant6(A);
             if (fabs(det) < 1e-15 || std::isnan(det)) {
+                if (next_enqueued) xs_icp_post_pose(mailbox, nullptr, nullptr, next_mail_seq, 1);  // the enqueued launch returns at once
                 if (std::isnan(det)) std::cout << "qnan det" << std::endl;
                 else std::cout << "eps det: " << fabs(det) << std::endl;
                 stage_end(ST_ICP);
@@ -310,6 +366,8 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
             Vector3cf rt = Rinc * tcurr;
             for (int i = 0; i < 3; ++i) tcurr[i] = rt[i] + tinc[i];
             Rcurr = Rinc * Rcurr;
+            if (next_enqueued)
+                xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rcurr).data[0].x.re, &device_cast<devComplex3>(tcurr).x.re, next_mail_seq, 0);
             for (int i = 0; i < 3; ++i) {
                 for (int j = 0; j < 3; ++j) c2w_curr(i, j) = Rcurr(i, j);
                 c2w_curr(i, 3) = tcurr[i];

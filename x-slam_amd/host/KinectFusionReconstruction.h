@@ -77,6 +77,13 @@ public:
     // per iteration slower on this machine (a serial double-precision Cholesky + substitution is ~9000
     // cycles for one wave), kept for hosts that cannot spin.  YAML key icp_solve_on_device.
     bool icp_solve_on_device = false;
+    // true (default): each iteration's launch is enqueued while the previous one is still running and
+    // receives its pose through a pinned-memory mailbox once the host has solved for it
+    // (xs_icp_accumulate_posted / xs_icp_post_pose): the launch latency leaves the per-iteration
+    // turnaround.  Same kernel arithmetic, same poses.  false: launch after the solve (the reference's
+    // order).  Applies when this rank evaluates whole images (not with icp_shard_rows).  YAML key
+    // icp_post_pose.
+    bool icp_post_pose = true;
     // Sharded runs (SetSharding): false (default) — every rank evaluates the whole ICP itself; all ranks hold
     // the same current-frame maps and the composited previous-frame maps, the reduction is deterministic,
     // so they reach the same pose bit for bit with no collective inside the ICP loop.  true — pixel rows
@@ -170,6 +177,8 @@ private:
     // device-side loop, [128 + 64*n ..) the 55 values of its iteration n
     enum { ICP_LOG_MAX = 62, PINNED_DOUBLES = 128 + 64 * ICP_LOG_MAX };
     double *pinned_sums_ = nullptr;
+    void *icp_mailbox_ = nullptr;              // pose mailbox of the posted ICP launches (xs_icp_mailbox_alloc)
+    int icp_mailbox_in_device_ = 0;
     unsigned long long icp_seq_ = 0;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
     hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr;
