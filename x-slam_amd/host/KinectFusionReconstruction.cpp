@@ -18,7 +18,8 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     hipSafeCall(hipEventCreateWithFlags(&surface_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
-    hipSafeCall(hipHostMalloc((void **)&pinned_counters_, PROF_RING * 2 * sizeof(unsigned long long)));
+    hipSafeCall(hipEventCreateWithFlags(&scale_done_, hipEventDisableTiming));
+    hipSafeCall(hipHostMalloc((void **)&pinned_counters_, COUNTER_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, PINNED_DOUBLES * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < PINNED_DOUBLES; ++i) pinned_sums_[i] = 0.0;
 }
@@ -31,6 +32,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (surface_done_) (void)hipEventDestroy(surface_done_);
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
+    if (scale_done_) (void)hipEventDestroy(scale_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
     if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
@@ -154,8 +156,8 @@ void KinectFusionReconstruction::AllocateBuffers() {
             ray_min_keys_.create((size_t)depth_width * depth_height);
         }
     }
-    counters_.create(2);  // [0] updated voxels, [1] raycast hits
-    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), current_stream()));
+    counters_.create(2 * COUNTER_RING);
+    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * COUNTER_RING * sizeof(unsigned long long), current_stream()));
     depth_max_.create(4);
 }
 
@@ -499,7 +501,13 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     hipStream_t st = current_stream();
-    hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * sizeof(unsigned long long), st));
+    // this frame's counter slot; entering a half of the ring clears that half (its frames were folded or
+    // abandoned at least COUNTER_RING / 2 frames ago)
+    if (counter_frame_ % (COUNTER_RING / 2) == 0 && counter_frame_ > 0)
+        hipSafeCall(hipMemsetAsync(frame_counters(), 0, (COUNTER_RING / 2) * 2 * sizeof(unsigned long long), st));
+    unsigned long long *counters = frame_counters();
+    // the depth scaling ran on the auxiliary stream behind the map preparation
+    if (scale_recorded_) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
     float *depth_max_dev = depth_max_.ptr();  // filled with the scaled depth by SurfaceMeasure, on the auxiliary stream
     // integrateTsdfVolume (TsdfFusion.cu:173-201), its two launches timed separately
     const int res[3] = {volume_res.x, volume_res.y, volume_res.z};
@@ -522,7 +530,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             check_rc(xs_integrate_scaled(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
                                          &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
                                          &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
-                                         grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters_.ptr() : nullptr,
+                                         grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters : nullptr,
                                          depth_max_dev, integrate_ws_.ptr(), st), "integrateTsdfVolume");
             if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);
         }
@@ -531,11 +539,14 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     hipSafeCall(hipEventRecord(integrate_done_, st));
     integrate_recorded_ = true;
     stage_begin(ST_RAYCAST);
+    hits_counter_ = counters + 1;
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
+    hits_counter_ = nullptr;
     stage_end(ST_RAYCAST);
     stage_begin(ST_RESIZE);
     ModelMapPyramid();
     stage_end(ST_RESIZE);
+    ++counter_frame_;
     return 1;
 }
 
@@ -601,8 +612,11 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
             }
     }
     stage_end(ST_SURFACE);
+    // the ICP needs the maps and nothing else of this stream: the main stream picks them up here, not
+    // behind the depth scaling below (two more kernels and their packets in front of the first ICP launch)
+    hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
     // scaleDepthKernal of integrateTsdfVolume (TsdfFusion.cu:182-187) also depends on the depth image
-    // alone: metres + the frame's largest valid depth, ready before integrate needs them
+    // alone: metres + the frame's largest valid depth, ready long before integrate asks for them
     // (the previous frame's integrate, possibly still running on the main stream, reads the same
     // buffers: wait for it — it is the first thing in that frame's tail)
     if (integrate_recorded_) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_, 0));
@@ -611,7 +625,8 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
                                 depthRawScaled_d.step(), depth_max_.ptr(), aux_stream_), "scaleDepth");
     stage_end(ST_SCALE);
-    hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
+    hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
+    scale_recorded_ = true;
     current_stream() = main_stream;
     hipSafeCall(hipStreamWaitEvent(main_stream, surface_done_, 0));
 }
@@ -635,7 +650,7 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.z = volume_resolution.z();
     if (shard_count == 1 && !force_shard_composite) {
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
-                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, counters_.ptr() + 1, ray_ws_.ptr());
+                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, hits_counter_, ray_ws_.ptr());
         return 0;
     }
     // sharded: march this rank's planes, agree on the first event of every ray, add the winners
@@ -660,7 +675,7 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
         }
     }
     check_rc(xs_raycast_compose_finish(ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols,
-                                       counters_.ptr() + 1, st), "raycast");
+                                       hits_counter_, st), "raycast");
     return 0;
 }
 
@@ -773,15 +788,14 @@ bool KinectFusionReconstruction::CPointCloud::exportPly(const std::string &filen
 
 void KinectFusionReconstruction::synchronize() { hipSafeCall(hipStreamSynchronize(current_stream())); }
 
-long long KinectFusionReconstruction::lastUpdatedVoxels() {
-    unsigned long long h[2];
-    counters_.download(h);
-    return (long long)h[0];
-}
-long long KinectFusionReconstruction::lastRaycastHits() {
-    unsigned long long h[2];
-    counters_.download(h);
-    return (long long)h[1];
+long long KinectFusionReconstruction::lastUpdatedVoxels() { return last_frame_counter(0); }
+long long KinectFusionReconstruction::lastRaycastHits() { return last_frame_counter(1); }
+long long KinectFusionReconstruction::last_frame_counter(int which) {
+    if (counter_frame_ == 0) return 0;
+    unsigned long long h[2] = {0, 0};
+    synchronize();
+    hipSafeCall(hipMemcpy(h, counters_.ptr() + 2 * (size_t)((counter_frame_ - 1) % COUNTER_RING), sizeof(h), hipMemcpyDeviceToHost));
+    return (long long)h[which];
 }
 
 // ---- volume checkpoint --------------------------------------------------------------------
@@ -843,7 +857,8 @@ bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
 }
 
 // ---- per-stage HIP event timing (on the stream the kernels are launched on) -----------------
-void KinectFusionReconstruction::set_profiling(bool on) {
+void KinectFusionReconstruction::set_profiling(int level) {
+    const bool on = level > 0;
     if (on && prof_ring_.empty()) {
         prof_ring_.resize(PROF_RING);
         for (auto &slot : prof_ring_)
@@ -853,29 +868,34 @@ void KinectFusionReconstruction::set_profiling(bool on) {
                 slot.used[s] = false;
             }
     }
-    if (!on && profiling) collect_stage_times();
+    if (profiling) collect_stage_times();
     profiling = on;
+    profiling_stages = level > 1;
 }
 void KinectFusionReconstruction::stage_begin(int st) {
-    if (!profiling) return;
+    if (!profiling_stages) return;
     hipSafeCall(hipEventRecord(prof_ring_[prof_pending_].ev[st][0], current_stream()));
 }
 void KinectFusionReconstruction::stage_end(int st) {
-    if (!profiling) return;
+    if (!profiling_stages) return;
     hipSafeCall(hipEventRecord(prof_ring_[prof_pending_].ev[st][1], current_stream()));
     prof_ring_[prof_pending_].used[st] = true;
 }
 void KinectFusionReconstruction::end_profiled_frame() {
-    // counters of this frame -> pinned ring, asynchronously; nothing waits here
-    hipSafeCall(hipMemcpyAsync(pinned_counters_ + 2 * prof_pending_, counters_.ptr(), 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                               current_stream()));
+    // nothing is enqueued here: the frame's counters stay in their ring slot until the pending frames are folded
     if (++prof_pending_ == PROF_RING) collect_stage_times();
 }
 void KinectFusionReconstruction::collect_stage_times() {
     synchronize();
+    if (prof_pending_ > 0)
+        hipSafeCall(hipMemcpy(pinned_counters_, counters_.ptr(), COUNTER_RING * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int f = 0; f < prof_pending_; ++f) {
-        cum_updated += (long long)pinned_counters_[2 * f];
-        cum_hits += (long long)pinned_counters_[2 * f + 1];
+        // pending frame f is the (prof_pending_ - f)-th most recent integrated frame
+        const long long fr = counter_frame_ - prof_pending_ + f;
+        if (fr >= 0) {
+            cum_updated += (long long)pinned_counters_[2 * (fr % COUNTER_RING)];
+            cum_hits += (long long)pinned_counters_[2 * (fr % COUNTER_RING) + 1];
+        }
         for (int s = 0; s < ST_COUNT; ++s) {
             if (!prof_ring_[f].used[s]) continue;
             float ms = 0.f;

@@ -154,10 +154,18 @@ public:
     // counters of the last frame (synchronise the stream)
     long long lastUpdatedVoxels();
     long long lastRaycastHits();
+    long long last_frame_counter(int which);
     void synchronize();
 
 private:
-    DeviceArray<unsigned long long> counters_;  // [0] updated voxels, [1] raycast hits
+    // Per-frame diagnostics counters ([0] updated voxels, [1] raycast hits) live in a device ring, one slot
+    // per frame; half of the ring is cleared by one fill every COUNTER_RING / 2 frames instead of one fill
+    // (and, when profiling, one download) per frame on the critical stream.
+    enum { COUNTER_RING = 512 };
+    DeviceArray<unsigned long long> counters_;  // [COUNTER_RING][2]
+    long long counter_frame_ = 0;               // frames integrated so far = next slot to use
+    unsigned long long *frame_counters() { return counters_.ptr() + 2 * (size_t)(counter_frame_ % COUNTER_RING); }
+    unsigned long long *hits_counter_ = nullptr;  // set while IntegrateFrame runs the raycast
     DeviceArray<float> depth_max_;              // [0] largest valid depth of the frame (scale kernel -> integrate far clip)
     DeviceArray<unsigned char> integrate_ws_;  // brick work list of the integrate kernel
     DeviceArray<unsigned char> icp_ws_;        // per-workgroup partial records of the ICP reduction
@@ -181,8 +189,8 @@ private:
     int icp_mailbox_in_device_ = 0;
     unsigned long long icp_seq_ = 0;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
-    hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr;
-    bool integrate_recorded_ = false;
+    hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr, scale_done_ = nullptr;
+    bool integrate_recorded_ = false, scale_recorded_ = false;
     bool profiling_icp_sync = false;           // true: copy + stream synchronise instead of the spin (debug aid)
     int PoseEstimateOnDevice(Matrix3frm Rcurr, Vector3cf tcurr, const Matrix3frm &Rprev_inv, const Vector3cf &tprev, Matrix4cf c2w_curr,
                              int total_iters);
@@ -190,16 +198,20 @@ private:
                               hostComplexICP *A, hostComplexICP *b, long long *inliers);
     // deferred profiling: one slot of events + one pinned counter record per frame, folded into
     // stage_ms / cum_* only when somebody asks (no per-frame synchronisation)
-    enum { PROF_RING = 1024 };
+    enum { PROF_RING = COUNTER_RING / 2 };
     struct ProfSlot { hipEvent_t ev[ST_COUNT][2]; bool used[ST_COUNT]; };
     std::vector<ProfSlot> prof_ring_;
     int prof_pending_ = 0;
-    unsigned long long *pinned_counters_ = nullptr;  // [PROF_RING][2]
+    unsigned long long *pinned_counters_ = nullptr;  // [COUNTER_RING][2]: the ring, downloaded when the pending frames are folded
     void stage_begin(int st);
     void stage_end(int st);
     void end_profiled_frame();
 public:
     void collect_stage_times();  // synchronises and folds the pending frames
-    void set_profiling(bool on);
+    // level 0: off.  1: the integrate kernel's own event pair + the counters (what bench.py's timed region
+    // needs; nothing extra on the stream between kernels).  2: an event pair around every stage as well —
+    // each record is a packet the next kernel has to queue behind, so stage times come from their own pass.
+    void set_profiling(int level);
+    bool profiling_stages = false;
 private:
 };

@@ -178,7 +178,7 @@ void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes) {
     return a.ptr();
 }
 
-void xs_kf_set_profiling(void *kf, int on) { ((KF *)kf)->set_profiling(on != 0); }
+void xs_kf_set_profiling(void *kf, int level) { ((KF *)kf)->set_profiling(level); }
 void xs_kf_stage_times(void *kf, double *ms6, long long *calls6) {
     KF *k = (KF *)kf;
     if (k->profiling) k->collect_stage_times();

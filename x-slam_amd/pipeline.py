@@ -226,8 +226,9 @@ class KinectFusion:
         p = _lib.xs_kf_volume_ptr(self.h, {"value": 0, "weight": 1, "grad": 2}[which], C.byref(step))
         return p, step.value
 
-    def set_profiling(self, on=True):
-        _lib.xs_kf_set_profiling(self.h, 1 if on else 0)
+    def set_profiling(self, level=2):
+        """0 off, 1 integrate-kernel events + counters only, 2 (True) every stage."""
+        _lib.xs_kf_set_profiling(self.h, 2 if level is True else int(level))
 
     def stage_times(self):
         ms = np.zeros(6, np.float64)
