@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
                 const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
                 if (s0 == a.mailbox_seq && s1 == a.mailbox_seq) break;
                 if (polls >= MAILBOX_MAX_POLLS) { cmd_override = 2; break; }
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(8);
             }
             if (threadIdx.x < MAILBOX_WORDS) s_mail[threadIdx.x] = threadIdx.x == 1 && cmd_override ? cmd_override : v;
         }

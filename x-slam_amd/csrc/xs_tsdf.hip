@@ -518,7 +518,7 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         a.brick_count = (unsigned *)workspace;
         a.brick_list = (int *)((char *)workspace + 256);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-        XS_CHECK(hipMemsetAsync(a.brick_count, 0, 8 * (1 + COUNT_SLOTS), st));  // brick count + update-count slots
+        XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // brick count + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
         hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
         // resident workgroups stride over the list: 256 CUs x 8
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;

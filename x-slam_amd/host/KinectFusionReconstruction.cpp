@@ -340,6 +340,25 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 inliers = (long long)pinned_sums_[54];
             } else
                 icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
+            // The solve and the post come first: the enqueued launch is waiting for them.  The reference's
+            // determinant gate (:203-210) is evaluated right after; a launch that was handed the pose of a
+            // singular system finishes unobserved (nothing reads its sums, the next launch on the stream
+            // follows it).
+            hostComplexICP sol[6];
+            llt_solve6(A, b, sol);
+            hostComplex result[6];
+            for (int i = 0; i < 6; ++i) result[i] = hostComplex((float)sol[i].real(), (float)sol[i].imag());
+            const hostComplex alpha = result[0], beta = result[1], gamma = result[2];
+            const Matrix3cf Rinc = (angle_axis(gamma, 2) * angle_axis(beta, 1)) * angle_axis(alpha, 0);
+            Vector3cf tinc; tinc[0] = result[3]; tinc[1] = result[4]; tinc[2] = result[5];
+            const Vector3cf rt = Rinc * tcurr;
+            Vector3cf tnext;
+            for (int i = 0; i < 3; ++i) tnext[i] = rt[i] + tinc[i];
+            const Matrix3frm Rnext = Rinc * Rcurr;
+            if (next_enqueued)
+                xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rnext).data[0].x.re, &device_cast<devComplex3>(tnext).x.re, next_mail_seq, 0);
+            const double det = real_determinant6(A);
+            const bool singular = fabs(det) < 1e-15 || std::isnan(det);
             {   // diagnostics: re-pack the 27 sums in launch order
                 int shift = 0;
                 for (int i = 0; i < 6; ++i)
@@ -350,26 +369,14 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                     }
                 icp_log.push_back((double)inliers);
             }
-            const double det = real_determinant6(A);
-            if (fabs(det) < 1e-15 || std::isnan(det)) {
-                if (next_enqueued) xs_icp_post_pose(mailbox, nullptr, nullptr, next_mail_seq, 1);  // the enqueued launch returns at once
+            if (singular) {
                 if (std::isnan(det)) std::cout << "qnan det" << std::endl;
                 else std::cout << "eps det: " << fabs(det) << std::endl;
                 stage_end(ST_ICP);
                 return 0;
             }
-            hostComplexICP sol[6];
-            llt_solve6(A, b, sol);
-            hostComplex result[6];
-            for (int i = 0; i < 6; ++i) result[i] = hostComplex((float)sol[i].real(), (float)sol[i].imag());
-            const hostComplex alpha = result[0], beta = result[1], gamma = result[2];
-            const Matrix3cf Rinc = (angle_axis(gamma, 2) * angle_axis(beta, 1)) * angle_axis(alpha, 0);
-            Vector3cf tinc; tinc[0] = result[3]; tinc[1] = result[4]; tinc[2] = result[5];
-            Vector3cf rt = Rinc * tcurr;
-            for (int i = 0; i < 3; ++i) tcurr[i] = rt[i] + tinc[i];
-            Rcurr = Rinc * Rcurr;
-            if (next_enqueued)
-                xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rcurr).data[0].x.re, &device_cast<devComplex3>(tcurr).x.re, next_mail_seq, 0);
+            tcurr = tnext;
+            Rcurr = Rnext;
             for (int i = 0; i < 3; ++i) {
                 for (int j = 0; j < 3; ++j) c2w_curr(i, j) = Rcurr(i, j);
                 c2w_curr(i, 3) = tcurr[i];
