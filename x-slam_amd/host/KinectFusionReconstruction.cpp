@@ -276,11 +276,12 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
         return PoseEstimateOnDevice(Rcurr, tcurr, Rprev_inv, tprev, c2w_curr, total_iters);
     // posted mode: launch n + 1 is enqueued before the host waits for launch n, and gets its pose through
     // the mailbox after the solve (xs_icp_accumulate_posted)
-    const bool posted = icp_post_pose && icp_local && !profiling_icp_sync && total_iters >= 1;
+    // (only with the mailbox in device memory behind a large BAR: 512 workgroups polling pinned host memory
+    // over PCIe cost more than the launch latency they would save)
+    const bool posted = icp_post_pose && icp_local && !profiling_icp_sync && total_iters >= 1 && icp_mailbox_ && icp_mailbox_in_device_;
     std::vector<int> level_of;
     for (int level_index = num_levels - 1; level_index >= 0; --level_index)
         for (int iter = 0; iter < icp_iterations[level_index]; ++iter) level_of.push_back(level_index);
-    if (posted && !icp_mailbox_) check_rc(xs_icp_mailbox_alloc(&icp_mailbox_, &icp_mailbox_in_device_), "icp mailbox");
     void *mailbox = icp_mailbox_;
     unsigned long long seq_of_launch = 0;
     auto launch_local = [&](int level, const MatS33 *R, const devComplex3 *t, unsigned mail_seq) {
