@@ -156,6 +156,36 @@ def test_device_pose_solve_matches_host_solve(dev):
     a.close(); b.close()
 
 
+def test_posted_pose_loop_is_bit_identical_to_launch_after_solve(dev):
+    """icp_post_pose (default: every iteration's launch enqueued before its pose is known, pose delivered
+    through the BAR mailbox) against the reference's order (launch after the solve): the same kernel
+    arithmetic on the same inputs — every sum of every iteration, every pose and the volume must be the
+    same bits; and the frame after a lost frame (all-zero depth: no inliers, singular system, ProcessFrame
+    returns 0 while a posted launch is still in flight) is processed normally."""
+    torch, pl = dev
+    prm = synth.s1_params(96)
+    a = pl.KinectFusion(dict(prm, icp_post_pose=True))
+    b = pl.KinectFusion(dict(prm, icp_post_pose=False))
+    for k in range(5):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+        assert np.array_equal(a.icp_log(), b.icp_log())
+        assert np.array_equal(a.world2camera(), b.world2camera())
+    blank = upload(torch, np.zeros_like(synth.s1_frame(0)))
+    assert a.process_frame(blank) == 0 and b.process_frame(blank) == 0
+    assert a.icp_log().shape[0] == 1 and np.array_equal(a.icp_log(), b.icp_log())
+    for k in range(5, 7):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+        assert np.array_equal(a.icp_log(), b.icp_log())
+        assert np.array_equal(a.world2camera(), b.world2camera())
+    va, wa, ga = a.volume()
+    vb, wb, gb = b.volume()
+    assert np.array_equal(wa, wb) and np.array_equal(va, vb) and np.array_equal(ga, gb)
+    assert a.last_U() == b.last_U() > 0
+    a.close(); b.close()
+
+
 def test_pipeline_gt_pose_mode_s2(dev, oracle):
     """flag_use_gtPose: only surface measure + integrate + raycast run (scene S2 at a small size)."""
     torch, pl = dev
