@@ -143,3 +143,59 @@ def test_relocalize_recovers_a_perturbed_pose(dev):
     assert e1[0] < 0.7 * e0[0] and e1[1] < 1.3 * e0[1], (e0, e1)
     assert np.all(refined[..., 1] == 0)
     kf.close()
+
+
+def test_gn_terms_full_size_1024_eight_slabs(dev):
+    """BASELINE config 5's size: a 1024^3 volume (two S1 frames fused into it on the GPU), then the
+    Gauss-Newton terms of the next frame over the whole volume and over the eight z-slabs an 8-GPU run
+    gives its ranks.  Size-independent properties: the slab counts add up exactly, the 28 sums add up to
+    double rounding (what the ranks all-reduce), a second launch returns the same bits, J^T J is positive
+    semi-definite, and the band holds a sensible share of the volume."""
+    torch, capi, _ = dev
+    n = 1024
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    value = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+    weight = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
+    grad = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+    scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    iws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+    upd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for k in (0, 1):
+        T = s1_transforms(k, prm)
+        depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
+        dmax.zero_()
+        capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+        capi.integrate_scaled(scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm),
+                              value, weight, grad, n * 4, z0=0, z1=n, updated=upd, depth_max=dmax, workspace=iws)
+    torch.cuda.synchronize()
+    assert int(upd.item()) > 10_000_000       # 8x the voxels of the 512^3 run's ~1.9 M per frame, two frames
+    del weight, grad
+    T2 = s1_transforms(2, prm)
+    v2c = np.eye(4); v2c[:3, :3] = np.asarray(T2["Rv2c"])[..., 0]; v2c[:3, 3] = np.asarray(T2["tv2c"])[..., 0]
+    Rs, ts = seeded_poses(np.linalg.inv(v2c))
+    depth = torch.from_numpy(synth.s1_frame(2).view(np.int16)).cuda()
+    capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+    ws = torch.zeros(capi.tsdf_reduce_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(32, dtype=torch.float64, device="cuda")
+
+    def terms(z0, z1):
+        out.zero_()
+        capi.tsdf_gauss_newton_terms(scaled, W * 4, H, W, intr_of(prm), res, prm["tsdf_voxel_size"], Rs, ts, tranc_dist(prm),
+                                     value[z0 * n:], ws, out, z0=z0, z1=z1)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()[:29].copy()
+
+    whole = terms(0, n)
+    assert np.array_equal(whole, terms(0, n))
+    parts = np.zeros(29)
+    for r in range(8):
+        parts += terms(r * n // 8, (r + 1) * n // 8)
+    assert parts[28] == whole[28] and whole[28] > 500_000
+    assert np.allclose(parts[:28], whole[:28], rtol=1e-9, atol=1e-11 * np.abs(whole[:28]).max())
+    JtJ = np.zeros((6, 6))
+    JtJ[np.triu_indices(6)] = whole[:21]
+    JtJ = JtJ + np.triu(JtJ, 1).T
+    assert np.linalg.eigvalsh(JtJ).min() >= -1e-9 * np.abs(JtJ).max()
+    assert whole[27] >= 0

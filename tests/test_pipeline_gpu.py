@@ -320,3 +320,31 @@ def test_full_size_first_frame_figures(dev, n):
     na = np.isnan(ma[:H, :, 0])
     assert np.array_equal(na, np.isnan(mb[:H, :, 0])) and np.array_equal(ma[:H][~na], mb[:H][~na])
     a.close(); b.close()
+
+
+def test_full_size_1024_tracks_like_512(dev):
+    """The largest volume BASELINE names (1024^3: 4.3 GB per array, so byte offsets leave 32 bits and the raycast
+    takes its 64-bit-offset kernels): four frames of scene S1 track, the camera ends within millimetres of where the
+    512^3 run puts it (the scene constrains sliding along its wall only through the sphere, and the two
+    discretisations slide differently: 4 mm apart after 27 mm of motion) and has moved as far as the scene's ground
+    truth says; the rays find the same surface, and the voxel count scales with the resolution (a truncation band
+    of fixed metric width: eight times the voxels at twice the resolution)."""
+    torch, pl = dev
+    big, ref = pl.KinectFusion(synth.s1_params(1024)), pl.KinectFusion(synth.s1_params(512))
+    position = lambda kf: np.linalg.inv(kf.world2camera()[..., 0].astype(np.float64))[:3, 3]
+    start = None
+    for k in range(4):
+        d = upload(torch, synth.s1_frame(k))
+        assert big.process_frame(d) == 1 and ref.process_frame(d) == 1
+        if k == 0:
+            start = position(big)
+    apart = np.linalg.norm(position(big) - position(ref))
+    assert apart <= 0.006, f"1024^3 and 512^3 camera positions differ by {apart * 1e3:.2f} mm"
+    gt_step = np.linalg.norm(synth.s1_pose(3, 300)[:3, 3] - synth.s1_pose(0, 300)[:3, 3])
+    moved = np.linalg.norm(position(big) - start)
+    assert gt_step > 0.02 and abs(moved - gt_step) <= 0.003, f"moved {moved * 1e3:.2f} mm, ground truth {gt_step * 1e3:.2f} mm"
+    assert abs(big.last_hits() - ref.last_hits()) <= 0.02 * ref.last_hits()
+    assert 7.0 <= big.last_U() / ref.last_U() <= 9.0
+    deriv = big.world2camera()[..., 1]
+    assert np.isfinite(deriv).all() and np.abs(deriv).max() > 0     # the CSFD seed's derivative rides along
+    big.close(); ref.close()
