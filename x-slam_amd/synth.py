@@ -8,6 +8,10 @@ Scene S1 ("ICL-like", tracks):   plane z = 2.5 m + sphere centre (0.2, 0.1, 1.8)
                                  world = camera-0 frame, slow sinusoidal trajectory.
 Scene S2 ("frustum-filling"):    static camera on the z = 0 face of a 5.12 m cube
                                  looking at a plane 4.5 m away (HBM-bound integrate).
+Scene S3 ("room"):               the inside of a box, walls z = 2.5, x = +-1.0, y = -0.8 / +0.9, on
+                                 the S1 trajectory: three orthogonal walls are in view from every
+                                 pose, all six degrees of freedom are constrained, so the estimated
+                                 trajectory can be held against the ground truth.
 """
 import math
 
@@ -86,6 +90,27 @@ def render_s1(c2w, width=WIDTH, height=HEIGHT, fx=FX, fy=FY, cx=CX, cy=CY, noise
     mm = np.where(np.isfinite(mm), mm, 0.0)
     mm = np.clip(np.rint(mm), 0, 65535)
     return mm.astype(np.uint16)
+
+
+def render_s3(c2w, width=WIDTH, height=HEIGHT, fx=FX, fy=FY, cx=CX, cy=CY):
+    """Depth (u16 mm) of the room z = 2.5, x = +-1.0, y = -0.8 / +0.9 seen from inside, at c2w."""
+    u = np.arange(width, dtype=np.float64)
+    v = np.arange(height, dtype=np.float64)
+    d = np.stack([np.broadcast_to((u[None, :] - cx) / fx, (height, width)), np.broadcast_to((v[:, None] - cy) / fy, (height, width)),
+                  np.ones((height, width))], axis=-1)
+    R, o = c2w[:3, :3], c2w[:3, 3]
+    D = d @ R.T
+    best = np.full((height, width), np.inf)
+    for axis, level in ((2, 2.5), (0, 1.0), (0, -1.0), (1, -0.8), (1, 0.9)):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            s = (level - o[axis]) / D[..., axis]
+        best = np.minimum(best, np.where(np.isfinite(s) & (s > 0), s, np.inf))
+    mm = np.where(np.isfinite(best), 1000.0 * best, 0.0)
+    return np.clip(np.rint(mm), 0, 65535).astype(np.uint16)
+
+
+def s3_frame(k, T=300):
+    return render_s3(s1_pose(k, T))
 
 
 def s1_frame(k, T=300, noise_mm=0.0, **kw):
