@@ -377,3 +377,30 @@ def test_trajectory_against_ground_truth_on_a_constrained_scene(dev):
     assert worst_t <= 0.010, f"position error {worst_t * 1e3:.2f} mm over {travelled * 1e3:.0f} mm"
     assert worst_r <= 0.3, f"orientation error {worst_r:.3f} deg"
     kf.close()
+
+
+def test_csfd_derivative_survives_the_whole_pipeline(dev):
+    """A physical check of the complex-step derivative, end to end.  Seed the first camera pose's translation along
+    the optical axis (world2camera(2,3) += i h): the first depth image is then fused h further along z, every
+    later frame is tracked against that map, so every later world2camera(2,3) must carry d/dseed = 1 — through
+    integrate (complex projective SDF), the running average of (value, grad), the raycast's complex zero crossing,
+    27 complex sums per ICP iteration and the complex LLT solve, frame after frame.  Measured 1.00 -> 1.12 over
+    20 frames of scene S3.  The same seed on a lateral translation, (0,3), must die out within two frames with
+    nearest-pixel depth lookups (biInterpolate_threshold = 0: a projective SDF does not see a sideways shift of
+    the camera except through the depth lookup) and survive with the bilinear lookup."""
+    torch, pl = dev
+    def run(seed, threshold, frames=21):
+        kf = pl.KinectFusion(synth.s1_params(256, seed=seed, threshold=threshold))
+        out = []
+        for k in range(frames):
+            assert kf.process_frame(upload(torch, synth.s3_frame(k))) == 1
+            out.append(kf.world2camera()[:3, 3, 1] / np.float32(1e-7))
+        kf.close()
+        return np.array(out)
+    along = run((2, 3), 0.0)
+    assert along[0].tolist() == [0.0, 0.0, 1.0]
+    assert np.all(along[1:, 2] >= 0.95) and np.all(along[1:, 2] <= 1.25), along[:, 2]
+    lateral = run((0, 3), 0.0, frames=6)
+    assert lateral[0, 0] == 1.0 and np.all(np.abs(lateral[3:]) <= 0.02), lateral
+    lateral_bilinear = run((0, 3), 0.05, frames=6)
+    assert np.all(lateral_bilinear[1:, 0] >= 0.9) and np.all(lateral_bilinear[1:, 0] <= 1.6), lateral_bilinear[:, 0]
