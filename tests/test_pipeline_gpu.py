@@ -404,3 +404,27 @@ def test_csfd_derivative_survives_the_whole_pipeline(dev):
     assert lateral[0, 0] == 1.0 and np.all(np.abs(lateral[3:]) <= 0.02), lateral
     lateral_bilinear = run((0, 3), 0.05, frames=6)
     assert np.all(lateral_bilinear[1:, 0] >= 0.9) and np.all(lateral_bilinear[1:, 0] <= 1.6), lateral_bilinear[:, 0]
+
+
+@pytest.mark.parametrize("seed,threshold", [((2, 3), 0.0), ((0, 3), 0.05)], ids=["axial_seed_nearest", "lateral_seed_bilinear"])
+def test_pipeline_scene_s3_against_live_oracle(dev, oracle, seed, threshold):
+    """The box-room scene with the other CSFD seeds and the bilinear depth lookup (TsdfFusion.cu:128-158), side by
+    side with the oracle pipeline: poses, their derivatives, the voxel counts and the fused volume."""
+    torch, pl = dev
+    from oracle.oracle import OracleKinFu, params_from_dict
+    prm = synth.s1_params(96, seed=seed, threshold=threshold)
+    kf = pl.KinectFusion(prm)
+    ok_ = OracleKinFu(oracle, params_from_dict(prm))
+    for k in range(4):
+        d = synth.s3_frame(k)
+        assert kf.process_frame(upload(torch, d)) == 1 and ok_.process_frame(d) == 1
+        pose_close(kf.world2camera(), ok_.world2camera(), value_tol=1e-6 if k <= 1 else 2e-5, deriv_rel=1e-6 if k <= 1 else 1e-3)
+        assert abs(kf.last_U() - ok_.last_U()) <= max(3, 1e-4 * ok_.last_U())
+    assert abs(kf.world2camera()[seed[0], seed[1], 1] / np.float32(1e-7) - 1.0) <= 0.5     # the derivative is alive
+    v, w, g = kf.volume()
+    ov, ow, og = ok_.volume()
+    assert mismatch_fraction(w, ow) <= 1e-4
+    same = w == ow
+    assert frac_bad(np.abs(v[same] - ov[same]) <= 1e-4) <= 1e-4
+    assert frac_bad(np.abs(g[same] - og[same]) <= 1e-3 * np.abs(og).max()) <= 1e-4
+    kf.close()
