@@ -70,8 +70,9 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
  * workspace the kernel first lists the 64x4x8-voxel bricks that can intersect the frustum and
  * then spreads them over all CUs; without one (NULL) each column walks its own clipped range. */
 size_t xs_integrate_workspace_bytes(const int *res, int nz);
-/* Profiling hook (per host thread): hipEvent_t pair recorded on the launch stream immediately
- * around the integrate kernel proper, i.e. after the brick classification; NULL, NULL disables. */
+/* Profiling hook (per host thread): hipEvent_t pair attached to the dispatch of the integrate kernel
+ * proper (after the brick classification) — the kernel's own begin / end, no marker packets on the
+ * stream; NULL, NULL disables. */
 void xs_integrate_set_timing_events(void *start_event, void *stop_event);
 
 /* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */
