@@ -9,19 +9,23 @@ pyramid, all in complex float with the CSFD seed i*1e-7 on world2camera(0,3).  D
 are resident in HBM before the timed region.  One JSON line on rank 0 with the contract's
 fields plus
   roofline     : the TSDF-integrate kernel — algorithmic bytes 24*U + 2*W*H per launch (U = voxels
-                 written, counted by the kernel) / its mean duration from HIP events recorded on
-                 the launch stream inside the timed region; peak = 8 TB/s HBM3E; traffic = HBM bytes
-                 per launch from the committed rocprofv3 counter passes (profiles/r01_integrate_pmc_v3.json)
+                 written, counted by the kernel) / its mean duration from a HIP event pair attached to
+                 the kernel's dispatch on the launch stream, inside the timed region; peak = 8 TB/s HBM3E;
+                 traffic = HBM bytes per launch from the committed rocprofv3 counter passes
+                 (profiles/r01_integrate_pmc_v3.json)
   roofline_s2  : the same object for scene S2 (SURVEY 8d's frustum-filling placement, the one the
                  HBM claim is made on: ~0.95 GB per launch instead of S1's ~45 MB, which is over in
                  the time a launch takes to ramp up)
   cpu_baseline : the CPU oracle (oracle/, a port — not the product path) timed on this host's
                  cores on a bounded sample of the same workload
-  stages_ms    : per-stage mean ms
-N > 1 (launched by torch.distributed.run, one rank per GPU): the volume is sharded by z-slab,
-ICP rows by rank, and the 6x6 / 6x1 normal equations are all-reduced over RCCL (see
-x-slam_amd/sharded.py); max-over-ranks timing, "scaling": "strong" (one frame stream, fixed
-total work).
+  stages_ms    : per-stage mean ms, from a separate untimed pass with an event pair around every stage
+                 (those pairs are packets the kernels would queue behind: not in the timed region)
+N > 1 (launched by torch.distributed.run, one rank per GPU): the volume is sharded by z-slab
+(integrate, raycast + a two-collective composite over RCCL); the ICP runs replicated on every rank
+(default) or row-sharded with the 6x6 / 6x1 normal equations all-reduced per iteration
+(--icp-shard-rows; the other mode is timed briefly as "alt_mode"); see x-slam_amd/sharded.py.
+Max-over-ranks timing, "scaling": "strong" (one frame stream, fixed total work).
+--scene s3: a box room on the same camera path (every degree of freedom constrained) for long runs.
 """
 import argparse
 import importlib
