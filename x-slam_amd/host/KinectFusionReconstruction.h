@@ -72,10 +72,11 @@ public:
     void SetSharding(int rank, int count, collective_fn fn, void *user);  // call before SetYamlParameters
 
     // false (default): the reference's shape, one host solve per ICP iteration (the host spins on a
-    // completion word the kernel writes into pinned memory: ~3 us over back-to-back launches).  true: the
-    // pose update runs on the device (xs_icp_iterate) and the host waits once per frame — measured ~3 us
-    // per iteration slower on this machine (a serial double-precision Cholesky + substitution is ~9000
-    // cycles for one wave), kept for hosts that cannot spin.  YAML key icp_solve_on_device.
+    // completion word the kernel writes into pinned memory; with icp_post_pose below the next launch is
+    // already resident when the solve ends: ICP stage 0.24 ms).  true: the pose update runs on the device
+    // (xs_icp_iterate) and the host waits once per frame — slower on this machine (a serial
+    // double-precision Cholesky + substitution is ~9000 cycles for one wave, plus a second launch per
+    // iteration: 0.35 ms), kept for hosts that cannot spin.  YAML key icp_solve_on_device.
     bool icp_solve_on_device = false;
     // true (default): each iteration's launch is enqueued while the previous one is still running and
     // receives its pose through a pinned-memory mailbox once the host has solved for it
