@@ -19,6 +19,10 @@ extern "C" {
  * over arrays of n groups (re.re, re.im, im.re, im.im).  op: 0 add 1 sub 2 mul 3 div 4 sqrt 5 abs 6 exp
  * 7 log 8 sin 9 cos 10 pow(x, y.re.re) 11 f1(x, y) = (x + y)^2 12 conj 13 norm 14 (x > y, x < y).  CPU only. */
 int xs_host_double_complex_table(int op, long n, const float *a, const float *b, float *out);
+/* Host instantiation of the complex<float> operators (x-slam_amd/csrc/xs_complex.h is host + device, like
+ * DeviceArray/include/cuda_complex.hpp:12-16): n interleaved (re, im) pairs, op codes of xs_complex_table
+ * (include/xslam_amd.h).  Returns 0, -1 for a bad op.  CPU only. */
+int xs_host_complex_table(int op, long n, const float *a, const float *b, float *out);
 
 /* Flat "key: value" config reader (x-slam_amd/host/flat_yaml.hpp; stands in for yaml-cpp's
  * config["k"].as<T>() of KinectFusionReconstruction.cpp:12-72): copies the value of key into out.

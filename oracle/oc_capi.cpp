@@ -80,6 +80,16 @@ int ORC(cop)(int op, long n, const float *a, const float *b, float *out) {
             case 20: r = y.real() / x; break;        // scalar / complex
             case 21: r = x * y.real(); break;        // complex * scalar
             case 22: r = y.real() - x; break;        // scalar - complex
+            case 23: r = proj(x); break;
+            case 24: r = log10(x); break;
+            case 25: r = tanh(x); break;
+            case 26: r = tan(x); break;
+            case 27: r = asinh(x); break;
+            case 28: r = acosh(x); break;
+            case 29: r = atanh(x); break;
+            case 30: r = asin(x); break;
+            case 31: r = acos(x); break;
+            case 32: r = atan(x); break;
             default: return -1;
         }
         out[2 * i] = r.real(); out[2 * i + 1] = r.imag();

@@ -7,7 +7,9 @@
 //   complex<T>   : DeviceArray/include/cuda_complex.hpp:20-96 (members),
 //                  :100-342 (+ - * /), :436-473 (abs arg norm), :536-593
 //                  (polar log sqrt), :596-640 (exp pow), :705-751 (sinh
-//                  sinh_new cosh), :842-870 (sin sin_new cos)
+//                  sinh_new cosh), :842-870 (sin sin_new cos), and the rest of
+//                  the header's functions (:506-516, :570-577, :640-723, :770-841,
+//                  :873-881: proj log10 asinh acosh atanh tanh asin acos atan tan)
 //   d_complex<T> : DeviceArray/include/cuda_double_complex.hpp:16-134
 //                  (members, compound ops), :137-231 (free ops), :233-260
 //                  (abs, sqrt)
@@ -173,6 +175,108 @@ template <class T> inline cplx<T> sin_new(const cplx<T> &x) {
     return cplx<T>(std::sin(x.real()), std::sinh(x.imag()) * std::cos(x.real()));
 }
 template <class T> inline cplx<T> cos(const cplx<T> &x) { return cosh(cplx<T>(-x.imag(), x.real())); }
+
+// ---- the remaining functions of the header (hpp:506-516 proj, :570-577 log10, :640-723
+// asinh acosh atanh, :770-787 tanh, :789-841 asin acos atan, :873-881 tan) -------------
+template <class T> inline cplx<T> proj(const cplx<T> &c) {
+    cplx<T> r = c;
+    if (std::isinf(c.real()) || std::isinf(c.imag())) r = cplx<T>(T(INFINITY), std::copysign(T(0), c.imag()));
+    return r;
+}
+template <class T> inline cplx<T> log10(const cplx<T> &x) { return log(x) / std::log(T(10)); }
+template <class T> inline cplx<T> asinh(const cplx<T> &x) {
+    const T pi(std::atan2(+0., -0.));
+    if (std::isinf(x.real())) {
+        if (std::isnan(x.imag())) return x;
+        if (std::isinf(x.imag())) return cplx<T>(x.real(), std::copysign(pi * T(0.25), x.imag()));
+        return cplx<T>(x.real(), std::copysign(T(0), x.imag()));
+    }
+    if (std::isnan(x.real())) {
+        if (std::isinf(x.imag())) return cplx<T>(x.imag(), x.real());
+        if (x.imag() == 0) return x;
+        return cplx<T>(x.real(), x.real());
+    }
+    if (std::isinf(x.imag())) return cplx<T>(std::copysign(x.imag(), x.real()), std::copysign(pi / T(2), x.imag()));
+    cplx<T> z = log(x + sqrt(pow(x, T(2)) + T(1)));
+    return cplx<T>(std::copysign(z.real(), x.real()), std::copysign(z.imag(), x.imag()));
+}
+template <class T> inline cplx<T> acosh(const cplx<T> &x) {
+    const T pi(std::atan2(+0., -0.));
+    if (std::isinf(x.real())) {
+        if (std::isnan(x.imag())) return cplx<T>(std::fabs(x.real()), x.imag());
+        if (std::isinf(x.imag())) {
+            if (x.real() > 0) return cplx<T>(x.real(), std::copysign(pi * T(0.25), x.imag()));
+            return cplx<T>(-x.real(), std::copysign(pi * T(0.75), x.imag()));
+        }
+        if (x.real() < 0) return cplx<T>(-x.real(), std::copysign(pi, x.imag()));
+        return cplx<T>(x.real(), std::copysign(T(0), x.imag()));
+    }
+    if (std::isnan(x.real())) {
+        if (std::isinf(x.imag())) return cplx<T>(std::fabs(x.imag()), x.real());
+        return cplx<T>(x.real(), x.real());
+    }
+    if (std::isinf(x.imag())) return cplx<T>(std::fabs(x.imag()), std::copysign(pi / T(2), x.imag()));
+    cplx<T> z = log(x + sqrt(pow(x, T(2)) - T(1)));
+    return cplx<T>(std::copysign(z.real(), T(0)), std::copysign(z.imag(), x.imag()));
+}
+template <class T> inline cplx<T> atanh(const cplx<T> &x) {
+    const T pi(std::atan2(+0., -0.));
+    if (std::isinf(x.imag())) return cplx<T>(std::copysign(T(0), x.real()), std::copysign(pi / T(2), x.imag()));
+    if (std::isnan(x.imag())) {
+        if (std::isinf(x.real()) || x.real() == 0) return cplx<T>(std::copysign(T(0), x.real()), x.imag());
+        return cplx<T>(x.imag(), x.imag());
+    }
+    if (std::isnan(x.real())) return cplx<T>(x.real(), x.real());
+    if (std::isinf(x.real())) return cplx<T>(std::copysign(T(0), x.real()), std::copysign(pi / T(2), x.imag()));
+    if (std::fabs(x.real()) == T(1) && x.imag() == T(0))
+        return cplx<T>(std::copysign(T(INFINITY), x.real()), std::copysign(T(0), x.imag()));
+    cplx<T> z = log((T(1) + x) / (T(1) - x)) / T(2);
+    return cplx<T>(std::copysign(z.real(), x.real()), std::copysign(z.imag(), x.imag()));
+}
+template <class T> inline cplx<T> tanh(const cplx<T> &x) {
+    if (std::isinf(x.real())) {
+        if (!std::isfinite(x.imag())) return cplx<T>(T(1), T(0));
+        return cplx<T>(T(1), std::copysign(T(0), std::sin(T(2) * x.imag())));
+    }
+    if (std::isnan(x.real()) && x.imag() == 0) return x;
+    T r2(T(2) * x.real());
+    T i2(T(2) * x.imag());
+    T d(std::cosh(r2) + std::cos(i2));
+    return cplx<T>(std::sinh(r2) / d, std::sin(i2) / d);
+}
+template <class T> inline cplx<T> asin(const cplx<T> &x) {
+    cplx<T> z = asinh(cplx<T>(-x.imag(), x.real()));
+    return cplx<T>(z.imag(), -z.real());
+}
+template <class T> inline cplx<T> acos(const cplx<T> &x) {
+    const T pi(std::atan2(+0., -0.));
+    if (std::isinf(x.real())) {
+        if (std::isnan(x.imag())) return cplx<T>(x.imag(), x.real());
+        if (std::isinf(x.imag())) {
+            if (x.real() < T(0)) return cplx<T>(T(0.75) * pi, -x.imag());
+            return cplx<T>(T(0.25) * pi, -x.imag());
+        }
+        if (x.real() < T(0)) return cplx<T>(pi, std::signbit(x.imag()) ? -x.real() : x.real());
+        return cplx<T>(T(0), std::signbit(x.imag()) ? x.real() : -x.real());
+    }
+    if (std::isnan(x.real())) {
+        if (std::isinf(x.imag())) return cplx<T>(x.real(), -x.imag());
+        return cplx<T>(x.real(), x.real());
+    }
+    if (std::isinf(x.imag())) return cplx<T>(pi / T(2), -x.imag());
+    if (x.real() == 0) return cplx<T>(pi / T(2), -x.imag());
+    cplx<T> z = log(x + sqrt(pow(x, T(2)) - T(1)));
+    if (std::signbit(x.imag())) return cplx<T>(std::fabs(z.imag()), std::fabs(z.real()));
+    return cplx<T>(std::fabs(z.imag()), -std::fabs(z.real()));
+}
+template <class T> inline cplx<T> atan(const cplx<T> &x) {
+    cplx<T> z = atanh(cplx<T>(-x.imag(), x.real()));
+    return cplx<T>(z.imag(), -z.real());
+}
+template <class T> inline cplx<T> tan(const cplx<T> &x) {
+    cplx<T> z = tanh(cplx<T>(-x.imag(), x.real()));
+    return cplx<T>(z.imag(), -z.real());
+}
 
 // ---------------------------------------------------------------------------
 // dual complex a + b*j with a, b complex  (cuda_double_complex.hpp)

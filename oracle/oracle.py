@@ -122,7 +122,8 @@ class Oracle:
     # ---- scalar tables -----------------------------------------------------
     COP = {"add": 0, "sub": 1, "mul": 2, "div": 3, "sqrt": 4, "abs": 5, "exp": 6, "log": 7, "pow": 8, "sin": 9, "cos": 10,
            "sinh": 11, "cosh": 12, "sin_new": 13, "sinh_new": 14, "norm": 15, "arg": 16, "conj": 17, "polar": 18,
-           "div_scalar": 19, "scalar_div": 20, "mul_scalar": 21, "scalar_sub": 22}
+           "div_scalar": 19, "scalar_div": 20, "mul_scalar": 21, "scalar_sub": 22, "proj": 23, "log10": 24, "tanh": 25, "tan": 26,
+           "asinh": 27, "acosh": 28, "atanh": 29, "asin": 30, "acos": 31, "atan": 32}
     DOP = {"add": 0, "sub": 1, "mul": 2, "div": 3, "sqrt": 4, "abs": 5, "mul_scalar": 6, "div_scalar": 7, "add_scalar": 8,
            "scalar_sub": 9}
     HDOP = {"add": 0, "sub": 1, "mul": 2, "div": 3, "sqrt": 4, "abs": 5, "exp": 6, "log": 7, "sin": 8, "cos": 9, "pow": 10, "f1": 11}

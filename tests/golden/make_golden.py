@@ -40,6 +40,9 @@ synth = importlib.import_module("x-slam_amd.synth")
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+EXT_OPS = ("proj", "log10", "tanh", "tan", "asinh", "acosh", "atanh", "asin", "acos", "atan")
+
+
 def scalar_tables(ref):
     rng = np.random.default_rng(0xC5FD)
     n = 256
@@ -82,6 +85,17 @@ def scalar_tables(ref):
         out[f"d_{op}"] = ref.dop(op, d1, d2)
     out["d_sqrt"] = ref.dop("sqrt", dp)
     out["d_abs"] = ref.dop("abs", dp)
+    # the rest of the header's functions (cuda_complex.hpp:506-516, 570-577, 640-723, 770-841, 873-881): drawn after
+    # everything above so the earlier tables keep their values; "spec" is the cross product of the special values the
+    # branches of those functions test for
+    xa = rng.uniform(-2, 2, (n, 2)).astype(np.float32)
+    sv = np.array([0.0, -0.0, 1.0, -1.0, 0.5, np.inf, -np.inf, np.nan], np.float32)
+    spec = np.stack(np.meshgrid(sv, sv, indexing="ij"), -1).reshape(-1, 2)
+    out.update(ext_a=xa, spec_a=spec)
+    for op in EXT_OPS:
+        out[f"c_ext_{op}"] = ref.cop(op, xa)
+        out[f"c_csfdx_{op}"] = ref.cop(op, a)
+        out[f"c_spec_{op}"] = ref.cop(op, spec)
     np.savez_compressed(os.path.join(OUT, "scalar_tables.npz"), **out)
 
 

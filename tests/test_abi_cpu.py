@@ -92,6 +92,32 @@ def test_host_double_complex_class_against_oracle(oracle):
     assert abs(loss[1] / h - ka["dcsfd_gradient"]) < 2e-4 and abs(loss[3] / h / h - ka["dcsfd_second"]) < 2e-2
 
 
+def test_product_complex_header_on_the_host_against_reference_tables():
+    """x-slam_amd/csrc/xs_complex.h compiled for the host (g++, glibc) against the tables the reference's own
+    cuda_complex.hpp produced (tests/golden/scalar_tables.npz): every operator and function of the header,
+    bit for bit — including the divide's and the square root's short forms and every special-value branch."""
+    import numpy as np
+    from conftest import load_golden, ulp_diff
+    from oracle.oracle import Oracle
+    pl = importlib.import_module("x-slam_amd.pipeline")
+    t = load_golden("scalar_tables.npz")
+    for tag in ("csfd", "gen", "wide"):
+        for op in ("add", "sub", "mul", "div", "div_scalar", "scalar_div", "mul_scalar", "scalar_sub"):
+            assert ulp_diff(pl.host_complex(Oracle.COP[op], t[f"{tag}_a"], t[f"{tag}_b"]), t[f"c_{tag}_{op}"]).max() == 0, (tag, op)
+    for tag in ("csfd", "gen", "pos"):
+        for op in ("sqrt", "abs", "exp", "sin", "cos", "sinh", "cosh", "sin_new", "sinh_new", "norm", "arg", "conj"):
+            assert ulp_diff(pl.host_complex(Oracle.COP[op], t[f"{tag}_a"]), t[f"c_{tag}_{op}"]).max() == 0, (tag, op)
+    assert ulp_diff(pl.host_complex(Oracle.COP["log"], t["pos_a"]), t["c_pos_log"]).max() == 0
+    assert ulp_diff(pl.host_complex(Oracle.COP["log"], t["gen_a"]), t["c_gen_log"]).max() == 0
+    assert ulp_diff(pl.host_complex(Oracle.COP["pow"], t["pos_a"], t["csfd_b"]), t["c_pos_pow"]).max() == 0
+    assert ulp_diff(pl.host_complex(Oracle.COP["polar"], np.abs(t["gen_a"]), t["gen_b"]), t["c_gen_polar"]).max() == 0
+    for op in ("proj", "log10", "tanh", "tan", "asinh", "acosh", "atanh", "asin", "acos", "atan"):
+        for tag, key in (("ext", "ext_a"), ("csfdx", "csfd_a"), ("spec", "spec_a")):
+            assert ulp_diff(pl.host_complex(Oracle.COP[op], t[key]), t[f"c_{tag}_{op}"]).max() == 0, (op, tag)
+    with pytest.raises(ValueError):
+        pl.host_complex(99, t["gen_a"])
+
+
 def test_flat_yaml_reads_the_reference_config_format():
     """The reference's shipped config (Experiments/test_xkinect_fusion/configs/ICL_traj2.yaml) is flat
     key: value with comments, quoted strings and blank lines; all 34 keys must come through."""

@@ -603,6 +603,19 @@ def test_device_complex_tables_vs_reference_header(dev, oracle):
         assert np.allclose(got, want, rtol=4e-6, atol=4e-7), op
     got = _table(torch, capi, 0, Oracle.COP["log"], t["pos_a"], t["pos_a"])
     assert np.allclose(got, t["c_pos_log"], rtol=2e-6, atol=1e-12)
+    # the rest of the header (proj log10 tanh tan asinh acosh atanh asin acos atan): device libm, a few ulp on the
+    # general operands; on the special-value cross product the same NaN / inf / signed-zero pattern
+    for op in ("proj", "log10", "tanh", "tan", "asinh", "acosh", "atanh", "asin", "acos", "atan"):
+        for tag, key in (("ext", "ext_a"), ("csfdx", "csfd_a")):
+            got = _table(torch, capi, 0, Oracle.COP[op], t[key], t[key])
+            want = t[f"c_{tag}_{op}"]
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-6 if tag == "ext" else 1e-12), (op, tag, np.abs(got - want).max())
+        got = _table(torch, capi, 0, Oracle.COP[op], t["spec_a"], t["spec_a"])
+        want = t[f"c_spec_{op}"]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), op
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isinf(got), np.isinf(want)) and np.array_equal(np.signbit(got[~np.isnan(want)]), np.signbit(want[~np.isnan(want)])), op
+        assert np.allclose(got[fin], want[fin], rtol=2e-5, atol=1e-6), op
     # dual complex
     for op in ("add", "sub", "mul", "div", "mul_scalar", "div_scalar", "add_scalar", "scalar_sub"):
         got = _table(torch, capi, 1, Oracle.DOP[op], t["d_a"], t["d_b"])

@@ -42,6 +42,18 @@ def test_complex_log_pow_polar(oracle, tables):
     assert ulp_diff(oracle.cop("polar", np.abs(tables["gen_a"]), tables["gen_b"]), tables["c_gen_polar"]).max() == 0
 
 
+EXT = ("proj", "log10", "tanh", "tan", "asinh", "acosh", "atanh", "asin", "acos", "atan")
+
+
+@pytest.mark.parametrize("tag,key", [("ext", "ext_a"), ("csfdx", "csfd_a"), ("spec", "spec_a")])
+@pytest.mark.parametrize("op", EXT)
+def test_complex_remaining_functions_bit_exact(oracle, tables, tag, key, op):
+    """cuda_complex.hpp:506-516, 570-577, 640-723, 770-841, 873-881 — general operands, CSFD-regime operands and the
+    cross product of {0, -0, 1, -1, 0.5, inf, -inf, nan} (every special-value branch), NaN == NaN."""
+    got = oracle.cop(op, tables[key])
+    assert ulp_diff(got, tables[f"c_{tag}_{op}"]).max() == 0
+
+
 @pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "sqrt"])
 def test_complex_double_bit_exact(oracle, tables, op):
     got = oracle.cop_f64(op, tables["f64_a"], tables["f64_b"])

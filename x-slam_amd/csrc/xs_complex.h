@@ -218,6 +218,98 @@ template <class T> XS_HD cplx<T> sin_new(cplx<T> x) {  // cuda_complex.hpp:855-8
 }
 template <class T> XS_HD cplx<T> cos(cplx<T> x) { return cosh(cplx<T>(-x.im, x.re)); }
 
+// ---- the rest of the reference's surface (none of it on the kernels' path) ---------------------
+template <class T> XS_HD cplx<T> proj(cplx<T> c) {  // cuda_complex.hpp:508-516
+    if (isinf(c.re) || isinf(c.im)) return cplx<T>(T(INFINITY), copysign(T(0), c.im));
+    return c;
+}
+template <class T> XS_HD cplx<T> log10(cplx<T> x) { return log(x) / detail::xlog(T(10)); }  // :572-577
+template <class T> XS_HD cplx<T> tanh(cplx<T> x) {  // :772-787
+    if (isinf(x.re)) {
+        if (!isfinite(x.im)) return cplx<T>(T(1), T(0));
+        return cplx<T>(T(1), copysign(T(0), detail::xsin(T(2) * x.im)));
+    }
+    if (isnan(x.re) && x.im == 0) return x;
+    T r2 = T(2) * x.re, i2 = T(2) * x.im;
+    T d = detail::xcosh(r2) + detail::xcos(i2);
+    return cplx<T>(detail::xsinh(r2) / d, detail::xsin(i2) / d);
+}
+template <class T> XS_HD cplx<T> tan(cplx<T> x) { cplx<T> z = tanh(cplx<T>(-x.im, x.re)); return cplx<T>(z.im, -z.re); }  // :875-881
+namespace detail {
+template <class T> XS_HD T pi() { return T(3.14159265358979323846); }  // the reference's atan2(+0., -0.) rounded to T
+}
+template <class T> XS_HD cplx<T> asinh(cplx<T> x) {  // :642-665
+    const T pi = detail::pi<T>();
+    if (isinf(x.re)) {
+        if (isnan(x.im)) return x;
+        if (isinf(x.im)) return cplx<T>(x.re, copysign(pi * T(0.25), x.im));
+        return cplx<T>(x.re, copysign(T(0), x.im));
+    }
+    if (isnan(x.re)) {
+        if (isinf(x.im)) return cplx<T>(x.im, x.re);
+        if (x.im == 0) return x;
+        return cplx<T>(x.re, x.re);
+    }
+    if (isinf(x.im)) return cplx<T>(copysign(x.im, x.re), copysign(pi / T(2), x.im));
+    cplx<T> z = log(x + sqrt(pow(x, T(2)) + T(1)));
+    return cplx<T>(copysign(z.re, x.re), copysign(z.im, x.im));
+}
+template <class T> XS_HD cplx<T> acosh(cplx<T> x) {  // :669-695
+    const T pi = detail::pi<T>();
+    if (isinf(x.re)) {
+        if (isnan(x.im)) return cplx<T>(fabs(x.re), x.im);
+        if (isinf(x.im)) {
+            if (x.re > 0) return cplx<T>(x.re, copysign(pi * T(0.25), x.im));
+            return cplx<T>(-x.re, copysign(pi * T(0.75), x.im));
+        }
+        if (x.re < 0) return cplx<T>(-x.re, copysign(pi, x.im));
+        return cplx<T>(x.re, copysign(T(0), x.im));
+    }
+    if (isnan(x.re)) {
+        if (isinf(x.im)) return cplx<T>(fabs(x.im), x.re);
+        return cplx<T>(x.re, x.re);
+    }
+    if (isinf(x.im)) return cplx<T>(fabs(x.im), copysign(pi / T(2), x.im));
+    cplx<T> z = log(x + sqrt(pow(x, T(2)) - T(1)));
+    return cplx<T>(copysign(z.re, T(0)), copysign(z.im, x.im));
+}
+template <class T> XS_HD cplx<T> atanh(cplx<T> x) {  // :699-723
+    const T pi = detail::pi<T>();
+    if (isinf(x.im)) return cplx<T>(copysign(T(0), x.re), copysign(pi / T(2), x.im));
+    if (isnan(x.im)) {
+        if (isinf(x.re) || x.re == 0) return cplx<T>(copysign(T(0), x.re), x.im);
+        return cplx<T>(x.im, x.im);
+    }
+    if (isnan(x.re)) return cplx<T>(x.re, x.re);
+    if (isinf(x.re)) return cplx<T>(copysign(T(0), x.re), copysign(pi / T(2), x.im));
+    if (fabs(x.re) == T(1) && x.im == T(0)) return cplx<T>(copysign(T(INFINITY), x.re), copysign(T(0), x.im));
+    cplx<T> z = log((T(1) + x) / (T(1) - x)) / T(2);
+    return cplx<T>(copysign(z.re, x.re), copysign(z.im, x.im));
+}
+template <class T> XS_HD cplx<T> asin(cplx<T> x) { cplx<T> z = asinh(cplx<T>(-x.im, x.re)); return cplx<T>(z.im, -z.re); }  // :791-797
+template <class T> XS_HD cplx<T> acos(cplx<T> x) {  // :801-831
+    const T pi = detail::pi<T>();
+    if (isinf(x.re)) {
+        if (isnan(x.im)) return cplx<T>(x.im, x.re);
+        if (isinf(x.im)) {
+            if (x.re < T(0)) return cplx<T>(T(0.75) * pi, -x.im);
+            return cplx<T>(T(0.25) * pi, -x.im);
+        }
+        if (x.re < T(0)) return cplx<T>(pi, signbit(x.im) ? -x.re : x.re);
+        return cplx<T>(T(0), signbit(x.im) ? x.re : -x.re);
+    }
+    if (isnan(x.re)) {
+        if (isinf(x.im)) return cplx<T>(x.re, -x.im);
+        return cplx<T>(x.re, x.re);
+    }
+    if (isinf(x.im)) return cplx<T>(pi / T(2), -x.im);
+    if (x.re == 0) return cplx<T>(pi / T(2), -x.im);
+    cplx<T> z = log(x + sqrt(pow(x, T(2)) - T(1)));
+    if (signbit(x.im)) return cplx<T>(fabs(z.im), fabs(z.re));
+    return cplx<T>(fabs(z.im), -fabs(z.re));
+}
+template <class T> XS_HD cplx<T> atan(cplx<T> x) { cplx<T> z = atanh(cplx<T>(-x.im, x.re)); return cplx<T>(z.im, -z.re); }  // :835-841
+
 // ---------------------------------------------------------------------------------------
 // dual complex a + b*j, a and b complex; 16 B for T = float, member order re.re re.im
 // im.re im.im (cuda_double_complex.hpp:24-31)

@@ -142,6 +142,16 @@ __global__ void k_ctable(int op, const cfloat *a, const cfloat *b, cfloat *out, 
         case 20: r = y.re / x; break;
         case 21: r = x * y.re; break;
         case 22: r = y.re - x; break;
+        case 23: r = proj(x); break;
+        case 24: r = log10(x); break;
+        case 25: r = tanh(x); break;
+        case 26: r = tan(x); break;
+        case 27: r = asinh(x); break;
+        case 28: r = acosh(x); break;
+        case 29: r = atanh(x); break;
+        case 30: r = asin(x); break;
+        case 31: r = acos(x); break;
+        case 32: r = atan(x); break;
     }
     out[i] = r;
 }
@@ -169,7 +179,7 @@ __global__ void k_dtable(int op, const dcfloat *a, const dcfloat *b, dcfloat *ou
  * operator API (cuda_complex.hpp:100-881, cuda_double_complex.hpp:137-260) over arrays. */
 extern "C" int xs_complex_table(int dual, int op, const float *a, const float *b, float *out, long n, void *stream) {
     if (!a || !b || !out) return xs_set_error(hipErrorInvalidValue, "xs_complex_table: null pointer");
-    if (op < 0 || op > (dual ? 9 : 22)) return xs_set_error(hipErrorInvalidValue, "xs_complex_table: bad op");
+    if (op < 0 || op > (dual ? 9 : 32)) return xs_set_error(hipErrorInvalidValue, "xs_complex_table: bad op");
     if (n <= 0) return 0;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dual)

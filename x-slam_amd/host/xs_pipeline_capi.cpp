@@ -1,5 +1,6 @@
 // xs_pipeline_capi.cpp — C ABI over KinectFusionReconstruction (include/xslam_amd_pipeline.h).
 #include "../../include/xslam_amd_pipeline.h"
+#include "../csrc/xs_complex.h"
 #include "DoubleComplex.h"
 #include "KinectFusionReconstruction.h"
 #include <cstring>
@@ -34,6 +35,54 @@ int xs_host_double_complex_table(int op, long n, const float *a, const float *b,
             default: return -1;
         }
         out[4 * i] = r.real().real(); out[4 * i + 1] = r.real().imag(); out[4 * i + 2] = r.imag().real(); out[4 * i + 3] = r.imag().imag();
+    }
+    return 0;
+}
+
+// csrc/xs_complex.h compiled for the host (the DeviceArray operator API is __host__ __device__ in the
+// reference too, cuda_complex.hpp:12-16): n interleaved (re, im) pairs, op codes of xs_complex_table
+int xs_host_complex_table(int op, long n, const float *a, const float *b, float *out) {
+    using namespace xs;
+    for (long i = 0; i < n; ++i) {
+        const cfloat x(a[2 * i], a[2 * i + 1]), y(b[2 * i], b[2 * i + 1]);
+        cfloat r(0.f, 0.f);
+        switch (op) {
+            case 0: r = x + y; break;
+            case 1: r = x - y; break;
+            case 2: r = x * y; break;
+            case 3: r = x / y; break;
+            case 4: r = sqrt(x); break;
+            case 5: r = cfloat(abs(x), 0.f); break;
+            case 6: r = exp(x); break;
+            case 7: r = log(x); break;
+            case 8: r = pow(x, y); break;
+            case 9: r = sin(x); break;
+            case 10: r = cos(x); break;
+            case 11: r = sinh(x); break;
+            case 12: r = cosh(x); break;
+            case 13: r = sin_new(x); break;
+            case 14: r = sinh_new(x); break;
+            case 15: r = cfloat(norm(x), 0.f); break;
+            case 16: r = cfloat(arg(x), 0.f); break;
+            case 17: r = conj(x); break;
+            case 18: r = polar(x.re, y.re); break;
+            case 19: r = x / y.re; break;
+            case 20: r = y.re / x; break;
+            case 21: r = x * y.re; break;
+            case 22: r = y.re - x; break;
+            case 23: r = proj(x); break;
+            case 24: r = log10(x); break;
+            case 25: r = tanh(x); break;
+            case 26: r = tan(x); break;
+            case 27: r = asinh(x); break;
+            case 28: r = acosh(x); break;
+            case 29: r = atanh(x); break;
+            case 30: r = asin(x); break;
+            case 31: r = acos(x); break;
+            case 32: r = atan(x); break;
+            default: return -1;
+        }
+        out[2 * i] = r.re; out[2 * i + 1] = r.im;
     }
     return 0;
 }

@@ -23,6 +23,7 @@ _SIGS = {
     "xs_kf_create_sharded": (_vp, [C.c_char_p, C.c_int, C.c_int, COLLECTIVE_CB, _vp]),
     "xs_kf_shard_planes": (None, [_vp, _i32p, _i32p]),
     "xs_host_double_complex_table": (C.c_int, [C.c_int, C.c_long, _f32p, _f32p, _f32p]),
+    "xs_host_complex_table": (C.c_int, [C.c_int, C.c_long, _f32p, _f32p, _f32p]),
     "xs_flat_yaml_get": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
     "xs_kf_set_stream": (None, [_vp]),
     "xs_kf_create": (_vp, [C.c_char_p]),
@@ -85,6 +86,17 @@ def host_double_complex(op, a, b=None):
     b = a if b is None else np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 4)
     out = np.empty_like(a)
     rc = _lib.xs_host_double_complex_table(HDC_OPS[op], a.shape[0], a.ctypes.data_as(_f32p), b.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
+    if rc != 0:
+        raise ValueError("bad op")
+    return out
+
+
+def host_complex(op_code, a, b=None):
+    """Elementwise complex<float> op of csrc/xs_complex.h compiled for the host, over [n, 2] float32 arrays (CPU)."""
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 2)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 2)
+    out = np.empty_like(a)
+    rc = _lib.xs_host_complex_table(int(op_code), a.shape[0], a.ctypes.data_as(_f32p), b.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
     if rc != 0:
         raise ValueError("bad op")
     return out
