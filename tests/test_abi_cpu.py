@@ -118,6 +118,74 @@ def test_product_complex_header_on_the_host_against_reference_tables():
         pl.host_complex(99, t["gen_a"])
 
 
+# the reference's declarations of the launcher API (signatures as in XKinectFusion/include/TsdfVolume.h:16,
+# TsdfFusion.h:40-45, RayCaster.h:21-25, ICP.h:24-31, Map.h:16-54), restated over this repository's argument types, and
+# a caller of each: what the shim documented in INTEGRATION.md has to satisfy at link time
+_REFERENCE_DECLARATIONS = r"""
+#pragma once
+#include "xs_types.hpp"
+void initVolume(PtrStep<short2> volume, PtrStep<float> value_volume, PtrStep<int> weight_volume, PtrStep<float> grad_volume,
+                const int3 &volume_resolution);
+void integrateTsdfVolume(const PtrStepSz<ushort> &depth, const Intr &intr, int max_weight, const int3 &volume_resolution,
+                         float voxel_size, const MatS33 &Rv2c, const devComplex3 &tv2c, const devComplex3 &tc2v, float tranc_dist,
+                         PtrStep<float> value_volume, PtrStep<int> weight_volume, PtrStep<float> grad_volume,
+                         DeviceArray2D<float> &depthScaled, int frame_id, float threshold = 0.0f, float k = 0.0f);
+void raycast(const Intr &intr, const MatS33 &Rc2v, const devComplex3 &tc2v, const MatS33 &Rv2w, const devComplex3 &tv2w,
+             float tranc_dist, const int3 &volume_resolution, float voxel_size, const PtrStep<float> &value_volume,
+             const PtrStep<float> &grad_volume, MapArr &vmap, MapArr &nmap);
+void estimateCombined(const MatS33 &Rcurr, const devComplex3 &tcurr, const MapArr &vmap_curr, const MapArr &nmap_curr,
+                      const MatS33 &Rprev_inv, const devComplex3 &tprev, const Intr &intr, const MapArr &vmap_g_prev,
+                      const MapArr &nmap_g_prev, float distThres, float angleThres, DeviceArray2D<devComplexICP> &gbuf,
+                      DeviceArray<devComplexICP> &mbuf, hostComplexICP *matrixA_host, hostComplexICP *vectorB_host);
+void bilateralFilter(const DeviceArray2D<ushort> &src, MapArr &dst);
+void pyrDown(const MapArr &src, MapArr &dst);
+void createVMap(const Intr &intr, const MapArr &depth, MapArr &vmap);
+void createNMap(const MapArr &vmap, MapArr &nmap);
+void resizeVMap(const MapArr &input, MapArr &output);
+void resizeNMap(const MapArr &input, MapArr &output);
+"""
+_CALLER = r"""
+#include "CudaFunctions.h"
+void call_every_launcher() {
+    DeviceArray2D<ushort> depth; DeviceArray2D<float> scaled, value, grad; DeviceArray2D<int> weight; DeviceArray2D<short2> vol;
+    MapArr a, b, c, d; Intr k(1, 1, 0, 0); MatS33 R{}; devComplex3 t{}; int3 res{64, 64, 64};
+    DeviceArray2D<devComplexICP> gbuf; DeviceArray<devComplexICP> mbuf; hostComplexICP A[36], B[6];
+    initVolume(vol, value, weight, grad, res);
+    integrateTsdfVolume(depth, k, 100, res, 0.1f, R, t, t, 0.3f, value, weight, grad, scaled, 0);
+    raycast(k, R, t, R, t, 0.3f, res, 0.1f, value, grad, a, b);
+    estimateCombined(R, t, a, b, R, t, k, c, d, 0.1f, 0.2f, gbuf, mbuf, A, B);
+    bilateralFilter(depth, a); pyrDown(a, b); createVMap(k, a, b); createNMap(b, c); resizeVMap(a, b); resizeNMap(a, b);
+}
+"""
+
+
+def test_integration_md_shim_compiles_and_links(tmp_path):
+    """The reference-side binding shown in INTEGRATION.md section 2 is compiled as written against include/xslam_amd.h and linked,
+    with --no-undefined, together with a caller of every function the reference declares: a stale argument list in the
+    document (round 1: xs_raycast's workspace argument was missing) or a definition whose signature differs from the
+    reference's declaration fails here.  No GPU call is made."""
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", text, flags=re.S)
+    shim = [b for b in blocks if "HipLaunchers.cpp" in b]
+    assert len(shim) == 1
+    (tmp_path / "CudaFunctions.h").write_text(_REFERENCE_DECLARATIONS)
+    (tmp_path / "HipLaunchers.cpp").write_text(shim[0])
+    (tmp_path / "caller.cpp").write_text(_CALLER)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Werror=return-type", "-D__HIP_PLATFORM_AMD__", f"-I{tmp_path}",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "x-slam_amd", "host"), f"-I{rocm}/include",
+           str(tmp_path / "HipLaunchers.cpp"), str(tmp_path / "caller.cpp"), "-o", str(tmp_path / "libshim.so"), "-Wl,--no-undefined",
+           "-L" + os.path.join(ROOT, "x-slam_amd"), "-lxslam_hip", f"-L{rocm}/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "x-slam_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # and the argument count the document passes to every xs_ function equals the header's
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "xslam_amd.h")).read(), flags=re.S)
+    nargs = {m.group(1): m.group(2).count(",") + 1 for m in re.finditer(r"\b(xs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)}
+    assert nargs["xs_raycast"] == 19
+
+
 def test_flat_yaml_reads_the_reference_config_format():
     """The reference's shipped config (Experiments/test_xkinect_fusion/configs/ICL_traj2.yaml) is flat
     key: value with comments, quoted strings and blank lines; all 34 keys must come through."""
