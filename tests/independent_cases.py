@@ -1,0 +1,280 @@
+"""The cases that hold a kernel implementation (the CPU oracle on the CPU suite, the HIP kernels through the C ABI on
+the GPU suite) against tests/independent_f64.py: values against the float64 model, CSFD derivatives (imaginary parts / h)
+against float64 central differences.  Test infrastructure."""
+import numpy as np
+
+import independent_f64 as ind
+from helpers import intr_of, s1_transforms, synth, tranc_dist
+
+H, W = synth.HEIGHT, synth.WIDTH
+Hs = 1e-7          # first-order seed step (Internal.h:33-34)
+FD = 1e-5          # central-difference step of the float64 model (metres / radians of the seeded pose entry)
+
+
+class OracleBackend:
+    """oracle/ (complex<float> CPU restatement) behind the interface the cases use."""
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def scale_depth(self, d):
+        return self.o.scale_depth(d)
+
+    def integrate(self, state, depth_m, prm, T, threshold):
+        n = prm["tsdf_size_x"]
+        v, w, g = (a.copy() for a in state)
+        self.o.integrate(depth_m, v, w, g, [n, n, n], tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm), prm["tsdf_voxel_size"],
+                         threshold=threshold)
+        return v, w, g
+
+    def raycast(self, state, prm, T):
+        n = prm["tsdf_size_x"]
+        vm, nm, hits = self.o.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), [n, n, n],
+                                      prm["tsdf_voxel_size"], state[0], state[2], H, W)
+        return vm, nm, hits
+
+    def current_maps(self, depth_u16, prm, level):
+        d = self.o.bilateral(depth_u16)
+        for _ in range(level):
+            d = self.o.pyr_down(d)
+        v = self.o.create_vmap(intr_of(prm, level), d)
+        return v, self.o.create_nmap(v)
+
+    def resize(self, vm, nm):
+        return self.o.resize_map(vm, False), self.o.resize_map(nm, True)
+
+    def m3_inverse(self, R):
+        return self.o.m3_inverse(R)
+
+    def icp(self, Rcurr, tcurr, cv, cn, Rprev_inv, tprev, k, pv, pn, dist, angle):
+        s, _, _, inl = self.o.icp_combined(Rcurr, tcurr, cv, cn, Rprev_inv, tprev, k, pv, pn, dist, angle)
+        return s, inl
+
+    def hessian(self, depth_m, prm, R36, t12, gt, z0=0, z1=None):
+        n = prm["tsdf_size_x"]
+        return self.o.tsdf_hessian(depth_m, [n, n, n], prm["tsdf_voxel_size"], R36, t12, tranc_dist(prm), intr_of(prm), gt, z0=z0, z1=z1)
+
+
+class GpuBackend:
+    """The HIP kernels through the C ABI (x-slam_amd/capi.py)."""
+    def __init__(self, torch, capi, host_m3_inverse):
+        self.t, self.c, self._inv = torch, capi, host_m3_inverse
+
+    def dev(self, a):
+        a = np.ascontiguousarray(a)
+        return self.t.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).cuda()
+
+    def scale_depth(self, d):
+        out = self.t.zeros((H, W), dtype=self.t.float32, device="cuda")
+        self.c.scale_depth(self.dev(d), W * 2, H, W, out, W * 4)
+        self.t.cuda.synchronize()
+        return out.cpu().numpy()
+
+    def integrate(self, state, depth_m, prm, T, threshold):
+        n = prm["tsdf_size_x"]
+        v, w, g = (self.dev(a) for a in state)
+        self.c.integrate_scaled(self.dev(depth_m), W * 4, H, W, intr_of(prm), 100, [n, n, n], prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"],
+                                tranc_dist(prm), v, w, g, n * 4, threshold=threshold)
+        self.t.cuda.synchronize()
+        return v.cpu().numpy(), w.cpu().numpy(), g.cpu().numpy()
+
+    def raycast(self, state, prm, T):
+        n = prm["tsdf_size_x"]
+        vm = self.t.zeros((3 * H, W, 2), dtype=self.t.float32, device="cuda")
+        nm = self.t.zeros_like(vm)
+        hits = self.t.zeros(1, dtype=self.t.int64, device="cuda")
+        self.c.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), [n, n, n], prm["tsdf_voxel_size"],
+                       self.dev(state[0]), self.dev(state[2]), n * 4, vm, nm, W * 8, H, W, hits=hits)
+        self.t.cuda.synchronize()
+        return vm.cpu().numpy(), nm.cpu().numpy(), int(hits.item())
+
+    def current_maps(self, depth_u16, prm, level):
+        t, c = self.t, self.c
+        rows, cols = H, W
+        d = t.zeros((rows, cols, 2), dtype=t.float32, device="cuda")
+        c.bilateral_filter(self.dev(depth_u16), W * 2, H, W, d, W * 8)
+        for _ in range(level):
+            nd = t.zeros((rows // 2, cols // 2, 2), dtype=t.float32, device="cuda")
+            c.pyr_down(d, cols * 8, rows, cols, nd, (cols // 2) * 8)
+            d, rows, cols = nd, rows // 2, cols // 2
+        v = t.zeros((3 * rows, cols, 2), dtype=t.float32, device="cuda")
+        nm = t.zeros_like(v)
+        c.create_vmap(intr_of(prm, level), d, cols * 8, rows, cols, v, cols * 8)
+        c.create_nmap(v, nm, cols * 8, rows, cols)
+        t.cuda.synchronize()
+        return v.cpu().numpy(), nm.cpu().numpy()
+
+    def resize(self, vm, nm):
+        t, c = self.t, self.c
+        rows, cols = vm.shape[0] // 3, vm.shape[1]
+        ov = t.zeros((3 * (rows // 2), cols // 2, 2), dtype=t.float32, device="cuda")
+        on = t.zeros_like(ov)
+        c.resize_vmap(self.dev(vm), cols * 8, rows, cols, ov, (cols // 2) * 8)
+        c.resize_nmap(self.dev(nm), cols * 8, rows, cols, on, (cols // 2) * 8)
+        t.cuda.synchronize()
+        return ov.cpu().numpy(), on.cpu().numpy()
+
+    def m3_inverse(self, R):
+        return self._inv(R)
+
+    def icp(self, Rcurr, tcurr, cv, cn, Rprev_inv, tprev, k, pv, pn, dist, angle):
+        t, c = self.t, self.c
+        rows, cols = cv.shape[0] // 3, cv.shape[1]
+        ws = t.zeros(c.icp_workspace_bytes(), dtype=t.uint8, device="cuda")
+        sums = t.zeros(55, dtype=t.float64, device="cuda")
+        c.icp_accumulate(Rcurr, tcurr, self.dev(cv), self.dev(cn), Rprev_inv, tprev, k, self.dev(pv), self.dev(pn), cols * 8, rows, cols, dist, angle,
+                         ws, sums)
+        t.cuda.synchronize()
+        s = sums.cpu().numpy()
+        return s[:54], int(s[54])
+
+    def hessian(self, depth_m, prm, R36, t12, gt, z0=0, z1=None):
+        t, c = self.t, self.c
+        n = prm["tsdf_size_x"]
+        z1 = n if z1 is None else z1
+        ws = t.zeros(c.tsdf_reduce_workspace_bytes(), dtype=t.uint8, device="cuda")
+        out = t.zeros(4, dtype=t.float64, device="cuda")
+        c.compute_local_tsdf_hessian(self.dev(depth_m), W * 4, H, W, intr_of(prm), [n, n, n], prm["tsdf_voxel_size"], R36, t12, tranc_dist(prm),
+                                     self.dev(gt), ws, out, z0=z0, z1=z1)
+        t.cuda.synchronize()
+        return out.cpu().numpy()
+
+
+def _frame(scene, k):
+    return synth.s3_frame(k) if scene == "s3" else synth.s1_frame(k)
+
+
+def _flat_to_zyx(a, n):
+    return np.asarray(a).reshape(n, n, n)
+
+
+def two_frames(be, n, scene, seed, threshold):
+    """Volume after frames 0 and 1 (each with the seeded pose of its frame), through the implementation under test."""
+    prm = synth.s1_params(n, seed=seed, threshold=threshold)
+    state0 = (np.zeros(n ** 3, np.float32), np.zeros(n ** 3, np.int32), np.zeros(n ** 3, np.float32))
+    out = [state0]
+    for k in (0, 1):
+        T = s1_transforms(k, prm, seed=seed)
+        out.append(be.integrate(out[-1], be.scale_depth(_frame(scene, k)), prm, T, threshold))
+    return prm, out
+
+
+def check_integrate(be, n=128, scene="s3", seed=(2, 3), threshold=0.0, samples=200000, rng_seed=1):
+    """Voxel update of frame 1 on top of frame 0: every sampled voxel the kernel wrote, value and d/dseed."""
+    prm, states = two_frames(be, n, scene, seed, threshold)
+    T = s1_transforms(1, prm, seed=seed)
+    depth_m = be.scale_depth(_frame(scene, 1))
+    (v0, w0, g0), (v1, w1, g1) = states[1], states[2]
+    rng = np.random.default_rng(rng_seed)
+    written = np.nonzero(w1 != w0)[0]
+    band = written[np.abs(v1[written]) < 0.999]                       # inside the truncation band: the voxels that carry a derivative
+    pick = np.unique(np.concatenate([rng.choice(written, min(samples, written.size), replace=False),
+                                     rng.choice(band, min(samples, band.size), replace=False),
+                                     rng.choice(n ** 3, samples // 4, replace=False)]))
+    xyz = np.stack([pick % n, (pick // n) % n, pick // (n * n)], -1)
+    args = (T["Rv2c"], T["tv2c"], xyz, depth_m, intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm), threshold, v0[pick], g0[pick], w0[pick])
+    f0, dec = ind.integrate(0.0, Hs, *args)
+    fp, _ = ind.integrate(+FD, Hs, *args, dec=dec)
+    fm, _ = ind.integrate(-FD, Hs, *args, dec=dec)
+    dmodel = (fp - fm) / (2 * FD)
+    upd_impl = w1[pick] != w0[pick]
+    upd_model = dec["update"]
+    m = upd_impl & upd_model
+    got_v, got_d = v1[pick][m].astype(np.float64), g1[pick][m].astype(np.float64) / Hs
+    scale_d = np.abs(dmodel[m]).max()
+    out = dict(n_voxels=int(m.sum()), n_band=int((np.abs(f0[m]) < 0.999).sum()),
+               written_disagree=float((upd_impl != upd_model).mean()),
+               value_bad=float((np.abs(got_v - f0[m]) > 2e-5).mean()), value_err_p999=float(np.quantile(np.abs(got_v - f0[m]), 0.999)),
+               deriv_scale=float(scale_d),
+               deriv_bad=float((np.abs(got_d - dmodel[m]) > 1e-3 * scale_d).mean()),
+               deriv_err_p999_rel=float(np.quantile(np.abs(got_d - dmodel[m]), 0.999) / scale_d),
+               bilinear_share=float(dec["bil"][m].mean()))
+    return out
+
+
+def check_raycast(be, n=128, scene="s3", seed=(2, 3), threshold=0.0, samples=20000, rng_seed=2):
+    """Rays of the pose of frame 2 into the volume of frames 0-1: vertex and normal maps, values and d/dseed."""
+    prm, states = two_frames(be, n, scene, seed, threshold)
+    state = states[2]
+    T = s1_transforms(2, prm, seed=seed)
+    vm, nm, hits = be.raycast(state, prm, T)
+    rng = np.random.default_rng(rng_seed)
+    pix = np.sort(rng.choice(H * W, samples, replace=False))
+    py, px = pix // W, pix % W
+    vol, grd = _flat_to_zyx(state[0], n), _flat_to_zyx(state[2], n)
+    args = (intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), [n, n, n], prm["tsdf_voxel_size"], vol, grd, px, py)
+    v0, n0, dec = ind.raycast(0.0, Hs, *args)
+    vp, np_, _ = ind.raycast(+FD, Hs, *args, dec=dec)
+    vm_, nm_, _ = ind.raycast(-FD, Hs, *args, dec=dec)
+    dv, dn = (vp - vm_) / (2 * FD), (np_ - nm_) / (2 * FD)
+    gv = np.stack([vm[py + p * H, px] for p in range(3)], 1)          # [samples, 3, 2]
+    gn = np.stack([nm[py + p * H, px] for p in range(3)], 1)
+    hit_impl, nrm_impl = ~np.isnan(gv[:, 0, 0]), ~np.isnan(gn[:, 0, 0])
+    both = hit_impl & dec["hit"]
+    bn = nrm_impl & dec["has_normal"] & both
+    ev = np.abs(gv[both][:, :, 0] - v0[both]).max(-1)
+    en = np.abs(gn[bn][:, :, 0] - n0[bn]).max(-1)
+    sdv, sdn = np.abs(dv[both]).max(), np.abs(dn[bn]).max()
+    edv = np.abs(gv[both][:, :, 1] / Hs - dv[both]).max(-1)
+    edn = np.abs(gn[bn][:, :, 1] / Hs - dn[bn]).max(-1)
+    return dict(hits=int(hits), n_hit=int(both.sum()), hit_disagree=float((hit_impl != dec["hit"]).mean()),
+                normal_disagree=float((nrm_impl[both] != dec["has_normal"][both]).mean()),
+                vertex_bad=float((ev > 2e-5).mean()), vertex_err_p99=float(np.quantile(ev, 0.99)),
+                normal_bad=float((en > 2e-3).mean()), normal_err_p99=float(np.quantile(en, 0.99)),
+                dvertex_scale=float(sdv), dvertex_bad=float((edv > 2e-2 * sdv).mean()), dvertex_err_p99_rel=float(np.quantile(edv, 0.99) / sdv),
+                dnormal_scale=float(sdn), dnormal_bad=float((edn > 5e-2 * sdn).mean()), dnormal_err_p99_rel=float(np.quantile(edn, 0.99) / sdn))
+
+
+def check_icp(be, n=128, scene="s3", seed=(2, 3), threshold=0.0, level=0):
+    """27 complex sums of one ICP iteration (frame 2 against the model maps raycast at the pose of frame 1)."""
+    prm, states = two_frames(be, n, scene, seed, threshold)
+    T1 = s1_transforms(1, prm, seed=seed)
+    pv, pn, _ = be.raycast(states[2], prm, T1)
+    for _ in range(level):
+        pv, pn = be.resize(pv, pn)
+    cv, cn = be.current_maps(_frame(scene, 2), prm, level)
+    k = intr_of(prm, level)
+    Rprev_inv = be.m3_inverse(T1["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    sums, inl = be.icp(T1["Rc2w"], T1["tc2w"], cv, cn, Rprev_inv, T1["tc2w"], k, pv, pn, 0.10, angle)
+    args = (T1["Rc2w"], T1["tc2w"], cv, cn, Rprev_inv, T1["tc2w"], k, pv, pn, 0.10, angle)
+    s0, inl0, dec = ind.icp_normal_equations(0.0, Hs, *args)
+    sp, _, _ = ind.icp_normal_equations(+FD, Hs, *args, dec=dec)
+    sm, _, _ = ind.icp_normal_equations(-FD, Hs, *args, dec=dec)
+    ds = (sp - sm) / (2 * FD)
+    re, im = sums[0::2], sums[1::2] / Hs
+    return dict(inliers=int(inl), inliers_model=int(inl0), value_err_rel=float(np.abs(re - s0).max() / np.abs(s0).max()),
+                deriv_scale=float(np.abs(ds).max()), deriv_err_rel=float(np.abs(im - ds).max() / np.abs(ds).max()))
+
+
+def dual_pose(prm, k, h=1e-6):
+    """volume-to-camera pose of frame k as dual-complex groups with both first-order seeds on t_x (tests/golden/make_golden.py: hessian)."""
+    w2v = np.eye(4)
+    w2v[:3, 3] = [prm["init_x"], prm["init_y"], prm["init_z"]]
+    v2c = np.linalg.inv(w2v @ synth.s1_pose(k))
+    R = np.zeros((3, 3, 4), np.float32)
+    R[..., 0] = v2c[:3, :3]
+    t = np.zeros((3, 4), np.float32)
+    t[:, 0] = v2c[:3, 3]
+    t[0, 1] = h
+    t[0, 2] = h
+    return R, t
+
+
+def check_hessian(be, n=128, scene="s3", k=1, z0=0, z1=None, gt=None, fd=2e-4):
+    """Dual-complex local-TSDF residual: loss, d/dt_x and d2/dt_x^2 of the sum of squared errors against the TSDF of frame 0."""
+    prm = synth.s1_params(n)
+    h2 = 1e-6                                                           # DoubleComplex.cpp:61-66
+    if gt is None:
+        _, states = two_frames(be, n, scene, (0, 3), 0.0)
+        gt = states[1][0]
+    depth_m = be.scale_depth(_frame(scene, k))
+    R, t = dual_pose(prm, k, h2)
+    out = be.hessian(depth_m, prm, R, t, gt if z1 is None else gt[z0 * n * n:z1 * n * n], z0, z1)
+    g3 = _flat_to_zyx(gt, n)
+    args = (R, t, g3, depth_m, intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm), z0, z1)
+    l0, c0, dec = ind.tsdf_residual_loss(0.0, h2, *args)
+    lp, _, _ = ind.tsdf_residual_loss(+fd, h2, *args, dec=dec)
+    lm, _, _ = ind.tsdf_residual_loss(-fd, h2, *args, dec=dec)
+    g_model, h_model = (lp - lm) / (2 * fd), (lp - 2 * l0 + lm) / (fd * fd)
+    return dict(count=float(out[3]), count_model=c0, loss=float(out[0]), loss_model=l0, grad=float(out[1] / h2), grad_model=g_model,
+                hess=float(out[2] / h2 / h2), hess_model=h_model)
