@@ -230,6 +230,58 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     a.close(); b.close()
 
 
+def test_checkpoint_rejects_bad_files_without_touching_state(dev, tmp_path):
+    """loadCheckpoint validates the whole file before it changes anything: a wrong magic, another resolution / voxel size,
+    a zero, negative or absurd pose count, a truncated file and trailing bytes all return false and leave the pipeline
+    exactly where it was (the next frame gives the same bits as an instance that never saw the bad file)."""
+    import struct
+    torch, pl = dev
+    prm = synth.s1_params(64)
+    a, ref = pl.KinectFusion(prm), pl.KinectFusion(prm)
+    for k in range(3):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and ref.process_frame(d) == 1
+    good = str(tmp_path / "good.ckpt")
+    a.save_checkpoint(good)
+    blob = open(good, "rb").read()
+    hdr = struct.Struct("<8s3iff2i4i")            # magic, res[3], voxel_size, tranc_dist, frame_id, n_poses, zs0, zs1, rank, count
+    f = list(hdr.unpack_from(blob))
+    assert f[0].rstrip(b"\0") == b"XSTSDF2" and f[1:4] == [64, 64, 64] and f[7] == 3 and f[8:10] == [0, 64] and f[10:12] == [0, 1]
+
+    def variant(name, **kw):
+        g = list(f)
+        idx = dict(magic=0, res0=1, voxel_size=4, tranc_dist=5, frame_id=6, n_poses=7, zs0=8, zs1=9, rank=10, count=11)
+        tail = kw.pop("tail", None)
+        cut = kw.pop("cut", None)
+        for k_, v in kw.items():
+            g[idx[k_]] = v
+        data = hdr.pack(*g) + blob[hdr.size:]
+        if cut is not None:
+            data = data[:cut]
+        if tail is not None:
+            data += tail
+        path = str(tmp_path / f"{name}.ckpt")
+        open(path, "wb").write(data)
+        return path
+    bad = [variant("magic", magic=b"XSTSDF1\0"), variant("res", res0=32), variant("voxel", voxel_size=0.5), variant("trunc", tranc_dist=1.0),
+           variant("poses0", n_poses=0), variant("posesneg", n_poses=-5), variant("poseshuge", n_poses=2 ** 30), variant("frameneg", frame_id=-1),
+           variant("planes", zs1=32), variant("rank", rank=1, count=2), variant("short", cut=len(blob) - 4096), variant("header_only", cut=hdr.size),
+           variant("tiny", cut=10), variant("trailing", tail=b"\0" * 16), str(tmp_path / "does_not_exist.ckpt")]
+    poses_before, frame_before = a.num_poses(), a.frame_id
+    for path in bad:
+        assert not a.load_checkpoint(path), path
+        assert a.num_poses() == poses_before and a.frame_id == frame_before
+    d = upload(torch, synth.s1_frame(3))
+    assert a.process_frame(d) == 1 and ref.process_frame(d) == 1
+    assert np.array_equal(a.world2camera(), ref.world2camera())
+    for x, y in zip(a.volume(), ref.volume()):
+        assert np.array_equal(x, y)
+    # and the good file still loads into a fresh instance
+    b = pl.KinectFusion(prm)
+    assert b.load_checkpoint(good) and b.frame_id == 3
+    a.close(); b.close(); ref.close()
+
+
 def test_host_and_device_depth_entry_points_agree(dev):
     torch, pl = dev
     prm = synth.s1_params(64)

@@ -170,3 +170,75 @@ def test_single_rank_composite_path(dev):
     per_frame = calls[-2:]
     assert per_frame[0] == (1, 640 * 480) and per_frame[1][0] == 2 and per_frame[1][1] == 2 * 3 * 480 * (640 * 8 // 4)
     single.close(); forced.close()
+
+
+def test_sharded_checkpoint_roundtrip(dev, tmp_path):
+    """Every rank of a sharded run saves its own planes (owned slab + halo) and a fresh set of ranks restores them: the
+    restored run continues with the same bits as the one that never stopped; a rank refuses another rank's file and a
+    single-GPU checkpoint."""
+    torch, pl, sh = dev
+    n, world = 96, 2
+    prm = synth.s1_params(n)
+    shards, _ = run_world(torch, sh, prm, world, [0, 1, 2])
+    paths = [str(tmp_path / f"rank{r}.ckpt") for r in range(world)]
+    for r in range(world):
+        shards[r].save_checkpoint(paths[r])
+    single = pl.KinectFusion(prm)
+    assert single.process_frame(torch.from_numpy(synth.s1_frame(0).view(np.int16)).cuda()) == 1
+    single.save_checkpoint(str(tmp_path / "single.ckpt"))
+    lw = sh.LocalWorld(torch, world)
+    fresh = [sh.ShardedKinectFusion(prm, r, world, collective=lw.collective_for(r)) for r in range(world)]
+    assert not fresh[0].load_checkpoint(paths[1]) and not fresh[1].load_checkpoint(paths[0])
+    assert not fresh[0].load_checkpoint(str(tmp_path / "single.ckpt"))
+    d3 = torch.from_numpy(synth.s1_frame(3).view(np.int16)).cuda()
+    out = {}
+    errors = []
+
+    def resume(r):
+        try:
+            assert fresh[r].load_checkpoint(paths[r])      # the restore re-raycasts the model maps: a collective, every rank takes part
+            assert fresh[r].frame_id == 3
+            assert fresh[r].process_frame(d3) == 1
+            out[("fresh", r)] = (fresh[r].world2camera(), fresh[r].volume())
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e); lw.barrier.abort()
+    th = [threading.Thread(target=resume, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors, errors
+    # the original ranks take the same frame
+    errors2 = []
+
+    def go_on(r):
+        try:
+            assert shards[r].process_frame(d3) == 1
+            out[("orig", r)] = (shards[r].world2camera(), shards[r].volume())
+        except BaseException as e:  # noqa: BLE001
+            errors2.append(e)
+    th = [threading.Thread(target=go_on, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors2, errors2
+    for r in range(world):
+        assert np.array_equal(out[("fresh", r)][0], out[("orig", r)][0])
+        for x, y in zip(out[("fresh", r)][1], out[("orig", r)][1]):
+            assert np.array_equal(x, y)
+    for s_ in shards + fresh:
+        s_.close()
+    single.close()
+
+
+def test_cpp_host_runs_shard_mode_over_rccl_without_python():
+    """x-slam_amd/smoke_rccl (host/smoke_rccl.cpp): a C++ program that creates an RCCL communicator through
+    libxslam_rccl.so (include/xslam_amd_rccl.h), hands xs_rccl_collective to xs_kf_create_sharded and tracks four frames
+    of a synthetic room corner in shard mode with the ICP rows all-reduced — world = 1 here (one GPU), so the 44
+    collectives are single-rank ncclAllReduce calls on the orchestrator's stream."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "x-slam_amd", "smoke_rccl")
+    assert os.path.exists(exe), "smoke_rccl not built: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["tracked"] == 1 and out["collective_calls"] == 44 and out["rccl_version"] > 0

@@ -90,9 +90,9 @@ __device__ __forceinline__ void publish_done(const IcpArgs &a) {
 // Pose mailbox (xs_icp_post_pose writes it, k_icp<POSE_POSTED> polls it; xs_icp_mailbox_alloc puts it in
 // device memory the CPU reaches through the large BAR, so polling stays off the PCIe link — 512
 // workgroups polling pinned host memory cost 50 us per iteration): two 64-byte lines of 16
-// words, each line starting with the sequence number so that a line read as one unit is known to
-// be complete:   line 0 = {seq, cmd, f[0..13]}   line 1 = {seq, 0, f[14..23], pad}   with f = the 18
-// floats of Rcurr followed by the 6 of tcurr; cmd 0 = run, 1 = abandon the launch.
+// words, each line starting with the sequence number:   line 0 = {seq, cmd, f[0..13]}   line 1 = {seq, 0, f[14..23], pad}
+// with f = the 18 floats of Rcurr followed by the 6 of tcurr; cmd 0 = run, 1 = abandon the launch.  The poller takes
+// the payload from a second load issued after it has seen both sequence words (see there).
 enum { POSE_ARGS = 0, POSE_DEVICE = 1, POSE_POSTED = 2 };
 enum { MAILBOX_WORDS = 32, MAILBOX_MAX_POLLS = 400000 };  // ~2 us per poll: gives up after about a second
 constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
@@ -136,6 +136,18 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
                 if (s0 == a.mailbox_seq && s1 == a.mailbox_seq) break;
                 if (polls >= MAILBOX_MAX_POLLS) { cmd_override = 2; break; }
                 __builtin_amdgcn_s_sleep(8);
+            }
+            // The load that saw both sequence words is not taken as the payload: sixteen lanes reading one line are
+            // one request in practice, but nothing promises that its sectors are read at one instant, and a line caught
+            // between the host's payload stores and its sequence store would hand over a mixed pose without any error.
+            // The host orders payload -> store fence -> sequence words -> store fence (xs_icp_post_pose), so a load
+            // ISSUED after the sequence words were seen returns the complete payload: read the 32 words once more
+            // (the exit test above consumed v, i.e. the first load has returned before this one is issued; both are
+            // system-scope and bypass the caches).  The sequence words are checked again on the way.
+            if (!cmd_override) {
+                v = __hip_atomic_load(a.mailbox + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
+                if (s0 != a.mailbox_seq || s1 != a.mailbox_seq) cmd_override = 2;   // the host broke the one-post-per-launch contract
             }
             if (threadIdx.x < MAILBOX_WORDS) s_mail[threadIdx.x] = threadIdx.x == 1 && cmd_override ? cmd_override : v;
         }

@@ -341,10 +341,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 inliers = (long long)pinned_sums_[54];
             } else
                 icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
-            // The solve and the post come first: the enqueued launch is waiting for them.  The reference's
-            // determinant gate (:203-210) is evaluated right after; a launch that was handed the pose of a
-            // singular system finishes unobserved (nothing reads its sums, the next launch on the stream
-            // follows it).
+            // The solve and the post come first: the enqueued launch is waiting for them.
             hostComplexICP sol[6];
             llt_solve6(A, b, sol);
             hostComplex result[6];
@@ -356,10 +353,15 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
             Vector3cf tnext;
             for (int i = 0; i < 3; ++i) tnext[i] = rt[i] + tinc[i];
             const Matrix3frm Rnext = Rinc * Rcurr;
-            if (next_enqueued)
-                xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rnext).data[0].x.re, &device_cast<devComplex3>(tnext).x.re, next_mail_seq, 0);
+            // the reference's determinant gate (:203-210): a 6x6 LU in double, a fraction of a microsecond, so it is taken
+            // before the post — the enqueued launch of a singular system is told to leave (cmd 1) instead of running
+            // unobserved on maps the next frame's preparation may already be rewriting
             const double det = real_determinant6(A);
             const bool singular = fabs(det) < 1e-15 || std::isnan(det);
+            if (next_enqueued) {
+                if (singular) xs_icp_post_pose(mailbox, nullptr, nullptr, next_mail_seq, 1);
+                else xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rnext).data[0].x.re, &device_cast<devComplex3>(tnext).x.re, next_mail_seq, 0);
+            }
             {   // diagnostics: re-pack the 27 sums in launch order
                 int shift = 0;
                 for (int i = 0; i < 6; ++i)
@@ -816,18 +818,34 @@ void KinectFusionReconstruction::saveTSDFVolume(const std::string &tsdf_filename
     f.write(reinterpret_cast<const char *>(tsdf.data()), (std::streamsize)(tsdf.size() * sizeof(float)));
 }
 namespace {
-struct CkptHeader { char magic[8]; int res[3]; float voxel_size, tranc_dist; int frame_id; int n_poses; };
+// Volume checkpoint, version 2.  Layout: header, n_poses x Matrix4cf, then value / grad / weight of the stored planes
+// [zs0, zs1) as dense rows of X elements (a rank of a sharded run saves and restores its own planes).
+struct CkptHeader {
+    char magic[8];
+    int res[3];
+    float voxel_size, tranc_dist;
+    int frame_id, n_poses;
+    int zs0, zs1;        // planes held in this file
+    int shard_rank, shard_count;
+};
+const int CKPT_MAX_POSES = 1 << 24;   // a sanity bound on the pose record (16 M frames), not a format limit
+// one device <- host copy of a dense array into the EXISTING pitched buffer (no reallocation, no temporaries)
+template <class T>
+void restore_rows(DeviceArray2D<T> dst, const std::vector<T> &src, int cols, size_t rows) {
+    hipSafeCall(hipMemcpy2D(dst.ptr(), dst.step(), src.data(), (size_t)cols * sizeof(T), (size_t)cols * sizeof(T), rows, hipMemcpyHostToDevice));
 }
+}  // namespace
 void KinectFusionReconstruction::saveCheckpoint(const std::string &filename) {
     std::vector<float> v, g;
     std::vector<int> w;
     tsdf_volume_d_ptr->downloadTSDFWithGrad(v, g);
     tsdf_volume_d_ptr->downloadWeight(w);
     CkptHeader h{};
-    std::snprintf(h.magic, sizeof(h.magic), "XSTSDF1");
+    std::snprintf(h.magic, sizeof(h.magic), "XSTSDF2");
     for (int i = 0; i < 3; ++i) h.res[i] = volume_resolution[i];
     h.voxel_size = voxel_size; h.tranc_dist = tsdf_volume_d_ptr->getTsdfTruncDist(); h.frame_id = frame_id;
     h.n_poses = (int)world2camera_record.size();
+    h.zs0 = zs0; h.zs1 = zs1; h.shard_rank = shard_rank; h.shard_count = shard_count;
     std::ofstream f(filename, std::ios::binary);
     f.write(reinterpret_cast<const char *>(&h), sizeof(h));
     f.write(reinterpret_cast<const char *>(world2camera_record.data()), (std::streamsize)(h.n_poses * sizeof(Matrix4cf)));
@@ -835,29 +853,48 @@ void KinectFusionReconstruction::saveCheckpoint(const std::string &filename) {
     f.write(reinterpret_cast<const char *>(g.data()), (std::streamsize)(g.size() * 4));
     f.write(reinterpret_cast<const char *>(w.data()), (std::streamsize)(w.size() * 4));
 }
+// Nothing of *this is touched until the whole file has been read and validated: magic, volume geometry (resolution,
+// voxel size, truncation distance), the planes it holds against the planes this instance stores, a sane pose count and
+// the exact file length.  Returns false (state unchanged) on any mismatch.
 bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
     std::ifstream f(filename, std::ios::binary);
-    if (!f) return false;
+    if (!f || !tsdf_volume_d_ptr) return false;
+    f.seekg(0, std::ios::end);
+    const long long file_bytes = (long long)f.tellg();
+    f.seekg(0, std::ios::beg);
     CkptHeader h{};
+    if (file_bytes < (long long)sizeof(h)) return false;
     f.read(reinterpret_cast<char *>(&h), sizeof(h));
-    if (std::string(h.magic) != "XSTSDF1") return false;
+    if (!f || std::memcmp(h.magic, "XSTSDF2", 8) != 0) return false;
     for (int i = 0; i < 3; ++i) if (h.res[i] != volume_resolution[i]) return false;
-    world2camera_record.resize(h.n_poses);
-    f.read(reinterpret_cast<char *>(world2camera_record.data()), (std::streamsize)(h.n_poses * sizeof(Matrix4cf)));
-    world2camera = world2camera_record.back();
-    frame_id = h.frame_id;
-    const size_t n = (size_t)h.res[0] * h.res[1] * h.res[2];
+    if (h.voxel_size != voxel_size || h.tranc_dist != tsdf_volume_d_ptr->getTsdfTruncDist()) return false;
+    if (h.zs0 != zs0 || h.zs1 != zs1 || h.shard_rank != shard_rank || h.shard_count != shard_count) return false;
+    if (h.n_poses < 1 || h.n_poses > CKPT_MAX_POSES || h.frame_id < 0) return false;
+    const int X = h.res[0];
+    const size_t rows = (size_t)h.res[1] * (size_t)(h.zs1 - h.zs0), n = rows * (size_t)X;
+    const long long expect = (long long)sizeof(h) + (long long)h.n_poses * (long long)sizeof(Matrix4cf) + 3LL * (long long)n * 4LL;
+    if (file_bytes != expect) return false;            // truncated or trailing bytes
+    std::vector<Matrix4cf> poses((size_t)h.n_poses);
+    f.read(reinterpret_cast<char *>(poses.data()), (std::streamsize)(poses.size() * sizeof(Matrix4cf)));
     std::vector<float> v(n), g(n);
     std::vector<int> w(n);
     f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * 4));
     f.read(reinterpret_cast<char *>(g.data()), (std::streamsize)(n * 4));
     f.read(reinterpret_cast<char *>(w.data()), (std::streamsize)(n * 4));
     if (!f) return false;
-    const int X = h.res[0], rows = h.res[1] * h.res[2];
-    tsdf_volume_d_ptr->value().upload(v.data(), X * 4, rows, X);
-    tsdf_volume_d_ptr->grad().upload(g.data(), X * 4, rows, X);
-    tsdf_volume_d_ptr->weight().upload(w.data(), X * 4, rows, X);
-    // previous-frame maps are derived state: regenerate them from the restored volume and pose
+    DeviceArray2D<float> dv = tsdf_volume_d_ptr->value(), dg = tsdf_volume_d_ptr->grad();
+    DeviceArray2D<int> dw = tsdf_volume_d_ptr->weight();
+    if ((size_t)dv.rows() != rows || dv.cols() != X || (size_t)dg.rows() != rows || (size_t)dw.rows() != rows) return false;
+    // validated: commit
+    synchronize();
+    restore_rows(dv, v, X, rows);
+    restore_rows(dg, g, X, rows);
+    restore_rows(dw, w, X, rows);
+    world2camera_record.swap(poses);
+    world2camera = world2camera_record.back();
+    frame_id = h.frame_id;
+    // previous-frame maps are derived state: regenerate them from the restored volume and pose (in a sharded run every
+    // rank must load its own file before the next frame: the raycast composite is a collective)
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
     ModelMapPyramid();
     synchronize();

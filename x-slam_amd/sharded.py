@@ -81,11 +81,69 @@ class LocalWorld:
         return cb
 
 
+_rccl_lib = None
+
+
+def rccl_lib():
+    """libxslam_rccl.so (include/xslam_amd_rccl.h): the same three collectives as C++ RCCL calls."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        import os
+        lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxslam_rccl.so"))
+        lib.xs_rccl_get_unique_id.restype = C.c_int
+        lib.xs_rccl_get_unique_id.argtypes = [C.c_void_p]
+        lib.xs_rccl_comm_create.restype = C.c_void_p
+        lib.xs_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.xs_rccl_set_stream.restype = None
+        lib.xs_rccl_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.xs_rccl_comm_destroy.restype = C.c_int
+        lib.xs_rccl_comm_destroy.argtypes = [C.c_void_p]
+        lib.xs_rccl_all_reduce.restype = C.c_int
+        lib.xs_rccl_all_reduce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        lib.xs_rccl_version.restype = C.c_int
+        lib.xs_rccl_last_error.restype = C.c_char_p
+        _rccl_lib = lib
+    return _rccl_lib
+
+
+class NativeRccl:
+    """An RCCL communicator owned by the C++ side.  The 128-byte unique id travels from rank 0 over an existing
+    torch.distributed group (any backend) — after that no collective of the pipeline passes through Python: the
+    orchestrator calls xs_rccl_collective directly."""
+
+    def __init__(self, rank, world, dist=None, stream=None):
+        lib = rccl_lib()
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            if lib.xs_rccl_get_unique_id(buf) != 0:
+                raise RuntimeError(lib.xs_rccl_last_error().decode())
+        if world > 1:
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=0)
+            buf = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        sp = None if stream is None else (stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+        self.handle = lib.xs_rccl_comm_create(buf, rank, world, sp)
+        if not self.handle:
+            raise RuntimeError(lib.xs_rccl_last_error().decode())
+        self.callback = C.cast(lib.xs_rccl_collective, _CB)      # the C function itself, not a Python trampoline
+        self.version = lib.xs_rccl_version()
+
+    def all_reduce(self, op, tensor):
+        rc = rccl_lib().xs_rccl_all_reduce(self.handle, op, tensor.data_ptr(), tensor.numel())
+        if rc != 0:
+            raise RuntimeError(rccl_lib().xs_rccl_last_error().decode())
+
+    def close(self):
+        if self.handle:
+            rccl_lib().xs_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+
 class ShardedKinectFusion(pl.KinectFusion):
     """One rank's shard of the pipeline.  `dist` is torch.distributed with an initialised process
     group, or pass `collective` (a Python callable (user, op, ptr, count)) directly."""
 
-    def __init__(self, params, rank, world, dist=None, collective=None, torch=None):
+    def __init__(self, params, rank, world, dist=None, collective=None, torch=None, native=None):
         text = params if isinstance(params, str) else pl.yaml_text(params)
         self.cfg = {}
         for line in text.splitlines():
@@ -93,7 +151,11 @@ class ShardedKinectFusion(pl.KinectFusion):
                 k, v = line.split(":", 1)
                 self.cfg[k.strip()] = v.split("#")[0].strip()
         self.rank, self.world = rank, world
-        if collective is None:
+        user = None
+        if native is not None:
+            # a NativeRccl communicator: the orchestrator calls the C++ collective with the comm handle as user data
+            self._cb, user = native.callback, native.handle
+        elif collective is None:
             if torch is None:
                 import torch
             self._torch, self._dist = torch, dist
@@ -107,8 +169,9 @@ class ShardedKinectFusion(pl.KinectFusion):
                 if t is None:
                     t = views[key] = device_tensor(self._torch, ptr, count, op)
                 reduce_tensor(self._dist, op, t)
-        self._cb = _CB(collective)  # keep the trampoline alive as long as the handle
-        self.h = pl._lib.xs_kf_create_sharded(text.encode(), rank, world, self._cb, None)
+        if native is None:
+            self._cb = _CB(collective)  # keep the trampoline alive as long as the handle
+        self.h = pl._lib.xs_kf_create_sharded(text.encode(), rank, world, self._cb, user)
         if not self.h:
             raise ValueError("xs_kf_create_sharded failed")
         self.res = [int(self.cfg[f"tsdf_size_{a}"]) for a in "xyz"]
