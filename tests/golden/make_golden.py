@@ -117,7 +117,12 @@ def known_answers():
                   "scene S1 frame 0 (wall + sphere, identity pose, 7.68 m cube) in the survey session",
         "integrate_U": {"256": 253946, "512": 1930365},
         "raycast_hits": {"256": 294135, "512": 294338},
-        "tolerance": "U within 0.01 % (SURVEY 8d: rounding flips); hits within 2 pixels",
+        "icp_inliers_level0": {"256": 288814, "512": 289412},
+        "icp_note": "SURVEY.md section 6: reference search_newton + row build, level 0, on the same frame. SURVEY does not record which current-frame "
+                    "maps and which pose the call was given; with frame 0's own bilateral-filtered maps against the model maps raycast from frame 0's "
+                    "volume at the pose of frame 0 (distThres 0.10, angleThres sin 15 deg) the oracle and the HIP kernels both count 289128 / 290033, "
+                    "0.11 % / 0.21 % above the recorded figures: asserted to 0.3 %",
+        "tolerance": "U within 0.01 % (SURVEY 8d: rounding flips); hits within 2 pixels; ICP inliers within 0.3 % (see icp_note)",
     }
     json.dump(sv, open(os.path.join(OUT, "survey_reference_kernel_figures.json"), "w"), indent=1)
 

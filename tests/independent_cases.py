@@ -270,8 +270,8 @@ def check_hessian(be, n=128, scene="s3", k=1, z0=0, z1=None, gt=None, fd=2e-4):
     depth_m = be.scale_depth(_frame(scene, k))
     R, t = dual_pose(prm, k, h2)
     out = be.hessian(depth_m, prm, R, t, gt if z1 is None else gt[z0 * n * n:z1 * n * n], z0, z1)
-    g3 = _flat_to_zyx(gt, n)
-    args = (R, t, g3, depth_m, intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm), z0, z1)
+    g3 = _flat_to_zyx(gt, n)[z0:z1]
+    args = (R, t, g3, depth_m, intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm), z0)
     l0, c0, dec = ind.tsdf_residual_loss(0.0, h2, *args)
     lp, _, _ = ind.tsdf_residual_loss(+fd, h2, *args, dec=dec)
     lm, _, _ = ind.tsdf_residual_loss(-fd, h2, *args, dec=dec)

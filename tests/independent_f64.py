@@ -237,21 +237,19 @@ def icp_normal_equations(d, h, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tp
 
 # ------------------------------------------------------------------------------------------------
 # Dual-complex local-TSDF residual — ComputeLocalTsdfHessianKernel, XKinectFusion/src/TsdfFusion.cu:204-283
-def tsdf_residual_loss(p, h, Rv2c, tv2c, gt, depth_m, intr, voxel_size, trunc, z0=0, z1=None, dec=None):
-    """sum over voxels of planes [z0, z1) of error(p)^2, error = (|Dp (xl, yl, 1)| - |v_c| - gt * trunc) / trunc, for the
-    pose x(p) = re.re + p * re.im / h (Rv2c [3, 3, 4], tv2c [3, 4] dual-complex groups).  gt: [Z, Y, X].
-    Returns (loss, count, dec)."""
+def tsdf_residual_loss(p, h, Rv2c, tv2c, gt_planes, depth_m, intr, voxel_size, trunc, z0=0, dec=None):
+    """sum over the voxels of gt_planes ([nz, Y, X]: planes z0 .. z0 + nz of the map, as the C ABI takes a slab) of error(p)^2,
+    error = (|Dp (xl, yl, 1)| - |v_c| - gt * trunc) / trunc, for the pose x(p) = re.re + p * re.im / h (Rv2c [3, 3, 4],
+    tv2c [3, 4] dual-complex groups).  Returns (loss, count, dec)."""
     Rq, tq = np.asarray(Rv2c, np.float64).reshape(3, 3, 4), np.asarray(tv2c, np.float64).reshape(3, 4)
     R = Rq[..., 0] + (p / h) * Rq[..., 1]
     t = tq[..., 0] + (p / h) * tq[..., 1]
     fx, fy, cx, cy = (float(F32(v)) for v in intr)
     vs, tr = float(F32(voxel_size)), float(F32(trunc))
     rows, cols = depth_m.shape
-    Z, Y, X = gt.shape
-    z1 = Z if z1 is None else z1
     if dec is None:
         assert p == 0.0
-        g = np.asarray(gt[z0:z1], np.float64)
+        g = np.asarray(gt_planes, np.float64)
         band = (g != 0) & ~(np.abs(g) > 0.95)                            # :221-223
         zz, yy, xx = np.nonzero(band)
         dec = dict(xyz=np.stack([xx, yy, zz + z0], -1), gt=g[band])

@@ -82,3 +82,26 @@ def test_hessian_loss_gradient_and_second_derivative(be, scene, n):
     # scale sqrt(loss * hessian) is 6 100): tolerance relative to the larger of the two
     assert abs(r["grad"] - r["grad_model"]) <= 5e-4 * max(abs(r["grad_model"]), (r["loss_model"] * abs(r["hess_model"])) ** 0.5)
     assert abs(r["hess"] - r["hess_model"]) <= 5e-4 * abs(r["hess_model"])
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_survey_reference_kernel_figures_through_the_kernels(be, n):
+    """The counts SURVEY.md section 6 recorded from the reference's own kernel bodies on scene S1 frame 0, through the HIP
+    kernels alone (C ABI, no orchestrator): voxels written by integrate, rays hit by raycast, ICP inliers at level 0
+    (tests/golden/survey_reference_kernel_figures.json; tolerances stated there)."""
+    from helpers import intr_of, s1_transforms, synth
+    fig = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "survey_reference_kernel_figures.json")))
+    prm = synth.s1_params(n)
+    T = s1_transforms(0, prm)
+    d0 = synth.s1_frame(0)
+    zero = (np.zeros(n ** 3, np.float32), np.zeros(n ** 3, np.int32), np.zeros(n ** 3, np.float32))
+    state = be.integrate(zero, be.scale_depth(d0), prm, T, 0.0)
+    U = int((state[1] != 0).sum())
+    pv, pn, hits = be.raycast(state, prm, T)
+    cv, cn = be.current_maps(d0, prm, 0)
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    _, inl = be.icp(T["Rc2w"], T["tc2w"], cv, cn, be.m3_inverse(T["Rc2w"]), T["tc2w"], intr_of(prm), pv, pn, 0.10, angle)
+    LOG[f"survey_figures_{n}"] = dict(U=U, hits=hits, inliers=inl)
+    assert abs(U - fig["integrate_U"][str(n)]) <= max(2, 1e-4 * fig["integrate_U"][str(n)])
+    assert abs(hits - fig["raycast_hits"][str(n)]) <= 2
+    assert abs(inl - fig["icp_inliers_level0"][str(n)]) <= 0.003 * fig["icp_inliers_level0"][str(n)]

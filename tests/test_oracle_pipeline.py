@@ -166,3 +166,27 @@ def test_oracle_gn_terms_agree_with_dual_complex_hessian(oracle):
         grad = 2.0 * gn[21 + k] / float(h1)
         # the dual-complex kernel reports the raw first-derivative part: h2 * dL/dtheta
         assert abs(out4[1] / float(h2) - grad) <= 1e-4 * max(abs(grad), 1e-2 * np.abs(gn[21:27]).max() * 2 / float(h1))
+
+
+def test_oracle_reproduces_the_survey_figures_at_256(oracle, synth):
+    """The three counts SURVEY.md section 6 recorded from the reference's own kernel bodies on scene S1 frame 0 at 256^3:
+    voxels written by tsdfFusionKernal (exact), rays hit by rayCastKernel (within 2), ICP inliers of search_newton at
+    level 0 (within 0.3 %: the survey did not record the call's inputs, see the fixture's icp_note)."""
+    import json
+    from helpers import intr_of, s1_transforms, tranc_dist
+    fig = json.load(open(os.path.join(GOLDEN, "survey_reference_kernel_figures.json")))
+    n, H, W = 256, synth.HEIGHT, synth.WIDTH
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    T = s1_transforms(0, prm)
+    d0 = synth.s1_frame(0)
+    v, w, g = oracle.new_volume(res)
+    U = oracle.integrate(oracle.scale_depth(d0), v, w, g, res, tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm), prm["tsdf_voxel_size"])
+    pv, pn, hits = oracle.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], v, g, H, W)
+    cv = oracle.create_vmap(intr_of(prm), oracle.bilateral(d0))
+    cn = oracle.create_nmap(cv)
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    _, _, _, inl = oracle.icp_combined(T["Rc2w"], T["tc2w"], cv, cn, oracle.m3_inverse(T["Rc2w"]), T["tc2w"], intr_of(prm), pv, pn, 0.10, angle)
+    assert U == fig["integrate_U"]["256"]
+    assert abs(hits - fig["raycast_hits"]["256"]) <= 2
+    assert abs(inl - fig["icp_inliers_level0"]["256"]) <= 0.003 * fig["icp_inliers_level0"]["256"]

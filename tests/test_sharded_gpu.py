@@ -229,8 +229,9 @@ def test_sharded_checkpoint_roundtrip(dev, tmp_path):
 def test_cpp_host_runs_shard_mode_over_rccl_without_python():
     """x-slam_amd/smoke_rccl (host/smoke_rccl.cpp): a C++ program that creates an RCCL communicator through
     libxslam_rccl.so (include/xslam_amd_rccl.h), hands xs_rccl_collective to xs_kf_create_sharded and tracks four frames
-    of a synthetic room corner in shard mode with the ICP rows all-reduced — world = 1 here (one GPU), so the 44
-    collectives are single-rank ncclAllReduce calls on the orchestrator's stream."""
+    of a synthetic room corner in shard mode — world = 1 here (one GPU), so the raycast composite's collectives (two per
+    frame) are single-rank ncclAllReduce calls on the orchestrator's stream; with N ranks (`smoke_rccl <rank> <N> <id-file>`,
+    one process per GPU) the 12 per-frame ICP all-reduces join them."""
     import json
     import os
     import subprocess
@@ -241,4 +242,4 @@ def test_cpp_host_runs_shard_mode_over_rccl_without_python():
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["tracked"] == 1 and out["collective_calls"] == 44 and out["rccl_version"] > 0
+    assert out["tracked"] == 1 and out["collective_calls"] == 8 and out["rccl_version"] > 0
