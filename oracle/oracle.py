@@ -314,8 +314,17 @@ class Oracle:
         vols = [np.zeros(n, np.float32) for _ in range(3)] + [np.zeros(n, np.int32)] if want_volumes else [None] * 4
         out = np.zeros(4, np.float64)
         z1 = int(r[2]) if z1 is None else z1
+        gp = _p(gt, _f32p)
+        plane = int(r[0]) * int(r[1])
+        if gt.size == (z1 - z0) * plane and gt.size != plane * int(r[2]):
+            # gt holds the planes [z0, z1) only (as the C ABI takes a slab); the kernel indexes absolute planes and reads
+            # none outside [z0, z1): hand it the address plane 0 would have
+            assert not want_volumes
+            gp = C.cast(C.c_void_p(gt.ctypes.data - z0 * plane * 4), _f32p)
+        else:
+            assert gt.size == plane * int(r[2]), "gt must hold the whole volume or exactly the planes [z0, z1)"
         self._tsdf_hessian(_p(ds, _f32p), ds.shape[1] * 4, ds.shape[0], ds.shape[1], _p(r, _i32p), voxel_size, _p(R, _f32p),
-                           _p(t, _f32p), tranc_dist, _p(k, _f32p), _p(gt, _f32p), _p(vols[0], _f32p), _p(vols[1], _f32p),
+                           _p(t, _f32p), tranc_dist, _p(k, _f32p), gp, _p(vols[0], _f32p), _p(vols[1], _f32p),
                            _p(vols[2], _f32p), _p(vols[3], _i32p), z0, z1, _p(out, _f64p))
         return (out, vols) if want_volumes else out
 

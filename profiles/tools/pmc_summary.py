@@ -33,6 +33,17 @@ for scene, what in (("s2", "scene S2 512^3 (profiles/tools/probe_s2.py)"), ("s1"
         if os.path.isdir(d):
             a, cnt = counters(d, "k_integrate_bricks"); cs.update(a); n.update(cnt)
     e["counters"] = cs
+    # U (voxels written per launch) of the very runs the counters come from: the probes print it
+    import re
+    us = []
+    for sub in ("FETCH_SIZE", "WRITE_SIZE"):
+        try:
+            us += [int(m) for m in re.findall(r"['\"]U['\"]: (\d+)", open(os.path.join(out, scene + "_" + sub + ".log")).read())]
+        except OSError:
+            pass
+    e["U"] = us[0] if us and all(u == us[0] for u in us) else (us or None)
+    if isinstance(e["U"], int):
+        e["algorithmic_bytes_per_launch"] = 24 * e["U"] + 2 * 640 * 480
     e["launches_averaged"] = n
     if cs.get("FETCH_SIZE") and cs.get("WRITE_SIZE") and fac["FETCH_SIZE"]:
         e["traffic_read_bytes"] = cs["FETCH_SIZE"] * 1024.0 * fac["FETCH_SIZE"]

@@ -53,3 +53,12 @@ def test_hessian_loss_gradient_and_second_derivative(be, scene):
     assert abs(r["loss"] - r["loss_model"]) <= 2e-4 * abs(r["loss_model"])
     assert abs(r["grad"] - r["grad_model"]) <= 5e-4 * max(abs(r["grad_model"]), (r["loss_model"] * abs(r["hess_model"])) ** 0.5)
     assert abs(r["hess"] - r["hess_model"]) <= 5e-4 * abs(r["hess_model"])
+
+
+def test_hessian_on_a_slab_of_planes(be):
+    """The slab form (gt holds planes [z0, z1) only, as xs_compute_local_tsdf_hessian takes a z-shard) against the model."""
+    _, states = ic.two_frames(be, 64, "s3", (0, 3), 0.0)
+    r = ic.check_hessian(be, n=64, scene="s3", z0=20, z1=40, gt=states[1][0])
+    assert r["count"] > 50 and r["count"] == r["count_model"]
+    assert abs(r["loss"] - r["loss_model"]) <= 5e-4 * abs(r["loss_model"])
+    assert abs(r["hess"] - r["hess_model"]) <= 5e-4 * abs(r["hess_model"])
