@@ -191,6 +191,23 @@ int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vm
                       const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                       const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
                       void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq, void *stream);
+/* estimateCombined with the final addition left to the host (same reference interface, ICP.h:24-31; it replaces TranformReduction,
+ * ICP.cu:120-164, by a loop on the CPU that is waiting for the result anyway).  Every workgroup stores its record — 56 doubles: the 54
+ * partial sums, the inlier count, a sequence word — straight into records_host (host-coherent pinned memory, xs_icp_records_bytes()
+ * bytes, zero before first use) and leaves; the sequence word is written last, system-scope release.  No workspace, no ticket, no
+ * completion word.  Pose: Rcurr18 / tcurr6, or both NULL with a mailbox and its sequence number (xs_icp_accumulate_posted's
+ * protocol).  seq: non-zero, below 2^63, different from the previous launch's on the same buffer.
+ * xs_icp_records_count: records a launch over pixel rows [y0, y1) of a cols-wide level writes.
+ * xs_icp_sum_records (host only): waits for record 0 .. count - 1 in turn and adds them in that order (deterministic); sums55 = 54
+ * sums + inlier count.  Returns 0; 1 if the launch reports that it gave up waiting for a posted pose; -1 after max_spins polls of one
+ * record (max_spins <= 0: wait for ever). */
+size_t xs_icp_records_bytes(void);
+int xs_icp_records_count(int cols, int y0, int y1);
+int xs_icp_accumulate_records(const float *Rcurr18, const float *tcurr6, const void *mailbox, unsigned mailbox_seq, const float *vmap_curr,
+                              const float *nmap_curr, const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
+                              const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
+                              double *records_host, unsigned long long seq, void *stream);
+int xs_icp_sum_records(const double *records_host, int count, unsigned long long seq, double *sums55, long long max_spins);
 /* estimateCombined with the pose posted AFTER the launch (same reference interface as above; it
  * replaces the launch latency between two iterations of KinectFusionReconstruction.cpp:187-225).
  * The call is made while the previous iteration is still running; the launch becomes resident behind

@@ -443,6 +443,73 @@ def test_icp_posted_pose_mailbox(dev, oracle, where):
         free()
 
 
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_icp_records_folded_on_the_host(dev, oracle, level):
+    """xs_icp_accumulate_records + xs_icp_sum_records (every workgroup's record written straight to pinned host memory, the
+    host adds them in index order) against xs_icp_accumulate (last workgroup adds them on the device): the same records,
+    so the same inlier count and sums equal up to the association of the double additions; twice the same bits; a posted
+    launch (pose through the mailbox) gives the same bits as one given its pose; a record count per level of 90 / 300 / 512."""
+    import ctypes as C
+    torch, capi = dev
+    prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
+    for _ in range(level):
+        pv, pn = oracle.resize_map(pv, False), oracle.resize_map(pn, True)
+    d = oracle.bilateral(synth.s1_frame(1))
+    for _ in range(level):
+        d = oracle.pyr_down(d)
+    k = intr_of(prm, level)
+    cv = oracle.create_vmap(k, d)
+    cn = oracle.create_nmap(cv)
+    rows, cols = cv.shape[0] // 3, cv.shape[1]
+    Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    dv = [to_dev(torch, x) for x in (cv, cn, pv, pn)]
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    ref = torch.zeros(55, dtype=torch.float64, device="cuda")
+    capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle, ws, ref)
+    torch.cuda.synchronize()
+    ref = ref.cpu().numpy()
+    count = capi.icp_records_count(cols, 0, rows)
+    assert count == {0: 512, 1: 300, 2: 90}[level] and capi.icp_records_bytes() == 512 * 56 * 8
+    rec, free = _coherent_host_bytes(capi.icp_records_bytes())
+    mailbox, in_dev = capi.icp_mailbox_alloc()
+    try:
+        got = []
+        for seq in (3, 4):
+            capi.icp_accumulate_records(T0["Rc2w"], T0["tc2w"], dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle,
+                                        rec, seq)
+            rc, sums = capi.icp_sum_records(rec, count, seq)          # waits on the records themselves: no synchronise
+            assert rc == 0
+            got.append(sums)
+        assert np.array_equal(got[0], got[1])
+        assert got[0][54] == ref[54] > 1000
+        assert np.allclose(got[0], ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        # an older sequence number is not mistaken for the new launch's: nothing was launched with 9, so the wait runs out
+        rc, _ = capi.icp_sum_records(rec, count, 9, max_spins=1000)
+        assert rc == -1
+        # posted pose
+        capi.icp_accumulate_records(None, None, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle, rec, 11,
+                                    mailbox=mailbox, mailbox_seq=77)
+        capi.icp_post_pose(mailbox, T0["Rc2w"], T0["tc2w"], 77)
+        rc, sums = capi.icp_sum_records(rec, count, 11)
+        assert rc == 0 and np.array_equal(sums, got[0])
+        # a sharded row range
+        y0, y1 = rows // 4, rows // 2
+        capi.icp_accumulate_records(T0["Rc2w"], T0["tc2w"], dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle,
+                                    rec, 12, y0=y0, y1=y1)
+        rc, part = capi.icp_sum_records(rec, capi.icp_records_count(cols, y0, y1), 12)
+        want = torch.zeros(55, dtype=torch.float64, device="cuda")
+        capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle, ws, want,
+                            y0=y0, y1=y1)
+        torch.cuda.synchronize()
+        want = want.cpu().numpy()
+        assert rc == 0 and part[54] == want[54] and np.allclose(part, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    finally:
+        torch.cuda.synchronize()
+        free()
+        capi.icp_mailbox_free(mailbox, in_dev)
+
+
 def test_icp_posted_pose_gives_up(dev):
     """A launch whose pose is never posted must not hold the GPU: it leaves after about a second,
     writes nothing, and reports done_seq | 1<<63 through the completion word."""

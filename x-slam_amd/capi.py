@@ -82,6 +82,11 @@ _SIGS = {
     "xs_icp_accumulate_posted": (C.c_int, [_vp, C.c_uint, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                            C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_icp_post_pose": (None, [_vp, _f32p, _f32p, C.c_uint, C.c_int]),
+    "xs_icp_records_bytes": (_sz, []),
+    "xs_icp_records_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "xs_icp_accumulate_records": (C.c_int, [_f32p, _f32p, _vp, C.c_uint, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
+                                            C.c_float, C.c_int, C.c_int, _vp, C.c_ulonglong, _vp]),
+    "xs_icp_sum_records": (C.c_int, [_vp, C.c_int, C.c_ulonglong, _f64p, C.c_longlong]),
     "xs_icp_iterate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                  C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_estimate_combined": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -358,6 +363,33 @@ def icp_post_pose(mailbox, Rcurr, tcurr, mailbox_seq, cmd=0):
     else:
         a, b = _fa(Rcurr, 18), _fa(tcurr, 6)
         _lib.xs_icp_post_pose(_ptr(mailbox), P(a), P(b), mailbox_seq, cmd)
+
+
+def icp_records_bytes():
+    return int(_lib.xs_icp_records_bytes())
+
+
+def icp_records_count(cols, y0, y1):
+    return int(_lib.xs_icp_records_count(cols, y0, y1))
+
+
+def icp_accumulate_records(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols, distThres,
+                           angleThres, records, seq, y0=0, y1=None, mailbox=None, mailbox_seq=0, stream=None):
+    """estimateCombined with the final addition on the host: enqueue the launch; every workgroup writes its record into `records`
+    (a pinned host tensor of icp_records_bytes() bytes).  Rcurr / tcurr None: the pose is posted through `mailbox`."""
+    c, d, k = _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    a, b = (None, None) if Rcurr is None else (P(_fa(Rcurr, 18)), P(_fa(tcurr, 6)))
+    check(_lib.xs_icp_accumulate_records(a, b, _ptr(mailbox), mailbox_seq, _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev),
+                                         _ptr(nmap_g_prev), map_step, rows, cols, distThres, angleThres, y0, rows if y1 is None else y1,
+                                         _ptr(records), seq, _stream(stream)))
+
+
+def icp_sum_records(records, count, seq, max_spins=2000000000):
+    """Host: wait for the `count` records of launch `seq` and add them in index order.  (status, sums[55])."""
+    out = np.zeros(55, np.float64)
+    rc = _lib.xs_icp_sum_records(_ptr(records), count, seq, out.ctypes.data_as(_f64p), max_spins)
+    return rc, out
 
 
 def icp_mailbox_bytes():

@@ -38,6 +38,9 @@ struct IcpArgs {
     // optional posted pose (xs_icp_accumulate_posted): the launch was enqueued before its pose was known and
     // picks it up from a 128-byte mailbox in host-coherent pinned memory once the host has posted mailbox_seq
     const unsigned *mailbox; unsigned mailbox_seq;
+    // optional host fold (xs_icp_accumulate_records): every workgroup stores its record straight into host-coherent
+    // pinned memory, sequence number last, and leaves; the host adds the records (xs_icp_sum_records)
+    double *host_records; unsigned long long record_seq;
 };
 
 namespace {
@@ -156,6 +159,9 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
         if (cmd != 0) {
             if (cmd == 2 && threadIdx.x == 0 && a.done_flag)
                 __hip_atomic_store(a.done_flag, a.done_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (cmd == 2 && threadIdx.x == 0 && a.host_records)   // host fold: the give-up shows in the record's sequence word
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_records) + (size_t)blockIdx.x * NP + (NP - 1),
+                                   a.record_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
         auto word = [&](int i) { return uni(__uint_as_float(s_mail[i < 14 ? 2 + i : 18 + (i - 14)])); };
@@ -224,6 +230,29 @@ __global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
         }
     }
     __syncthreads();
+    if (a.host_records) {
+        // Host fold: the record goes straight to host-coherent pinned memory (28 16-byte stores of wave 0), then — once
+        // those stores are acknowledged and released at system scope — its last word receives the launch's sequence
+        // number, and the workgroup is done: no ticket, no write-back of this XCD's L2 for another workgroup to read,
+        // no last workgroup gathering 512 records from memory.  The host spins on the sequence words and adds the
+        // records in index order (xs_icp_sum_records): the same deterministic association for every launch.
+        if (threadIdx.x < 64) {
+            struct alignas(16) d2 { double x, y; };
+            if (threadIdx.x < NP / 2) {
+                const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
+                d2 v;
+                v.x = ((smem[0][k0] + smem[1][k0]) + smem[2][k0]) + smem[3][k0];
+                v.y = k1 <= NS ? ((smem[0][k1] + smem[1][k1]) + smem[2][k1]) + smem[3][k1] : 0.0;
+                if (k1 <= NS) reinterpret_cast<d2 *>(a.host_records)[(size_t)blockIdx.x * (NP / 2) + threadIdx.x] = v;
+                else a.host_records[(size_t)blockIdx.x * NP + k0] = v.x;      // the count; the pad word is the sequence slot
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_records) + (size_t)blockIdx.x * NP + (NP - 1), a.record_seq,
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (threadIdx.x < NP / 2) {
         // one 16-byte store per lane (a record is 28 of them; the pad entry is written as zero).  Plain
         // stores: the agent-scope release below carries them out of this XCD's L2.
@@ -412,14 +441,23 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
     return 0;
 }
 
+// workgroups (= records) of a launch over pixel rows [y0, y1): one 64-pixel tile per wave while the image is small
+static int icp_blocks(int cols, int y0, int y1) {
+    const int tiles = div_up(cols, 64) * (y1 - y0);
+    int blocks = div_up(tiles, 4);
+    if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
+    return blocks < 1 ? 1 : blocks;
+}
+
 // shared launcher of xs_icp_accumulate / xs_icp_iterate
 static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr, const float *Rprev_inv18,
                       const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev, size_t map_step, int rows,
                       int cols, float distThres, float angleThres, int y0, int y1, void *workspace, double *sums_dev,
                       unsigned long long *done_flag, unsigned long long done_seq, IcpPoseState *pose, IcpPoseState *pose_host, double *sums_host,
-                      void *stream, const char *who, const void *mailbox = nullptr, unsigned mailbox_seq = 0) {
+                      void *stream, const char *who, const void *mailbox = nullptr, unsigned mailbox_seq = 0, double *host_records = nullptr,
+                      unsigned long long record_seq = 0) {
     if ((!pose && !mailbox && (!Rcurr18 || !tcurr6)) || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
-        !workspace || !sums_dev)
+        (!host_records && (!workspace || !sums_dev)))
         return xs_set_error(hipErrorInvalidValue, who);
     if (y0 < 0 || y1 > rows || y1 < y0) return xs_set_error(hipErrorInvalidValue, "xs_icp: bad row range");
     IcpArgs a;
@@ -431,14 +469,12 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
     a.mstep = map_step; a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.distThres = distThres; a.angleThres = angleThres; a.cols = cols; a.rows = rows; a.y0 = y0; a.y1 = y1;
     a.ticket = (unsigned *)workspace;
-    a.partials = (double *)((char *)workspace + 256);
+    a.partials = workspace ? (double *)((char *)workspace + 256) : nullptr;
+    a.host_records = host_records; a.record_seq = record_seq;
     a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
     a.pose = pose; a.pose_host = pose_host; a.load_pose = (pose && Rcurr18) ? 1 : 0;
     a.mailbox = nullptr; a.mailbox_seq = 0;
-    const int tiles = div_up(cols, 64) * (y1 - y0);
-    int blocks = div_up(tiles, 4);  // one tile per wave when the image is small
-    if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
-    if (blocks < 1) blocks = 1;
+    const int blocks = icp_blocks(cols, y0, y1);
     // the ticket word must be zero on first use (xs_icp_workspace_init); every launch leaves it zero
     if (pose) {
         // the reduction, then the pose update it feeds; the completion word belongs to the second kernel
@@ -489,6 +525,51 @@ extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, cons
  * the loop: singular system).  A launch whose pose never arrives gives up after about a second and
  * stores done_seq | 1<<63 to done_flag; re-initialise the workspace (xs_icp_workspace_init) after that.
  * Everything else as xs_icp_accumulate. */
+/* estimateCombined with the final addition on the host.  Same kernel and the same per-workgroup records as xs_icp_accumulate, but
+ * every workgroup stores its record (56 doubles: 54 sums, inlier count, sequence word) straight into `records_host` — host-coherent
+ * pinned memory of xs_icp_records_bytes() bytes — and leaves; the sequence word is written last (system-scope release).  Nothing is
+ * gathered on the device: the launch has no ticket, no second pass over the records and no completion word.  The host adds the records
+ * with xs_icp_sum_records, which waits for each record's sequence word in index order.  Pose: Rcurr18 / tcurr6, or both NULL with a
+ * mailbox (as xs_icp_accumulate_posted).  seq: non-zero, different from the previous launch's on the same buffer. */
+extern "C" size_t xs_icp_records_bytes(void) { return (size_t)XS_ICP_MAX_BLOCKS * NP * sizeof(double); }
+extern "C" int xs_icp_records_count(int cols, int y0, int y1) { return icp_blocks(cols, y0, y1); }
+extern "C" int xs_icp_accumulate_records(const float *Rcurr18, const float *tcurr6, const void *mailbox, unsigned mailbox_seq, const float *vmap_curr,
+                                         const float *nmap_curr, const float *Rprev_inv18, const float *tprev6, const float *intr4,
+                                         const float *vmap_g_prev, const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres,
+                                         float angleThres, int y0, int y1, double *records_host, unsigned long long seq, void *stream) {
+    if (!records_host || seq == 0 || (seq >> 63)) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_records: bad records / seq");
+    if ((Rcurr18 == nullptr) != (tcurr6 == nullptr) || (!Rcurr18 && !mailbox))
+        return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_records: give a pose or a mailbox");
+    return icp_launch(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols, distThres,
+                      angleThres, y0, y1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream, "xs_icp_accumulate_records: null pointer",
+                      Rcurr18 ? nullptr : mailbox, mailbox_seq, records_host, seq);
+}
+/* Host half: waits (spinning) until record i carries `seq`, adds it, for i = 0 .. count - 1 — one fixed order, so the 55 results are
+ * the same bits for the same records whatever order the workgroups finished in.  sums55: 54 sums + inlier count.  Returns 0; 1 if a
+ * record reports that its launch gave up waiting for a posted pose; -1 after max_spins polls of one record (<= 0: no limit). */
+extern "C" int xs_icp_sum_records(const double *records_host, int count, unsigned long long seq, double *sums55, long long max_spins) {
+    if (!records_host || !sums55 || count < 1) return -1;
+    double acc[NP];
+    for (int k = 0; k < NP; ++k) acc[k] = 0.0;
+    for (int i = 0; i < count; ++i) {
+        const double *rec = records_host + (size_t)i * NP;
+        const volatile unsigned long long *flag = reinterpret_cast<const volatile unsigned long long *>(rec + (NP - 1));
+        long long spins = 0;
+        unsigned long long seen;
+        while ((seen = *flag) != seq) {
+            if (seen == (seq | kIcpTimeoutBit)) return 1;
+            if (max_spins > 0 && ++spins > max_spins) return -1;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int k = 0; k < NP - 1; ++k) acc[k] += rec[k];
+    }
+    for (int k = 0; k < NP - 1; ++k) sums55[k] = acc[k];
+    return 0;
+}
+
 extern "C" size_t xs_icp_mailbox_bytes(void) { return MAILBOX_WORDS * sizeof(unsigned); }
 extern "C" int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_seq, const float *vmap_curr, const float *nmap_curr,
                                         const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,

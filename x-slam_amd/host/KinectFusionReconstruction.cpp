@@ -22,6 +22,8 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, COUNTER_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, PINNED_DOUBLES * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < PINNED_DOUBLES; ++i) pinned_sums_[i] = 0.0;
+    hipSafeCall(hipHostMalloc((void **)&pinned_records_, xs_icp_records_bytes(), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(pinned_records_, 0, xs_icp_records_bytes());
 }
 
 void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn fn, void *user) {
@@ -35,6 +37,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (scale_done_) (void)hipEventDestroy(scale_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
+    if (pinned_records_) (void)hipHostFree(pinned_records_);
     if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
     for (int i = 0; i < 2; ++i) {
         if (ingest_pinned_[i]) { (void)hipEventSynchronize(ingest_done_[i]); (void)hipHostFree(ingest_pinned_[i]); (void)hipEventDestroy(ingest_done_[i]); }
@@ -107,6 +110,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
     icp_shard_rows = config.as<bool>("icp_shard_rows", false);
     icp_post_pose = config.as<bool>("icp_post_pose", true);
+    icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
@@ -290,6 +294,13 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
         const int rows = vc.rows() / 3, cols = vc.cols();
         unsigned long long *flag = reinterpret_cast<unsigned long long *>(pinned_sums_ + 56);
         const unsigned long long seq = ++icp_seq_;
+        if (icp_host_fold) {
+            check_rc(xs_icp_accumulate_records(R ? &R->data[0].x.re : nullptr, R ? &t->x.re : nullptr, R ? nullptr : mailbox, mail_seq, &vc.ptr()->re,
+                                               &nc.ptr()->re, &device_Rprev_inv.data[0].x.re, &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re,
+                                               vc.step(), rows, cols, distThres, angleThres, 0, rows, pinned_records_, seq, current_stream()),
+                     "estimateCombined (records)");
+            return seq;
+        }
         if (R)
             check_rc(xs_icp_accumulate(&R->data[0].x.re, &t->x.re, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
                                        &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres,
@@ -321,22 +332,30 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                     next_enqueued = true;
                 }
                 volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
-                long spins = 0;
-                unsigned long long seen;
-                while ((seen = *flag) != seq) {
-                    if (seen == (seq | (1ull << 63)) || ++spins > 2000000000L) {  // never expected: the launch gave up on its pose
-                        if (next_enqueued) xs_icp_post_pose(mailbox, nullptr, nullptr, next_mail_seq, 1);
-                        hipSafeCall(hipStreamSynchronize(current_stream()));
-                        check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
-                        stage_end(ST_ICP);
-                        std::cout << "error::KinectFusionReconstruction, ICP launch timed out waiting for its pose" << std::endl;
-                        return 0;
-                    }
+                auto launch_gave_up = [&]() {   // never expected: the launch gave up on its pose
+                    if (next_enqueued) xs_icp_post_pose(mailbox, nullptr, nullptr, next_mail_seq, 1);
+                    hipSafeCall(hipStreamSynchronize(current_stream()));
+                    check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
+                    stage_end(ST_ICP);
+                    std::cout << "error::KinectFusionReconstruction, ICP launch timed out waiting for its pose" << std::endl;
+                    return 0;
+                };
+                if (icp_host_fold) {
+                    // the workgroups' records arrive in pinned memory; add them here, in index order
+                    const int level_cols = vmaps_curr_d[level_index].cols(), level_rows = vmaps_curr_d[level_index].rows() / 3;
+                    if (xs_icp_sum_records(pinned_records_, xs_icp_records_count(level_cols, 0, level_rows), seq, pinned_sums_, 2000000000LL) != 0)
+                        return launch_gave_up();
+                } else {
+                    long spins = 0;
+                    unsigned long long seen;
+                    while ((seen = *flag) != seq) {
+                        if (seen == (seq | (1ull << 63)) || ++spins > 2000000000L) return launch_gave_up();
 #if defined(__x86_64__)
-                    __builtin_ia32_pause();
+                        __builtin_ia32_pause();
 #endif
+                    }
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 }
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 xs_icp_unpack(pinned_sums_, reinterpret_cast<double *>(A), reinterpret_cast<double *>(b));
                 inliers = (long long)pinned_sums_[54];
             } else
@@ -464,18 +483,28 @@ void KinectFusionReconstruction::icp_normal_equations(const MatS33 &Rcurr, const
         // publishes a sequence number; the host spins on it (no copy kernel, no stream synchronise)
         volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
         const unsigned long long seq = ++icp_seq_;
-        check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re,
-                                   &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,
-                                   icp_ws_.ptr(), pinned_sums_, reinterpret_cast<unsigned long long *>(pinned_sums_ + 56), seq, st),
-                 "estimateCombined");
-        long spins = 0;
-        while (*flag != seq) {
-            if (++spins > 2000000000L) { hipSafeCall(hipStreamSynchronize(st)); break; }  // never expected: fall back to a real wait
+        if (icp_host_fold) {
+            check_rc(xs_icp_accumulate_records(&Rcurr.data[0].x.re, &tcurr.x.re, nullptr, 0, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re,
+                                               &tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,
+                                               pinned_records_, seq, st), "estimateCombined (records)");
+            if (xs_icp_sum_records(pinned_records_, xs_icp_records_count(cols, y0, y1), seq, pinned_sums_, 2000000000LL) != 0) {
+                printf("HIP error(estimateCombined): the ICP records never arrived\n");
+                exit(-1);
+            }
+        } else {
+            check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re,
+                                       &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,
+                                       icp_ws_.ptr(), pinned_sums_, reinterpret_cast<unsigned long long *>(pinned_sums_ + 56), seq, st),
+                     "estimateCombined");
+            long spins = 0;
+            while (*flag != seq) {
+                if (++spins > 2000000000L) { hipSafeCall(hipStreamSynchronize(st)); break; }  // never expected: fall back to a real wait
 #if defined(__x86_64__)
-            __builtin_ia32_pause();
+                __builtin_ia32_pause();
 #endif
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {
         check_rc(xs_icp_accumulate(&Rcurr.data[0].x.re, &tcurr.x.re, &vc.ptr()->re, &nc.ptr()->re, &Rprev_inv.data[0].x.re, &tprev.x.re,
                                    &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, y0, y1,

@@ -85,6 +85,14 @@ public:
     // order).  Applies when this rank evaluates whole images (not with icp_shard_rows).  YAML key
     // icp_post_pose.
     bool icp_post_pose = true;
+    // The final addition of an ICP reduction on the host (xs_icp_accumulate_records / xs_icp_sum_records): every
+    // workgroup writes its record of 55 partial sums straight into pinned host memory and leaves; the host — which is
+    // spinning for the result anyway — adds the records in index order.  Takes the cross-XCD gather (write-back, ticket,
+    // last workgroup reading every record from memory) out of the launch.  Measured no faster than the device gather
+    // (profiles/r02_ab_icp_fold.txt: 2 270-2 540 against 2 530-2 550 frames/s — 90-512 workgroups each pushing 448 bytes
+    // and a system-scope release over PCIe cost what the agent-scope publish + final sum cost), so it is off by default.
+    // YAML key icp_host_fold.
+    bool icp_host_fold = false;
     // Sharded runs (SetSharding): false (default) — every rank evaluates the whole ICP itself; all ranks hold
     // the same current-frame maps and the composited previous-frame maps, the reduction is deterministic,
     // so they reach the same pose bit for bit with no collective inside the ICP loop.  true — pixel rows
@@ -186,6 +194,7 @@ private:
     // device-side loop, [128 + 64*n ..) the 55 values of its iteration n
     enum { ICP_LOG_MAX = 62, PINNED_DOUBLES = 128 + 64 * ICP_LOG_MAX };
     double *pinned_sums_ = nullptr;
+    double *pinned_records_ = nullptr;   // xs_icp_records_bytes() of host-coherent pinned memory (icp_host_fold)
     void *icp_mailbox_ = nullptr;              // pose mailbox of the posted ICP launches (xs_icp_mailbox_alloc)
     int icp_mailbox_in_device_ = 0;
     unsigned long long icp_seq_ = 0;
