@@ -587,8 +587,7 @@ struct HessArgs {
     unsigned *ticket;
     double *out;          // hessian: {loss, grad, hessian, count}; loss: {loss, count}
     float *real_out, *grad_out, *hess_out; int *count_out;  // optional per-voxel volumes (same indexing as gt)
-    int vec;              // columns per lane (host side: picks the kernel instance)
-    int tiles_x, tiles_y, tiles_z;  // (64*vec x 4 x zchunk) tiles; workgroups stride over them
+    int tiles_x, tiles_y, tiles_z;  // (64 x 4 x zchunk) tiles; workgroups stride over them
 };
 struct HessPoseD { MatD33 R; dcfloat3 t; };
 struct HessPoseF { float R[9]; float t[3]; };
@@ -655,146 +654,170 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
 
 // The dense ground-truth read is the kernels' only N^3 traffic, and a plain z loop keeps one 4-byte load
 // per lane in flight (measured: 0.85 TB/s for the Hessian kernel at 512^3).  Here a lane requests thirty-two
-// planes at once, keeps a bit per plane whose voxel is in the band (gt != 0, |gt| <= 0.95: a few per
-// column), and then visits its band voxels one after the other — the k-th band voxel of every lane of the
-// wave together, whatever their z, so the expensive body runs with full lanes instead of once per plane any
-// lane needs.  Each lane still meets its voxels in ascending z: the per-lane double sums are unchanged.
-// (Scanning the slab as one flat array — contiguous 8 KB per wave — streamed only 6 % faster and made the
-// Hessian kernel 1.7x slower: the band is a sheet, so whole waves land inside it with 32 band voxels per lane
-// while most have none; in the column walk every lane crosses the sheet once.)
-template <int VEC, class F>
-__device__ __forceinline__ void for_band_voxels(const HessArgs &a, int x, int y, int zb, int ze, F &&body) {
-    // VEC = 4: the lane owns four consecutive x and reads them as one 16-byte load (a wave-instruction moves
-    // 1 KiB instead of 256 B: the one-dword form streams at 2.3 TB/s); VEC = 1 for volumes whose X is not a
-    // multiple of four or whose base is not 16-byte aligned.
+// planes of its column at once and keeps a bit per plane whose voxel is in the band (gt != 0, |gt| <= 0.95).
+// The band is a sheet: where it lies across the columns every lane holds a handful of band voxels, but where it
+// runs ALONG them (a wall parallel to the z axis) six lanes of a wave hold thirty-two each and the other
+// fifty-eight none — a wave that let every lane work through its own voxels ran the dual-complex body at a tenth
+// of its lanes (the relocalisation pass of a box room at 1024^3: 4.7 ms against 1.4 ms for a wall across z).  So
+// the voxels are dealt out again: plane by plane, the lanes that hold a band voxel append its coordinates to a
+// per-wave queue in LDS (one ballot + one prefix count per plane), and whenever sixty-four are waiting every lane
+// takes one — full lanes whatever the sheet's orientation; the queue runs on across chunks and tiles and is
+// drained once at the end.  The order in which a lane's double sums meet their terms differs from the reference's
+// thrust::reduce (unspecified there) by association only.
+// (Scanning the slab as one flat array — contiguous 8 KB per wave — streamed only 6 % faster; four columns per
+// lane with 16-byte loads no faster either.)
+struct BandQueue {
+    enum { CAP = 128 };                 // entries per wave: at most 63 left over + 64 appended
+    unsigned long long (*q)[CAP];       // [wave][CAP] in LDS: x | y << 21 | z << 42
+    unsigned head, tail;
+};
+template <class F>
+__device__ __forceinline__ void band_queue_take(const HessArgs &a, BandQueue &Q, int wave, int lane, unsigned count, F &&body) {
+    // lanes 0 .. count - 1 take the entries head .. head + count - 1 (the appends are this wave's own: LDS operations of
+    // a wave complete in order, and the compiler may not move memory accesses across the asm)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((unsigned)lane < count) {
+        const unsigned long long e = Q.q[wave][(Q.head + lane) % BandQueue::CAP];
+        const int x = (int)(e & 0x1fffff), y = (int)((e >> 21) & 0x1fffff), z = (int)(e >> 42);
+        const size_t index = ((size_t)(z - a.z0) * a.Y + y) * a.X + x;
+        body(x, y, z, index, a.gt[index]);   // (re-read: a cache hit, instead of thirty-two live registers)
+    }
+    Q.head += count;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before a later append may reuse the slots
+}
+template <class F>
+__device__ __forceinline__ void for_band_voxels(const HessArgs &a, BandQueue &Q, int wave, int lane, int x, int y, bool in_volume, int zb, int ze,
+                                                F &&body) {
     constexpr int ZB = 32;
     const size_t plane = (size_t)a.Y * a.X;
-    const size_t first = (size_t)(zb - a.z0) * plane + (size_t)y * a.X + x;
+    const size_t first = in_volume ? (size_t)(zb - a.z0) * plane + (size_t)y * a.X + x : 0;
     for (int zc = zb; zc < ze; zc += ZB) {
         const float *col = a.gt + first + (size_t)(zc - zb) * plane;
-        unsigned long long mask = 0;
+        unsigned mask = 0;
+        if (in_volume) {
 #pragma unroll
-        for (int j = 0; j < ZB; ++j) {
-            float g[VEC];
-            if (VEC == 4) {
-                const float4 v = (zc + j < ze) ? *reinterpret_cast<const float4 *>(col + (size_t)j * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
-                g[0] = v.x; g[1 % VEC] = v.y; g[2 % VEC] = v.z; g[3 % VEC] = v.w;
-            } else
-                g[0] = (zc + j < ze) ? col[(size_t)j * plane] : 0.f;
-#pragma unroll
-            for (int q = 0; q < VEC; ++q)
-                if (!(g[q] == 0 || fabsf(g[q]) > 0.95)) mask |= 1ull << (j * VEC + q);
+            for (int j = 0; j < ZB; ++j) {
+                const float g = (zc + j < ze) ? col[(size_t)j * plane] : 0.f;
+                if (!(g == 0 || fabsf(g) > 0.95)) mask |= 1u << j;
+            }
         }
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int j = b / VEC, q = b % VEC;
-            const size_t index = first + (size_t)(zc - zb + j) * plane + q;
-            body(x + q, zc + j, index, a.gt[index]);  // (re-read: a cache hit, instead of 16 x VEC live registers)
+        if (!__ballot(mask != 0)) continue;                       // free space: the usual case
+        for (int j = 0; j < ZB; ++j) {
+            const bool mine = (mask >> j) & 1u;
+            const unsigned long long who = __ballot(mine);
+            if (!who) continue;
+            if (mine) {
+                const unsigned pos = Q.tail + __popcll(who & ((1ull << lane) - 1ull));
+                Q.q[wave][pos % BandQueue::CAP] = (unsigned long long)x | ((unsigned long long)y << 21) | ((unsigned long long)(zc + j) << 42);
+            }
+            Q.tail += (unsigned)__popcll(who);
+            if (Q.tail - Q.head >= 64u) band_queue_take(a, Q, wave, lane, 64u, body);
         }
     }
 }
-
-template <int VEC>
-__global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const HessPoseD P) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    // a bounded number of workgroups (each pays an L2 write-back and a ticket when it retires) stride over the tiles
+// the tile walk the three kernels share: a bounded number of workgroups (each pays an L2 write-back and a ticket
+// when it retires) stride over the (64 x 4 x zchunk) tiles, one column per lane, one row of columns per wave
+template <class F>
+__device__ __forceinline__ void walk_band(const HessArgs &a, F &&body) {
+    __shared__ unsigned long long s_queue[4][BandQueue::CAP];
+    BandQueue Q{s_queue, 0u, 0u};
+    const int lane = threadIdx.x, wave = threadIdx.y;            // blockDim = (64, 4)
     const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int x = (threadIdx.x + (tile % a.tiles_x) * 64) * VEC;
-    const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
-    if (x < a.X && y < a.Y) {
+        const int x = threadIdx.x + (tile % a.tiles_x) * 64;
+        const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
         const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        const dcfloat vgy((float(y) + 0.5f) * a.voxel_size);
-        for_band_voxels<VEC>(a, x, y, zb, ze, [&](int xq, int z, size_t index, float gt) {
-            const dcfloat gt_tsdf(gt);
-            const dcfloat vgx((float(xq) + 0.5f) * a.voxel_size);
-            const dcfloat vgz((float(z) + 0.5f) * a.voxel_size);
-            dcfloat3 v_g; v_g.x = vgx; v_g.y = vgy; v_g.z = vgz;
-            dcfloat3 v_c;
-            v_c.x = dot(P.R.data[0], v_g) + P.t.x;
-            v_c.y = dot(P.R.data[1], v_g) + P.t.y;
-            v_c.z = dot(P.R.data[2], v_g) + P.t.z;
-            const dcfloat inv_z = dcfloat(1.0f) / v_c.z;
-            if (inv_z.value() < 0) return;
-            const dcfloat image_x = v_c.x * inv_z * a.intr.fx + a.intr.cx;
-            const dcfloat image_y = v_c.y * inv_z * a.intr.fy + a.intr.cy;
-            const int coo_x = __float2int_rd(image_x.value() - 0.5f), coo_y = __float2int_rd(image_y.value() - 0.5f);
-            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return;
-            const int near_x = __float2int_rn(image_x.value()), near_y = __float2int_rn(image_y.value());
-            dcfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x]);
-            const dcfloat d00(row_ptr(a.depth, a.dstep, coo_y)[coo_x]), d10(row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1]);
-            const dcfloat d01(row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x]), d11(row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1]);
-            if (d00.value() != 0.0f && d01.value() != 0.0f && d10.value() != 0.0f && d11.value() != 0.0f) {  // :248-251, threshold unused
-                const dcfloat one(1.0f);
-                const dcfloat fa = image_x - dcfloat(float(coo_x) + 0.5f);
-                const dcfloat fb = image_y - dcfloat(float(coo_y) + 0.5f);
-                Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
-            }
-            if (Dp.value() > 5 || Dp.value() < 0.2) return;
-            const dcfloat xl = (image_x - a.intr.cx) / a.intr.fx;
-            const dcfloat yl = (image_y - a.intr.cy) / a.intr.fy;
-            dcfloat3 v_c_1; v_c_1.x = Dp * xl; v_c_1.y = Dp * yl; v_c_1.z = Dp;
-            const dcfloat distance = norm(v_c_1) - norm(v_c);
-            const dcfloat gt_distance = gt_tsdf * a.tranc_dist;
-            const dcfloat error = (distance - gt_distance) * a.tranc_dist_inv;
-            if (fabsf(error.value()) > 1) return;
-            const dcfloat loss = error * error;
-            if (a.real_out) {
-                a.real_out[index] = loss.value(); a.grad_out[index] = loss.grad();
-                a.hess_out[index] = loss.hessian(); a.count_out[index] = 1;
-            }
-            acc[0] += loss.value(); acc[1] += loss.grad(); acc[2] += loss.hessian(); acc[3] += 1.0;
-        });
+        for_band_voxels(a, Q, wave, lane, x, y, x < a.X && y < a.Y, zb, ze, body);
     }
+    band_queue_take(a, Q, wave, lane, Q.tail - Q.head, body);   // what is left: fewer than sixty-four
+}
+
+__global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const HessPoseD Pk) {
+    __shared__ HessPoseD P;   // 48 floats of pose through LDS rather than through vector registers (see k_tsdf_gauss_newton)
+    {
+        const float *src = reinterpret_cast<const float *>(&Pk);
+        float *dst = reinterpret_cast<float *>(&P);
+        for (int i = threadIdx.y * 64 + threadIdx.x; i < (int)(sizeof(HessPoseD) / sizeof(float)); i += 256) dst[i] = src[i];
     }
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    walk_band(a, [&](int xq, int yq, int z, size_t index, float gt) {
+        const dcfloat gt_tsdf(gt);
+        const dcfloat vgx((float(xq) + 0.5f) * a.voxel_size);
+        const dcfloat vgy((float(yq) + 0.5f) * a.voxel_size);
+        const dcfloat vgz((float(z) + 0.5f) * a.voxel_size);
+        dcfloat3 v_g; v_g.x = vgx; v_g.y = vgy; v_g.z = vgz;
+        dcfloat3 v_c;
+        v_c.x = dot(P.R.data[0], v_g) + P.t.x;
+        v_c.y = dot(P.R.data[1], v_g) + P.t.y;
+        v_c.z = dot(P.R.data[2], v_g) + P.t.z;
+        const dcfloat inv_z = dcfloat(1.0f) / v_c.z;
+        if (inv_z.value() < 0) return;
+        const dcfloat image_x = v_c.x * inv_z * a.intr.fx + a.intr.cx;
+        const dcfloat image_y = v_c.y * inv_z * a.intr.fy + a.intr.cy;
+        const int coo_x = __float2int_rd(image_x.value() - 0.5f), coo_y = __float2int_rd(image_y.value() - 0.5f);
+        if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return;
+        const int near_x = __float2int_rn(image_x.value()), near_y = __float2int_rn(image_y.value());
+        dcfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x]);
+        const dcfloat d00(row_ptr(a.depth, a.dstep, coo_y)[coo_x]), d10(row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1]);
+        const dcfloat d01(row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x]), d11(row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1]);
+        if (d00.value() != 0.0f && d01.value() != 0.0f && d10.value() != 0.0f && d11.value() != 0.0f) {  // :248-251, threshold unused
+            const dcfloat one(1.0f);
+            const dcfloat fa = image_x - dcfloat(float(coo_x) + 0.5f);
+            const dcfloat fb = image_y - dcfloat(float(coo_y) + 0.5f);
+            Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+        }
+        if (Dp.value() > 5 || Dp.value() < 0.2) return;
+        const dcfloat xl = (image_x - a.intr.cx) / a.intr.fx;
+        const dcfloat yl = (image_y - a.intr.cy) / a.intr.fy;
+        dcfloat3 v_c_1; v_c_1.x = Dp * xl; v_c_1.y = Dp * yl; v_c_1.z = Dp;
+        const dcfloat distance = norm(v_c_1) - norm(v_c);
+        const dcfloat gt_distance = gt_tsdf * a.tranc_dist;
+        const dcfloat error = (distance - gt_distance) * a.tranc_dist_inv;
+        if (fabsf(error.value()) > 1) return;
+        const dcfloat loss = error * error;
+        if (a.real_out) {
+            a.real_out[index] = loss.value(); a.grad_out[index] = loss.grad();
+            a.hess_out[index] = loss.hessian(); a.count_out[index] = 1;
+        }
+        acc[0] += loss.value(); acc[1] += loss.grad(); acc[2] += loss.hessian(); acc[3] += 1.0;
+    });
     block_fold_and_finish<4>(acc, a.partials, a.ticket, a.out);
 }
 
-template <int VEC>
 __global__ void __launch_bounds__(256) k_tsdf_loss(const HessArgs a, const HessPoseF P) {
     double acc[2] = {0.0, 0.0};
-    // a bounded number of workgroups (each pays an L2 write-back and a ticket when it retires) stride over the tiles
-    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int x = (threadIdx.x + (tile % a.tiles_x) * 64) * VEC;
-    const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
-    if (x < a.X && y < a.Y) {
-        const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        const float vgy = (float(y) + 0.5f) * a.voxel_size;
-        for_band_voxels<VEC>(a, x, y, zb, ze, [&](int xq, int z, size_t index, float gt_tsdf) {
-            const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
-            const float vcx = (P.R[0] * vgx + P.R[1] * vgy + P.R[2] * vgz) + P.t[0];
-            const float vcy = (P.R[3] * vgx + P.R[4] * vgy + P.R[5] * vgz) + P.t[1];
-            const float vcz = (P.R[6] * vgx + P.R[7] * vgy + P.R[8] * vgz) + P.t[2];
-            const float inv_z = 1.0f / vcz;
-            if (inv_z < 0) return;
-            const float image_x = vcx * inv_z * a.intr.fx + a.intr.cx;
-            const float image_y = vcy * inv_z * a.intr.fy + a.intr.cy;
-            const int coo_x = __float2int_rd(image_x - 0.5f), coo_y = __float2int_rd(image_y - 0.5f);
-            if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return;
-            const int near_x = __float2int_rn(image_x), near_y = __float2int_rn(image_y);
-            float Dp = row_ptr(a.depth, a.dstep, near_y)[near_x];
-            const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x], d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
-            const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x], d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
-            if (d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
-                const float one = 1.0f;
-                const float fa = image_x - (float(coo_x) + 0.5f), fb = image_y - (float(coo_y) + 0.5f);
-                Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
-            }
-            if (Dp > 5 || Dp < 0.2) return;
-            const float xl = (image_x - a.intr.cx) / a.intr.fx, yl = (image_y - a.intr.cy) / a.intr.fy;
-            const float v1x = Dp * xl, v1y = Dp * yl, v1z = Dp;
-            const float distance = sqrtf(v1x * v1x + v1y * v1y + v1z * v1z) - sqrtf(vcx * vcx + vcy * vcy + vcz * vcz);
-            const float gt_distance = gt_tsdf * a.tranc_dist;
-            const float error = (distance - gt_distance) * a.tranc_dist_inv;
-            if (fabsf(error) > 1) return;
-            const float loss = error * error;
-            if (a.real_out) { a.real_out[index] = loss; a.count_out[index] = 1; }
-            acc[0] += loss; acc[1] += 1.0;
-        });
-    }
-    }
+    walk_band(a, [&](int xq, int yq, int z, size_t index, float gt_tsdf) {
+        const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgy = (float(yq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
+        const float vcx = (P.R[0] * vgx + P.R[1] * vgy + P.R[2] * vgz) + P.t[0];
+        const float vcy = (P.R[3] * vgx + P.R[4] * vgy + P.R[5] * vgz) + P.t[1];
+        const float vcz = (P.R[6] * vgx + P.R[7] * vgy + P.R[8] * vgz) + P.t[2];
+        const float inv_z = 1.0f / vcz;
+        if (inv_z < 0) return;
+        const float image_x = vcx * inv_z * a.intr.fx + a.intr.cx;
+        const float image_y = vcy * inv_z * a.intr.fy + a.intr.cy;
+        const int coo_x = __float2int_rd(image_x - 0.5f), coo_y = __float2int_rd(image_y - 0.5f);
+        if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return;
+        const int near_x = __float2int_rn(image_x), near_y = __float2int_rn(image_y);
+        float Dp = row_ptr(a.depth, a.dstep, near_y)[near_x];
+        const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x], d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
+        const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x], d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+        if (d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
+            const float one = 1.0f;
+            const float fa = image_x - (float(coo_x) + 0.5f), fb = image_y - (float(coo_y) + 0.5f);
+            Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
+        }
+        if (Dp > 5 || Dp < 0.2) return;
+        const float xl = (image_x - a.intr.cx) / a.intr.fx, yl = (image_y - a.intr.cy) / a.intr.fy;
+        const float v1x = Dp * xl, v1y = Dp * yl, v1z = Dp;
+        const float distance = sqrtf(v1x * v1x + v1y * v1y + v1z * v1z) - sqrtf(vcx * vcx + vcy * vcy + vcz * vcz);
+        const float gt_distance = gt_tsdf * a.tranc_dist;
+        const float error = (distance - gt_distance) * a.tranc_dist_inv;
+        if (fabsf(error) > 1) return;
+        const float loss = error * error;
+        if (a.real_out) { a.real_out[index] = loss; a.count_out[index] = 1; }
+        acc[0] += loss; acc[1] += 1.0;
+    });
     block_fold_and_finish<2>(acc, a.partials, a.ticket, a.out);
 }
 
@@ -841,39 +864,42 @@ __device__ __forceinline__ bool tsdf_error_c(const HessArgs &a, const MatS33 &R,
     error = (distance - gt_distance) * a.tranc_dist_inv;
     return !(fabsf(error.re) > 1);
 }
-template <int VEC>
-__global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, const GnPoses P) {
+__global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, const GnPoses Pk) {
+    // The six poses (144 floats) do not fit the scalar registers next to everything else, and the compiler then keeps them
+    // in vector registers for the whole kernel (256 of them: one wave per SIMD).  They go through LDS instead: broadcast
+    // reads where an evaluation needs them.
+    __shared__ GnPoses P;
+    {
+        const float *src = reinterpret_cast<const float *>(&Pk);
+        float *dst = reinterpret_cast<float *>(&P);
+        for (int i = threadIdx.y * 64 + threadIdx.x; i < (int)(sizeof(GnPoses) / sizeof(float)); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
     double acc[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-    // a bounded number of workgroups (each pays an L2 write-back and a ticket when it retires) stride over the tiles
-    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int x = (threadIdx.x + (tile % a.tiles_x) * 64) * VEC;
-    const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
-    if (x < a.X && y < a.Y) {
-        const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        const float vgy = (float(y) + 0.5f) * a.voxel_size;
-        for_band_voxels<VEC>(a, x, y, zb, ze, [&](int xq, int z, size_t index, float gt) {
-            const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
-            cfloat e[6];
-            bool ok = true;
+    walk_band(a, [&](int xq, int yq, int z, size_t index, float gt) {
+        const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgy = (float(yq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
+        cfloat e[6];
+        bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ok = ok && tsdf_error_c(a, P.R[k], P.t[k], vgx, vgy, vgz, gt, e[k]);
-            if (!ok) return;  // a voxel counts only if every seeded evaluation keeps it (they share their real parts)
-            const double r = (double)e[0].re;
-            int s = 0;
+        for (int k = 0; k < 6; ++k) {
+            ok = ok && tsdf_error_c(a, P.R[k], P.t[k], vgx, vgy, vgz, gt, e[k]);
+            // one evaluation at a time: left to itself the scheduler interleaves all six (256 registers, one wave per SIMD)
+            asm volatile("" : "+v"(e[k].re), "+v"(e[k].im) :: "memory");
+        }
+        if (!ok) return;  // a voxel counts only if every seeded evaluation keeps it (they share their real parts)
+        const double r = (double)e[0].re;
+        int s = 0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < 6; ++j)
 #pragma unroll
-                for (int k = j; k < 6; ++k) acc[s++] += (double)e[j].im * (double)e[k].im;
+            for (int k = j; k < 6; ++k) acc[s++] += (double)e[j].im * (double)e[k].im;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) acc[21 + k] += (double)e[k].im * r;
-            acc[27] += r * r;
-            acc[28] += 1.0;
-        });
-    }
-    }
+        for (int k = 0; k < 6; ++k) acc[21 + k] += (double)e[k].im * r;
+        acc[27] += r * r;
+        acc[28] += 1.0;
+    });
     block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out);
 }
 
@@ -894,8 +920,7 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     // kernel slower: four times the band voxels per lane, worse balance.)  Tiles of 64 x 4 columns x zchunk
     // planes; at most 1024 workgroups stride over them — with 4096 workgroups the per-workgroup L2 write-back
     // of the release fence halved the streaming rate (2.3 instead of 4.6 TB/s at 512^3).
-    a.vec = 1;
-    int gx = div_up(a.X, 64 * a.vec), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
+    int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
     while ((long long)gx * gy * zsplit < 1024 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
     a.zchunk = div_up(nz, zsplit);
     a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = div_up(nz, a.zchunk);
@@ -936,8 +961,7 @@ extern "C" int xs_compute_local_tsdf_hessian(const float *depth_scaled, size_t s
     P.t.x = dcfloat(tv2c12[0], tv2c12[1], tv2c12[2], tv2c12[3]);
     P.t.y = dcfloat(tv2c12[4], tv2c12[5], tv2c12[6], tv2c12[7]);
     P.t.z = dcfloat(tv2c12[8], tv2c12[9], tv2c12[10], tv2c12[11]);
-    if (a.vec == 4) hipLaunchKernelGGL(k_tsdf_hessian<4>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
-    else hipLaunchKernelGGL(k_tsdf_hessian<1>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    hipLaunchKernelGGL(k_tsdf_hessian, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -958,8 +982,7 @@ extern "C" int xs_compute_local_tsdf_loss(const float *depth_scaled, size_t scal
     HessPoseF P;
     for (int i = 0; i < 9; ++i) P.R[i] = Rv2c9[i];
     for (int i = 0; i < 3; ++i) P.t[i] = tv2c3[i];
-    if (a.vec == 4) hipLaunchKernelGGL(k_tsdf_loss<4>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
-    else hipLaunchKernelGGL(k_tsdf_loss<1>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    hipLaunchKernelGGL(k_tsdf_loss, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -980,8 +1003,7 @@ extern "C" int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scal
     a.real_out = nullptr; a.grad_out = nullptr; a.hess_out = nullptr; a.count_out = nullptr;
     GnPoses P;
     for (int k = 0; k < 6; ++k) { load_mat(Rv2c108 + 18 * k, P.R[k]); load_vec(tv2c36 + 6 * k, P.t[k]); }
-    if (a.vec == 4) hipLaunchKernelGGL(k_tsdf_gauss_newton<4>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
-    else hipLaunchKernelGGL(k_tsdf_gauss_newton<1>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    hipLaunchKernelGGL(k_tsdf_gauss_newton, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
     XS_CHECK(hipGetLastError());
     return 0;
 }
