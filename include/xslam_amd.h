@@ -66,6 +66,20 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
                         const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
                         int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
                         unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, void *stream);
+/* xs_integrate_scaled with its two bracketing launches under the caller's control (both are tiny, but each is a dependent
+ * dispatch on the stream: ~14 us of a 390 us frame).  flags: XS_INTEGRATE_HEADER_IS_CLEAR — the caller has cleared the
+ * workspace header since the previous call (xs_integrate_workspace_clear, on any stream ordered before this call);
+ * XS_INTEGRATE_NO_FOLD — the voxel count stays in the header's slots until the caller folds it into updated_dev
+ * (xs_integrate_fold_counts, ordered after this call and before the next clear).  updated_dev non-NULL still enables
+ * the counting.  flags = 0 is xs_integrate_scaled. */
+#define XS_INTEGRATE_HEADER_IS_CLEAR 1u
+#define XS_INTEGRATE_NO_FOLD 2u
+int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
+                           const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
+                           int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
+                           unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, unsigned flags, void *stream);
+int xs_integrate_workspace_clear(void *workspace, void *stream);
+int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, void *stream);
 /* Device workspace for xs_integrate_scaled's brick work list, for a slab of nz planes.  With a
  * workspace the kernel first lists the 64x4x8-voxel bricks that can intersect the frustum and
  * then spreads them over all CUs; without one (NULL) each column walks its own clipped range. */

@@ -43,6 +43,10 @@ _SIGS = {
                                            _vp, _vp, _vp, _sz, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "xs_integrate_scaled": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float,
                                       _vp, _vp, _vp, _sz, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "xs_integrate_scaled_ex": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, _vp, _vp,
+                                        _sz, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_uint, _vp]),
+    "xs_integrate_workspace_clear": (C.c_int, [_vp, _vp]),
+    "xs_integrate_fold_counts": (C.c_int, [_vp, _vp, _vp]),
     "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
     "xs_integrate_set_timing_events": (None, [_vp, _vp]),
     "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
@@ -178,6 +182,26 @@ def integrate_scaled(depth_scaled, scaled_step, rows, cols, intr, max_weight, re
                                    r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
                                    _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _ptr(depth_max),
                                    _ptr(workspace), _stream(stream)))
+
+
+def integrate_scaled_ex(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight,
+                        grad, vol_step, flags, threshold=0.0, z0=0, z1=None, updated=None, depth_max=None, workspace=None, stream=None):
+    """xs_integrate_scaled with flags: 1 = the header was cleared by the caller (integrate_workspace_clear), 2 = the caller folds the count."""
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
+    z1 = int(r[2]) if z1 is None else z1
+    check(_lib.xs_integrate_scaled_ex(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), max_weight,
+                                      r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
+                                      _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _ptr(depth_max),
+                                      _ptr(workspace), flags, _stream(stream)))
+
+
+def integrate_workspace_clear(workspace, stream=None):
+    check(_lib.xs_integrate_workspace_clear(_ptr(workspace), _stream(stream)))
+
+
+def integrate_fold_counts(workspace, updated, stream=None):
+    check(_lib.xs_integrate_fold_counts(_ptr(workspace), _ptr(updated), _stream(stream)))
 
 
 def integrate_workspace_bytes(res, nz=None):

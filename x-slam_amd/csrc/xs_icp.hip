@@ -104,8 +104,13 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 // POSE_DEVICE: they are what k_icp_solve left in device memory after the previous iteration.
 // POSE_POSTED: the host posts them while this launch is already resident — the launch latency of an
 // iteration (~4 us) overlaps the previous iteration's epilogue and the host's solve.
+#ifdef XS_ICP_WAVES_PER_EU   // experiment switch (profiles/tools/ab_icp_occupancy.sh): force the occupancy of the reduction kernel
+#define XS_ICP_OCC __attribute__((amdgpu_waves_per_eu(XS_ICP_WAVES_PER_EU, XS_ICP_WAVES_PER_EU)))
+#else
+#define XS_ICP_OCC
+#endif
 template <int POSE_SRC>
-__global__ void __launch_bounds__(256) k_icp(const IcpArgs a) {
+__global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
     // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel

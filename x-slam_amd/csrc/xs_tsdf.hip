@@ -489,12 +489,36 @@ extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     return 256 + nb * sizeof(int);
 }
 
+/* The two tiny launches xs_integrate_scaled wraps around its kernels, for a caller that takes them off its critical path
+ * (xs_integrate_scaled_ex with XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD): the clear of the workspace's 256-byte
+ * header (brick count + update-count slots) before the classification, and the fold of the update-count slots into
+ * updated_dev after the integrate kernel. */
+extern "C" int xs_integrate_workspace_clear(void *workspace, void *stream) {
+    if (!workspace) return xs_set_error(hipErrorInvalidValue, "xs_integrate_workspace_clear: null pointer");
+    XS_CHECK(hipMemsetAsync(workspace, 0, 256, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, void *stream) {
+    if (!workspace || !updated_dev) return xs_set_error(hipErrorInvalidValue, "xs_integrate_fold_counts: null pointer");
+    hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long *>(workspace) + 1, updated_dev);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                                    float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
                                    unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, void *stream) {
+    return xs_integrate_scaled_ex(depth_scaled, scaled_step, rows, cols, intr4, max_weight, res, voxel_size, Rv2c18, tv2c6, tranc_dist, value, weight,
+                                  grad, vol_step, threshold, z0, z1, updated_dev, depth_max_dev, workspace, 0u, stream);
+}
+extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
+                                      const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
+                                      float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
+                                      unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, unsigned flags, void *stream) {
     if (!depth_scaled || !intr4 || !res || !Rv2c18 || !tv2c6 || !value || !weight || !grad)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: null pointer");
+    if ((flags & (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD)) && !workspace)
+        return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: the flags concern the workspace path");
     if (z0 < 0 || z1 > res[2] || z1 < z0 || (vol_step % 4) != 0 || vol_step < (size_t)res[0] * 4)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: bad slab or pitch");
     if (z1 == z0 || res[0] == 0 || res[1] == 0) return 0;
@@ -519,7 +543,8 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
         a.brick_count = (unsigned *)workspace;
         a.brick_list = (int *)((char *)workspace + 256);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-        XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // brick count + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
+        if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR))
+            XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // brick count + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
         hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
         // resident workgroups stride over the list: 256 CUs x 8
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
@@ -537,7 +562,8 @@ extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step
             hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
         else
             hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
-        if (updated_dev) hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
+        if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
+            hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
     } else {
         int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
         while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;

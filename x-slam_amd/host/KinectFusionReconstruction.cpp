@@ -517,6 +517,16 @@ void KinectFusionReconstruction::icp_normal_equations(const MatS33 &Rcurr, const
     if (inliers) *inliers = (long long)pinned_sums_[54];
 }
 
+// one integrate call per frame (the volume is not sharded): its header clear and count fold can leave the main stream
+bool KinectFusionReconstruction::integrate_split() const { return zs0 == zo0 && zs1 == zo1 && integrate_ws_.ptr() != nullptr; }
+// the voxel count of the last integrate call still sits in the workspace header: fold it into its frame's counter slot
+// (on `st`, which must be ordered behind that call: the main stream, or the auxiliary one after integrate_done_)
+void KinectFusionReconstruction::flush_pending_fold(hipStream_t st) {
+    if (!pending_fold_) return;
+    check_rc(xs_integrate_fold_counts(integrate_ws_.ptr(), pending_fold_, st), "integrate count");
+    pending_fold_ = nullptr;
+}
+
 // reference :237-278
 int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d) {
     if (use_gtPose) {
@@ -566,11 +576,15 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             const int za = zr[i][0], zb = zr[i][1];
             if (zb <= za) continue;
             const size_t off = (size_t)(za - zs0) * res[1];
-            check_rc(xs_integrate_scaled(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
-                                         &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
-                                         &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
-                                         grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters : nullptr,
-                                         depth_max_dev, integrate_ws_.ptr(), st), "integrateTsdfVolume");
+            // header cleared and count folded on the auxiliary stream (SurfaceMeasure) when there is one call per frame
+            const bool split = integrate_split() && integrate_header_clear_ && i == 0;
+            check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
+                                            &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
+                                            &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
+                                            grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters : nullptr,
+                                            depth_max_dev, integrate_ws_.ptr(), split ? (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD) : 0u, st),
+                     "integrateTsdfVolume");
+            if (split) { integrate_header_clear_ = false; pending_fold_ = counters; }
             if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);
         }
     }
@@ -659,6 +673,14 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     // (the previous frame's integrate, possibly still running on the main stream, reads the same
     // buffers: wait for it — it is the first thing in that frame's tail)
     if (integrate_recorded_) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_, 0));
+    // The two tiny launches that bracket an integrate call — the fold of the previous frame's voxel count and the clear of
+    // the brick-list header — run here, off the main stream's dependent chain (each cost that chain a dispatch: ~14 us a
+    // frame); the integrate call below is told so (IntegrateFrame).  One integrate call per frame only, i.e. not sharded.
+    if (integrate_split()) {
+        flush_pending_fold(aux_stream_);
+        check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), aux_stream_), "integrate workspace");
+        integrate_header_clear_ = true;
+    }
     stage_begin(ST_SCALE);
     hipSafeCall(hipMemsetAsync(depth_max_.ptr(), 0, sizeof(float), aux_stream_));
     check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
@@ -833,6 +855,8 @@ long long KinectFusionReconstruction::last_frame_counter(int which) {
     if (counter_frame_ == 0) return 0;
     unsigned long long h[2] = {0, 0};
     synchronize();
+    flush_pending_fold(current_stream());
+    hipSafeCall(hipStreamSynchronize(current_stream()));
     hipSafeCall(hipMemcpy(h, counters_.ptr() + 2 * (size_t)((counter_frame_ - 1) % COUNTER_RING), sizeof(h), hipMemcpyDeviceToHost));
     return (long long)h[which];
 }
@@ -960,6 +984,7 @@ void KinectFusionReconstruction::end_profiled_frame() {
     if (++prof_pending_ == PROF_RING) collect_stage_times();
 }
 void KinectFusionReconstruction::collect_stage_times() {
+    flush_pending_fold(current_stream());
     synchronize();
     if (prof_pending_ > 0)
         hipSafeCall(hipMemcpy(pinned_counters_, counters_.ptr(), COUNTER_RING * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

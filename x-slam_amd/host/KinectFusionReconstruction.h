@@ -194,6 +194,11 @@ private:
     // device-side loop, [128 + 64*n ..) the 55 values of its iteration n
     enum { ICP_LOG_MAX = 62, PINNED_DOUBLES = 128 + 64 * ICP_LOG_MAX };
     double *pinned_sums_ = nullptr;
+    // the integrate call's header clear / count fold taken off the main stream (SurfaceMeasure, IntegrateFrame)
+    bool integrate_split() const;
+    void flush_pending_fold(hipStream_t st);
+    bool integrate_header_clear_ = false;
+    unsigned long long *pending_fold_ = nullptr;
     double *pinned_records_ = nullptr;   // xs_icp_records_bytes() of host-coherent pinned memory (icp_host_fold)
     void *icp_mailbox_ = nullptr;              // pose mailbox of the posted ICP launches (xs_icp_mailbox_alloc)
     int icp_mailbox_in_device_ = 0;
