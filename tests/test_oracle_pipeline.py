@@ -190,3 +190,24 @@ def test_oracle_reproduces_the_survey_figures_at_256(oracle, synth):
     assert U == fig["integrate_U"]["256"]
     assert abs(hits - fig["raycast_hits"]["256"]) <= 2
     assert abs(inl - fig["icp_inliers_level0"]["256"]) <= 0.003 * fig["icp_inliers_level0"]["256"]
+
+
+def test_oracle_pipeline_matches_ref_fixture_s3_ten_frames(oracle):
+    """The box room over ten frames: oc::cplx<float> (restatement) against the fixture made with the reference's own
+    ::complex<float> (oracle/_ref) — identical bits in every pose, and in the sampled voxels / ICP sums of frames 0, 1, 4, 9."""
+    from oracle.oracle import OracleKinFu, params_from_dict
+    g = load_golden("pipeline_s3_n96.npz")
+    kf = OracleKinFu(oracle, params_from_dict(synth.s1_params(96, seed=(2, 3))))
+    vox = g["voxel_index"]
+    for k in range(10):
+        d = synth.s3_frame(k)
+        assert int(d.astype(np.uint64).sum()) == int(g["depth_checksums"][k])
+        assert kf.process_frame(d) == 1
+        assert np.array_equal(kf.world2camera(), g[f"w2c_{k}"]), k
+        if k in (0, 1, 4, 9):
+            v, w, gr = kf.volume()
+            assert np.array_equal(v[vox], g[f"value_{k}"]) and np.array_equal(w[vox], g[f"weight_{k}"]) and np.array_equal(gr[vox], g[f"grad_{k}"])
+            assert kf.last_U() == g[f"sums_{k}"][4] and kf.last_hits() == g[f"sums_{k}"][5]
+            if k > 0:
+                assert np.array_equal(kf.icp_log(), g[f"icp_{k}"])
+    kf.close()

@@ -65,6 +65,9 @@ def test_pipeline_against_committed_fixture(dev, name, solve_on_device):
             # a couple of 1 mm pixels after the bilateral filter (expf ulp).  Beyond frame 1 only
             # coarse agreement is meaningful (rotation about the optical axis is weakly constrained
             # by a plane + sphere scene, so that entry drifts first).
+            # (the growth is measured, not assumed: tests/test_trajectory_gpu.py runs this scene beside the oracle for 30
+            # frames together with the pipeline against itself under a one-pixel perturbation — both depart by the same
+            # 0.6 ... 1.8e-2; the ten-frame fixture test below uses the constrained scene, where every frame is tight)
             assert np.all(np.isfinite(kf.world2camera()))
             pose_close(kf.world2camera(), g[f"w2c_{k}"], value_tol=2e-2, deriv_rel=10.0)
             if sums is not None:
@@ -102,6 +105,36 @@ def test_pipeline_against_committed_fixture(dev, name, solve_on_device):
             for it, rel in ((0, 1e-6), (-1, 1e-4)):
                 assert np.all(np.abs(il[it, 0:54:2] - wl[it, 0:54:2]) <= rel * np.abs(wl[it, 0:54:2]).max())
                 assert np.all(np.abs(il[it, 1:54:2] - wl[it, 1:54:2]) <= rel * np.abs(wl[it, 1:54:2]).max())
+    kf.close()
+
+
+@pytest.mark.parametrize("solve_on_device", [True, False], ids=["device_solve", "host_solve"])
+def test_pipeline_against_committed_fixture_ten_frames_constrained_scene(dev, solve_on_device):
+    """The fixture test above can only be tight for two frames: scene S1 amplifies a last-digit difference ~10x per frame at
+    these voxel sizes.  On the box room (every degree of freedom constrained; fixture made with the reference's complex class
+    over ten frames, axial CSFD seed) the GPU pipeline must stay with the fixture to the last digits for ALL ten frames:
+    poses |d| <= 2e-6, pose derivatives within 1e-3 of their largest entry (measured: identical bits for most frames), voxel
+    and hit counts within 3, sampled voxels equal up to the flip budget, d pose(2,3) / d seed alive (0.95 ... 1.25)."""
+    torch, pl = dev
+    g = load_golden("pipeline_s3_n96.npz")
+    n = int(g["n"])
+    kf = pl.KinectFusion(dict(synth.s1_params(n, seed=(2, 3)), icp_solve_on_device=solve_on_device))
+    vox = g["voxel_index"]
+    for k in range(10):
+        d = synth.s3_frame(k)
+        assert int(d.astype(np.uint64).sum()) == int(g["depth_checksums"][k]), "synthetic depth differs from the fixture's"
+        assert kf.process_frame(upload(torch, d)) == 1
+        pose_close(kf.world2camera(), g[f"w2c_{k}"], value_tol=2e-6, deriv_rel=1e-3)
+        assert 0.95 <= kf.world2camera()[2, 3, 1] / np.float32(1e-7) <= 1.25
+        if k in (0, 1, 4, 9):
+            sums = g[f"sums_{k}"]
+            assert abs(kf.last_U() - sums[4]) <= 3 and abs(kf.last_hits() - sums[5]) <= 3
+            v, w, gr = kf.volume()
+            assert mismatch_fraction(w[vox], g[f"weight_{k}"]) <= 1e-3
+            ok = w[vox] == g[f"weight_{k}"]
+            assert frac_bad(np.abs(v[vox][ok] - g[f"value_{k}"][ok]) <= 1e-5) <= FLIPS
+            gs = np.abs(g[f"grad_{k}"]).max()
+            assert frac_bad(np.abs(gr[vox][ok] - g[f"grad_{k}"][ok]) <= 1e-4 * gs) <= FLIPS
     kf.close()
 
 
