@@ -84,9 +84,10 @@ int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, v
  * workspace the kernel first lists the 64x4x8-voxel bricks that can intersect the frustum and
  * then spreads them over all CUs; without one (NULL) each column walks its own clipped range. */
 size_t xs_integrate_workspace_bytes(const int *res, int nz);
-/* Profiling hook (per host thread): hipEvent_t pair attached to the dispatch of the integrate kernel
+/* Event hook (per host thread): hipEvent_t pair attached to the dispatch of the integrate kernel
  * proper (after the brick classification) — the kernel's own begin / end, no marker packets on the
- * stream; NULL, NULL disables. */
+ * stream; either may be NULL (a stop event alone is a completion event another stream can wait on);
+ * NULL, NULL disables.  Workspace path only. */
 void xs_integrate_set_timing_events(void *start_event, void *stop_event);
 
 /* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */

@@ -382,6 +382,27 @@ def test_other_pyramid_depths_and_image_sizes(dev, oracle, levels, width, height
     kf.close()
 
 
+def test_seven_scenes_intrinsics_against_live_oracle(dev, oracle):
+    """BASELINE configs 3 and 5 name 7-Scenes: its Kinect intrinsics (585, 585, 320, 240 — fy positive, unlike the ICL file's
+    -480) on the box room rendered through those intrinsics, GPU pipeline beside the oracle pipeline for six frames: same
+    tolerances as the ICL-intrinsics runs, trajectory within a third of a voxel of the ground truth, derivative of the axial seed alive."""
+    torch, pl = dev
+    from oracle.oracle import OracleKinFu, params_from_dict
+    prm = dict(synth.s1_params(128, seed=(2, 3)), **synth.SEVEN_SCENES)
+    kf = pl.KinectFusion(prm)
+    ok_ = OracleKinFu(oracle, params_from_dict(prm))
+    for k in range(6):
+        d = synth.s3_frame(k, **synth.SEVEN_SCENES)
+        assert kf.process_frame(upload(torch, d)) == 1 and ok_.process_frame(d) == 1
+        pose_close(kf.world2camera(), ok_.world2camera(), value_tol=2e-6, deriv_rel=1e-3)
+        assert abs(kf.last_U() - ok_.last_U()) <= 3 and abs(kf.last_hits() - ok_.last_hits()) <= 3
+    c2w = np.linalg.inv(kf.world2camera()[..., 0].astype(np.float64))
+    gt = np.linalg.inv(synth.s1_pose(0)) @ synth.s1_pose(5)
+    assert np.linalg.norm(c2w[:3, 3] - gt[:3, 3]) <= 0.02      # 6 cm voxels at 128^3: a third of a voxel
+    assert 0.9 <= kf.world2camera()[2, 3, 1] / np.float32(1e-7) <= 1.3
+    kf.close(); ok_.close()
+
+
 @pytest.mark.parametrize("n", [256, 512])
 def test_full_size_first_frame_figures(dev, n):
     """BASELINE configs 2 and 3 at their full sizes: after frame 0 of scene S1 the voxels written and the rays that

@@ -553,7 +553,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // profiling: the event pair rides on the dispatch packet itself (hipExtLaunchKernelGGL: start / stop are
         // the kernel's own begin / end timestamps), so it adds no marker packets to the stream and times what
         // rocprofv3 times
-        if (g_int_ev0 && g_int_ev1) {
+        if (g_int_ev0 || g_int_ev1) {   // either may be null: a completion event alone lets another stream wait for this kernel without a marker packet
             if (threshold > 0.0f)
                 hipExtLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
             else

@@ -556,7 +556,9 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
         hipSafeCall(hipMemsetAsync(frame_counters(), 0, (COUNTER_RING / 2) * 2 * sizeof(unsigned long long), st));
     unsigned long long *counters = frame_counters();
     // the depth scaling ran on the auxiliary stream behind the map preparation
-    if (scale_recorded_) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
+    // (a wait is a packet the next kernel queues behind: none is enqueued for an event that has already completed — the
+    // scaling finished under the ICP loop long ago)
+    if (scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
     float *depth_max_dev = depth_max_.ptr();  // filled with the scaled depth by SurfaceMeasure, on the auxiliary stream
     // integrateTsdfVolume (TsdfFusion.cu:173-201), its two launches timed separately
     const int res[3] = {volume_res.x, volume_res.y, volume_res.z};
@@ -564,10 +566,17 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     DeviceArray2D<int> weight = tsdf_volume_d_ptr->weight();
     // ST_INTEGRATE brackets the integrate kernel proper of the owned planes (the events are recorded
     // inside xs_integrate_scaled, after the brick classification): the figure the roofline uses
+    // The integrate kernel's completion is what the auxiliary stream waits for before it touches the scaled depth / the
+    // workspace header again.  With one integrate call per frame that completion event rides on the kernel's own dispatch
+    // (its stop event — the profiling pair's when profiling) instead of a marker packet behind it, which the raycast
+    // launch would queue behind (~5 us of every frame).
+    hipEvent_t integrate_stop = integrate_done_;
     if (profiling) {
-        xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], prof_ring_[prof_pending_].ev[ST_INTEGRATE][1]);
+        integrate_stop = prof_ring_[prof_pending_].ev[ST_INTEGRATE][1];
+        xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], integrate_stop);
         prof_ring_[prof_pending_].used[ST_INTEGRATE] = true;
-    }
+    } else if (integrate_split())
+        xs_integrate_set_timing_events(nullptr, integrate_stop);
     {
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
@@ -589,7 +598,8 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
         }
     }
 
-    hipSafeCall(hipEventRecord(integrate_done_, st));
+    if (integrate_split()) integrate_done_now_ = integrate_stop;          // attached to the dispatch above
+    else { hipSafeCall(hipEventRecord(integrate_done_, st)); integrate_done_now_ = integrate_done_; }   // after the halo calls too
     integrate_recorded_ = true;
     stage_begin(ST_RAYCAST);
     hits_counter_ = counters + 1;
@@ -672,7 +682,7 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     // alone: metres + the frame's largest valid depth, ready long before integrate asks for them
     // (the previous frame's integrate, possibly still running on the main stream, reads the same
     // buffers: wait for it — it is the first thing in that frame's tail)
-    if (integrate_recorded_) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_, 0));
+    if (integrate_recorded_ && hipEventQuery(integrate_done_now_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_now_, 0));
     // The two tiny launches that bracket an integrate call — the fold of the previous frame's voxel count and the clear of
     // the brick-list header — run here, off the main stream's dependent chain (each cost that chain a dispatch: ~14 us a
     // frame); the integrate call below is told so (IntegrateFrame).  One integrate call per frame only, i.e. not sharded.
@@ -689,7 +699,9 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
     scale_recorded_ = true;
     current_stream() = main_stream;
-    hipSafeCall(hipStreamWaitEvent(main_stream, surface_done_, 0));
+    // the main stream picks the maps up — without a wait packet when they are already there (the usual case once the
+    // previous frame's tail is the longer of the two)
+    if (hipEventQuery(surface_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(main_stream, surface_done_, 0));
 }
 
 // reference :302-332

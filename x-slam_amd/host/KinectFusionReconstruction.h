@@ -205,6 +205,7 @@ private:
     unsigned long long icp_seq_ = 0;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
     hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr, scale_done_ = nullptr;
+    hipEvent_t integrate_done_now_ = nullptr;   // the event that marks the last integrate call's completion (integrate_done_, or its dispatch's stop event)
     bool integrate_recorded_ = false, scale_recorded_ = false;
     bool profiling_icp_sync = false;           // true: copy + stream synchronise instead of the spin (debug aid)
     int PoseEstimateOnDevice(Matrix3frm Rcurr, Vector3cf tcurr, const Matrix3frm &Rprev_inv, const Vector3cf &tprev, Matrix4cf c2w_curr,

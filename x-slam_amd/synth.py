@@ -109,8 +109,12 @@ def render_s3(c2w, width=WIDTH, height=HEIGHT, fx=FX, fy=FY, cx=CX, cy=CY):
     return np.clip(np.rint(mm), 0, 65535).astype(np.uint16)
 
 
-def s3_frame(k, T=300):
-    return render_s3(s1_pose(k, T))
+def s3_frame(k, T=300, **kw):
+    return render_s3(s1_pose(k, T), **kw)
+
+
+# 7-Scenes (BASELINE configs 3 and 5): Kinect intrinsics 585 / 585 / 320 / 240, 640 x 480 — the dataset itself is not available
+SEVEN_SCENES = dict(fx=585.0, fy=585.0, cx=320.0, cy=240.0)
 
 
 def s1_frame(k, T=300, noise_mm=0.0, **kw):
