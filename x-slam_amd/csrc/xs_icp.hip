@@ -90,6 +90,15 @@ __device__ __forceinline__ void publish_done(const IcpArgs &a) {
     __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the per-wave partial sums of a workgroup, added in wave order
+template <int WAVES>
+__device__ __forceinline__ double wave_order_sum(const double (*smem)[NP], int k) {
+    double t = smem[0][k];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) t += smem[w][k];
+    return t;
+}
+
 // Pose mailbox (xs_icp_post_pose writes it, k_icp<POSE_POSTED> polls it; xs_icp_mailbox_alloc puts it in
 // device memory the CPU reaches through the large BAR, so polling stays off the PCIe link — 512
 // workgroups polling pinned host memory cost 50 us per iteration): two 64-byte lines of 16
@@ -109,8 +118,13 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 #else
 #define XS_ICP_OCC
 #endif
-template <int POSE_SRC>
-__global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
+// WAVES = 4: lanes stride over the tiles and carry the 27 complex sums in registers (54 doubles: two waves per SIMD) — any
+// image size.  WAVES = 8: one tile per wave, chosen whenever the image has few enough tiles (a 640 x 480 level 0 has 4 800):
+// nothing is carried from tile to tile, so the products go straight from the row to the LDS fold as floats, the kernel needs
+// half the registers and runs at four waves per SIMD with every tile resident at once (the pixel loop is latency-bound:
+// profiles/r02_icp_occupancy.txt), and a launch writes an eighth as many records as it has tiles instead of a quarter.
+template <int POSE_SRC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) XS_ICP_OCC k_icp(const IcpArgs a) {
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
     // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel
@@ -178,14 +192,17 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
         }
         tcurr.x = cfloat(word(18), word(19)); tcurr.y = cfloat(word(20), word(21)); tcurr.z = cfloat(word(22), word(23));
     }
+    // 64 consecutive columns per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (a.cols + 63) / 64;
+    const int ntiles = tiles_x * (a.y1 - a.y0);
+    __shared__ double smem[WAVES][NP];
+    if constexpr (WAVES == 4) {
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
     double cnt = 0.0;
-    // 64 consecutive columns per wave; workgroups stride over (row, column-tile) pairs
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (a.cols + 63) / 64;
-    const int ntiles = tiles_x * (a.y1 - a.y0);
+    // workgroups stride over (row, column-tile) pairs
     for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
         const int y = a.y0 + t / tiles_x;
         const int x = (t % tiles_x) * 64 + lane;
@@ -215,7 +232,6 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
     // added in wave order — fixed association, no cross-lane shuffles (55 dependent 6-step
     // ds_bpermute chains cost ~20 us here).  Two passes of 28 values keep the tile at 58 KB.
     __shared__ double tile[4][28][65];
-    __shared__ double smem[4][NP];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
@@ -234,6 +250,59 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
             smem[q][half * 28 + kk] = sacc;
         }
     }
+    } else {
+    // one tile per wave: the row's 27 complex products (complex<f32>, ICP.cu:273) go to the LDS tile as they are formed —
+    // floats, [wave][value][lane], two passes of 28 values — and are added in double, lane order then wave order, as above
+    cfloat row[7];
+    float one = 0.0f;
+    {
+        const int t = blockIdx.x * 8 + wave;
+        bool ok = false;
+        cfloat3 n, d, s;
+        if (t < ntiles) {
+            const int y = a.y0 + t / tiles_x;
+            const int x = (t % tiles_x) * 64 + lane;
+            if (x < a.cols) ok = search(a, Rcurr, tcurr, x, y, n, d, s);
+        }
+        if (ok) {
+            const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
+            row[0] = cr.x; row[1] = cr.y; row[2] = cr.z;
+            row[3] = n.x; row[4] = n.y; row[5] = n.z;
+            row[6] = dot(n, d - s);
+            one = 1.0f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) row[i] = cfloat(0.0f, 0.0f);   // ICP.cu:262: a rejected pixel contributes zeros
+        }
+    }
+    __shared__ float tile[8][28][65];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        int shift = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 7; ++j) {
+                const int kre = 2 * shift, kim = 2 * shift + 1;
+                if (kre / 28 == half || kim / 28 == half) {
+                    const cfloat p = row[i] * row[j];
+                    if (kre / 28 == half) tile[wave][kre % 28][lane] = p.re;
+                    if (kim / 28 == half) tile[wave][kim % 28][lane] = p.im;
+                }
+                ++shift;
+            }
+        if (half == NS / 28) tile[wave][NS % 28][lane] = one;
+        __syncthreads();
+        const int kk = threadIdx.x >> 3, q = threadIdx.x & 7;
+        if (kk < 28 && half * 28 + kk <= NS) {
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) sacc += (double)tile[q][kk][i];
+            smem[q][half * 28 + kk] = sacc;
+        }
+    }
+    }
     __syncthreads();
     if (a.host_records) {
         // Host fold: the record goes straight to host-coherent pinned memory (28 16-byte stores of wave 0), then — once
@@ -246,8 +315,8 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
             if (threadIdx.x < NP / 2) {
                 const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
                 d2 v;
-                v.x = ((smem[0][k0] + smem[1][k0]) + smem[2][k0]) + smem[3][k0];
-                v.y = k1 <= NS ? ((smem[0][k1] + smem[1][k1]) + smem[2][k1]) + smem[3][k1] : 0.0;
+                v.x = wave_order_sum<WAVES>(smem, k0);
+                v.y = k1 <= NS ? wave_order_sum<WAVES>(smem, k1) : 0.0;
                 if (k1 <= NS) reinterpret_cast<d2 *>(a.host_records)[(size_t)blockIdx.x * (NP / 2) + threadIdx.x] = v;
                 else a.host_records[(size_t)blockIdx.x * NP + k0] = v.x;      // the count; the pad word is the sequence slot
             }
@@ -264,8 +333,8 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
         struct alignas(16) d2 { double x, y; };
         const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
         d2 v;
-        v.x = ((smem[0][k0] + smem[1][k0]) + smem[2][k0]) + smem[3][k0];
-        v.y = k1 <= NS ? ((smem[0][k1] + smem[1][k1]) + smem[2][k1]) + smem[3][k1] : 0.0;
+        v.x = wave_order_sum<WAVES>(smem, k0);
+        v.y = k1 <= NS ? wave_order_sum<WAVES>(smem, k1) : 0.0;
         reinterpret_cast<d2 *>(a.partials)[(size_t)blockIdx.x * (NP / 2) + threadIdx.x] = v;
     }
     // publish: every storing wave drains its stores, the workgroup meets, one lane takes a ticket
@@ -289,21 +358,23 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
         // after the acquire (this CU's L1 invalidated) + barrier, plain loads see every record.  The records
         // come from memory (other XCDs wrote them), so the sum is latency-bound: a record is 28 16-byte
         // chunks; thread (g, q) adds chunk q of records g, g+9, g+18, ... in that order with 32 loads in
-        // flight, and the nine row groups are then added in group order — a fixed association, so
+        // flight, and the row groups are then added in group order — a fixed association, so
         // deterministic — leaving two or three memory round trips where a plain loop had sixteen.
         struct alignas(16) d2 { double x, y; };
-        __shared__ d2 s_red[9][28];
+        // (eight waves: twice the threads, so eighteen row groups with sixteen loads each in flight — the same bytes in
+        // flight per workgroup at half the registers per lane, which is what lets this instance run at four waves per SIMD)
+        constexpr int G = WAVES == 8 ? 18 : 9, DEPTH = WAVES == 8 ? 16 : 32;
+        __shared__ d2 s_red[G][28];
         const int q = threadIdx.x % 28, g = threadIdx.x / 28;
-        if (g < 9) {
+        if (g < G) {
             const d2 *p = reinterpret_cast<const d2 *>(a.partials) + q;
             d2 acc2 = {0.0, 0.0};
             unsigned b = g;
             const unsigned nb = gridDim.x;
-            enum { DEPTH = 32 };
-            for (; b + 9 * (DEPTH - 1) < nb; b += 9 * DEPTH) {
+            for (; b + G * (DEPTH - 1) < nb; b += G * DEPTH) {
                 d2 v[DEPTH];
 #pragma unroll
-                for (int k = 0; k < DEPTH; ++k) v[k] = p[(size_t)(b + 9 * k) * (NP / 2)];
+                for (int k = 0; k < DEPTH; ++k) v[k] = p[(size_t)(b + G * k) * (NP / 2)];
 #pragma unroll
                 for (int k = 0; k < DEPTH; ++k) { acc2.x += v[k].x; acc2.y += v[k].y; }
             }
@@ -311,12 +382,12 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
                 d2 v[DEPTH];
 #pragma unroll
                 for (int k = 0; k < DEPTH; ++k) {
-                    const unsigned bb = b + 9 * k;
+                    const unsigned bb = b + G * k;
                     v[k] = bb < nb ? p[(size_t)bb * (NP / 2)] : d2{0.0, 0.0};
                 }
 #pragma unroll
                 for (int k = 0; k < DEPTH; ++k)
-                    if (b + 9 * k < nb) { acc2.x += v[k].x; acc2.y += v[k].y; }
+                    if (b + G * k < nb) { acc2.x += v[k].x; acc2.y += v[k].y; }
             }
             s_red[g][q] = acc2;
         }
@@ -324,7 +395,7 @@ __global__ void __launch_bounds__(256) XS_ICP_OCC k_icp(const IcpArgs a) {
         if (threadIdx.x < 28) {
             d2 t = s_red[0][threadIdx.x];
 #pragma unroll
-            for (int gg = 1; gg < 9; ++gg) { t.x += s_red[gg][threadIdx.x].x; t.y += s_red[gg][threadIdx.x].y; }
+            for (int gg = 1; gg < G; ++gg) { t.x += s_red[gg][threadIdx.x].x; t.y += s_red[gg][threadIdx.x].y; }
             a.out[2 * threadIdx.x] = t.x;
             if (2 * threadIdx.x + 1 < NS + 1) a.out[2 * threadIdx.x + 1] = t.y;
         }
@@ -436,7 +507,7 @@ static void ld_mat(const float *p, MatS33 &m) {
 }
 static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
 
-enum { XS_ICP_MAX_BLOCKS = 512 };  // two workgroups per CU (60 KB of LDS and 2 waves per SIMD each)
+enum { XS_ICP_MAX_BLOCKS = 512 };  // records a launch may write (two workgroups per CU are resident: 60-70 KB of LDS each)
 
 extern "C" size_t xs_icp_workspace_bytes(void) { return (size_t)XS_ICP_MAX_BLOCKS * NP * sizeof(double) + 256; }
 /* zero the arrival ticket once after allocating the workspace (launches re-arm it themselves) */
@@ -446,12 +517,25 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
     return 0;
 }
 
-// workgroups (= records) of a launch over pixel rows [y0, y1): one 64-pixel tile per wave while the image is small
-static int icp_blocks(int cols, int y0, int y1) {
+// workgroups (= records) of a launch over pixel rows [y0, y1), and the kernel shape: eight waves with one 64-pixel tile each
+// while all of them are resident at once (two such workgroups per CU: 512, i.e. up to 4 096 tiles — levels 1 and 2 of a
+// 640 x 480 frame: 13.7 us a launch against 16.0 / 14.6), else four waves striding over the tiles (level 0, 4 800 tiles: 23.1 us;
+// as 600 eight-wave workgroups a second round of workgroups has to wait for the first: 25.5 us)
+static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
     const int tiles = div_up(cols, 64) * (y1 - y0);
-    int blocks = div_up(tiles, 4);
-    if (blocks > XS_ICP_MAX_BLOCKS) blocks = XS_ICP_MAX_BLOCKS;
+    int w = 8, blocks = div_up(tiles, 8);
+    if (blocks > 512) {
+        w = 4;
+        blocks = div_up(tiles, 4);
+        if (blocks > 512) blocks = 512;
+    }
+    if (waves) *waves = w;
     return blocks < 1 ? 1 : blocks;
+}
+template <int POSE_SRC>
+static void icp_dispatch(int waves, int blocks, hipStream_t st, const IcpArgs &a) {
+    if (waves == 8) hipLaunchKernelGGL((k_icp<POSE_SRC, 8>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_icp<POSE_SRC, 4>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 // shared launcher of xs_icp_accumulate / xs_icp_iterate
@@ -479,7 +563,8 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
     a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
     a.pose = pose; a.pose_host = pose_host; a.load_pose = (pose && Rcurr18) ? 1 : 0;
     a.mailbox = nullptr; a.mailbox_seq = 0;
-    const int blocks = icp_blocks(cols, y0, y1);
+    int waves = 4;
+    const int blocks = icp_blocks(cols, y0, y1, &waves);
     // the ticket word must be zero on first use (xs_icp_workspace_init); every launch leaves it zero
     if (pose) {
         // the reduction, then the pose update it feeds; the completion word belongs to the second kernel
@@ -487,14 +572,14 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
         sa.sums = sums_dev; sa.sums_host = sums_host; sa.Rcurr = a.Rcurr; sa.tcurr = a.tcurr; sa.load_pose = a.load_pose;
         sa.pose = pose; sa.pose_host = pose_host; sa.done_flag = done_flag; sa.done_seq = done_seq;
         a.done_flag = nullptr;
-        if (a.load_pose) hipLaunchKernelGGL(k_icp<POSE_ARGS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(k_icp<POSE_DEVICE>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        if (a.load_pose) icp_dispatch<POSE_ARGS>(waves, blocks, (hipStream_t)stream, a);
+        else icp_dispatch<POSE_DEVICE>(waves, blocks, (hipStream_t)stream, a);
         hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(128), 0, (hipStream_t)stream, sa);
     } else if (mailbox) {
         a.mailbox = (const unsigned *)mailbox; a.mailbox_seq = mailbox_seq;
-        hipLaunchKernelGGL(k_icp<POSE_POSTED>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        icp_dispatch<POSE_POSTED>(waves, blocks, (hipStream_t)stream, a);
     } else
-        hipLaunchKernelGGL(k_icp<POSE_ARGS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        icp_dispatch<POSE_ARGS>(waves, blocks, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }
