@@ -59,17 +59,14 @@ def test_pipeline_against_committed_fixture(dev, name, solve_on_device):
         assert int(d.astype(np.uint64).sum()) == int(g["depth_checksums"][k]), "synthetic depth differs from the fixture's"
         assert kf.process_frame(upload(torch, d)) == 1
         sums = g[f"sums_{k}"] if k in frames else None
-        if k > 1:
-            # Tracking at 12 / 8 cm voxels amplifies a perturbation ~10x per frame (the fixture's own
-            # pose derivative grows 1e-7 -> 1e-6 over four frames), and the two sides already differ by
-            # a couple of 1 mm pixels after the bilateral filter (expf ulp).  Beyond frame 1 only
-            # coarse agreement is meaningful (rotation about the optical axis is weakly constrained
-            # by a plane + sphere scene, so that entry drifts first).
-            # (the growth is measured, not assumed: tests/test_trajectory_gpu.py runs this scene beside the oracle for 30
-            # frames together with the pipeline against itself under a one-pixel perturbation — both depart by the same
-            # 0.6 ... 1.8e-2; the ten-frame fixture test below uses the constrained scene, where every frame is tight)
-            assert np.all(np.isfinite(kf.world2camera()))
-            pose_close(kf.world2camera(), g[f"w2c_{k}"], value_tol=2e-2, deriv_rel=10.0)
+        if k > 2:
+            # Scene S1 at 12 / 8 cm voxels amplifies a last-digit difference ~100x per frame (the sphere alone holds the slide along the
+            # wall).  Measured against these fixtures: frames 0-2 identical bits; frame 3: 3.2e-7 / 1.8e-5 (pose / derivative relative to
+            # its largest entry) at 64^3, 6.7e-8 / 2.3e-6 at 96^3; frame 4: 1.0e-4 / 3.0e-3 and 1.0e-6 / 9.6e-5.  The bound is ten
+            # times the larger of the two; beyond frame 4 see tests/test_trajectory_gpu.py (30 frames beside the oracle, with the
+            # scene's own sensitivity measured) and the constrained-scene fixture test below, which is tight for every frame.
+            value_tol, deriv_rel = {3: (5e-6, 2e-4), 4: (1e-3, 3e-2)}[k]
+            pose_close(kf.world2camera(), g[f"w2c_{k}"], value_tol=value_tol, deriv_rel=deriv_rel)
             if sums is not None:
                 assert abs(kf.last_U() - sums[4]) <= 0.02 * sums[4] and abs(kf.last_hits() - sums[5]) <= 0.02 * sums[5]
             continue
