@@ -123,8 +123,12 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 // nothing is carried from tile to tile, so the products go straight from the row to the LDS fold as floats, the kernel needs
 // half the registers and runs at four waves per SIMD with every tile resident at once (the pixel loop is latency-bound:
 // profiles/r02_icp_occupancy.txt), and a launch writes an eighth as many records as it has tiles instead of a quarter.
-template <int POSE_SRC, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) XS_ICP_OCC k_icp(const IcpArgs a) {
+// PASSES (eight-wave instance only): the LDS fold takes the 55 values in two passes of 28 (70 KB per workgroup: two workgroups
+// per CU, 105 VGPRs, four waves per SIMD — up to 512 workgroups resident: levels 1 and 2) or in three of 19 (51 KB: three per CU
+// at six waves per SIMD, i.e. 85 VGPRs, which costs three spilled registers — up to 768 resident: level 0's 600).
+template <int POSE_SRC, int WAVES, int PASSES>
+__global__ void __launch_bounds__(64 * WAVES)
+    __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 ? 2 : (PASSES == 2 ? 4 : 6)))) k_icp(const IcpArgs a) {
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
     // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel
@@ -275,31 +279,32 @@ __global__ void __launch_bounds__(64 * WAVES) XS_ICP_OCC k_icp(const IcpArgs a) 
             for (int i = 0; i < 7; ++i) row[i] = cfloat(0.0f, 0.0f);   // ICP.cu:262: a rejected pixel contributes zeros
         }
     }
-    __shared__ float tile[8][28][65];
+    constexpr int PV = (NS + 1 + PASSES - 1) / PASSES;   // 28 or 19 values per pass
+    __shared__ float tile[8][PV][65];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass) __syncthreads();
         int shift = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = i; j < 7; ++j) {
                 const int kre = 2 * shift, kim = 2 * shift + 1;
-                if (kre / 28 == half || kim / 28 == half) {
+                if (kre / PV == pass || kim / PV == pass) {
                     const cfloat p = row[i] * row[j];
-                    if (kre / 28 == half) tile[wave][kre % 28][lane] = p.re;
-                    if (kim / 28 == half) tile[wave][kim % 28][lane] = p.im;
+                    if (kre / PV == pass) tile[wave][kre % PV][lane] = p.re;
+                    if (kim / PV == pass) tile[wave][kim % PV][lane] = p.im;
                 }
                 ++shift;
             }
-        if (half == NS / 28) tile[wave][NS % 28][lane] = one;
+        if (pass == NS / PV) tile[wave][NS % PV][lane] = one;
         __syncthreads();
         const int kk = threadIdx.x >> 3, q = threadIdx.x & 7;
-        if (kk < 28 && half * 28 + kk <= NS) {
+        if (kk < PV && pass * PV + kk <= NS) {
             double sacc = 0.0;
 #pragma unroll 8
             for (int i = 0; i < 64; ++i) sacc += (double)tile[q][kk][i];
-            smem[q][half * 28 + kk] = sacc;
+            smem[q][pass * PV + kk] = sacc;
         }
     }
     }
@@ -507,7 +512,7 @@ static void ld_mat(const float *p, MatS33 &m) {
 }
 static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y = cfloat(p[2], p[3]); v.z = cfloat(p[4], p[5]); }
 
-enum { XS_ICP_MAX_BLOCKS = 512 };  // records a launch may write (two workgroups per CU are resident: 60-70 KB of LDS each)
+enum { XS_ICP_MAX_BLOCKS = 768 };  // records a launch may write = eight-wave workgroups resident at once (three per CU: 51 KB of LDS, 79 VGPRs)
 
 extern "C" size_t xs_icp_workspace_bytes(void) { return (size_t)XS_ICP_MAX_BLOCKS * NP * sizeof(double) + 256; }
 /* zero the arrival ticket once after allocating the workspace (launches re-arm it themselves) */
@@ -518,13 +523,12 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
 }
 
 // workgroups (= records) of a launch over pixel rows [y0, y1), and the kernel shape: eight waves with one 64-pixel tile each
-// while all of them are resident at once (two such workgroups per CU: 512, i.e. up to 4 096 tiles — levels 1 and 2 of a
-// 640 x 480 frame: 13.7 us a launch against 16.0 / 14.6), else four waves striding over the tiles (level 0, 4 800 tiles: 23.1 us;
-// as 600 eight-wave workgroups a second round of workgroups has to wait for the first: 25.5 us)
+// while all of them are resident at once (two or three such workgroups per CU, see PASSES: up to 768, i.e. 6 144 tiles — every
+// level of a 640 x 480 frame), else four waves striding over the tiles with the sums in registers (any size)
 static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
     const int tiles = div_up(cols, 64) * (y1 - y0);
     int w = 8, blocks = div_up(tiles, 8);
-    if (blocks > 512) {
+    if (blocks > XS_ICP_MAX_BLOCKS) {
         w = 4;
         blocks = div_up(tiles, 4);
         if (blocks > 512) blocks = 512;
@@ -534,8 +538,9 @@ static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
 }
 template <int POSE_SRC>
 static void icp_dispatch(int waves, int blocks, hipStream_t st, const IcpArgs &a) {
-    if (waves == 8) hipLaunchKernelGGL((k_icp<POSE_SRC, 8>), dim3(blocks), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_icp<POSE_SRC, 4>), dim3(blocks), dim3(256), 0, st, a);
+    if (waves == 8 && blocks <= 512) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2>), dim3(blocks), dim3(512), 0, st, a);
+    else if (waves == 8) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 3>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_icp<POSE_SRC, 4, 2>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 // shared launcher of xs_icp_accumulate / xs_icp_iterate
