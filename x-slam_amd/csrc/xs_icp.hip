@@ -45,18 +45,20 @@ struct IcpArgs {
 
 namespace {
 // ICP.cu:196-244
-__device__ __forceinline__ bool search(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, cfloat3 &n, cfloat3 &d,
-                                       cfloat3 &s) {
-    // all six current-frame values are requested before the sentinel is looked at (the y / z planes of an
-    // invalid pixel are allocated, merely unused): one memory round trip instead of two — the kernel is
-    // latency-bound at two waves per SIMD
-    cfloat3 ncurr, vcurr;
+// the six current-frame values of a pixel: they depend on nothing but the pixel, so the one-tile-per-wave instance requests them
+// before it even has its pose (a posted launch spends ~3 us waiting for it)
+__device__ __forceinline__ void load_current(const IcpArgs &a, int x, int y, cfloat3 &ncurr, cfloat3 &vcurr) {
+    // all six are requested before the sentinel is looked at (the y / z planes of an invalid pixel are allocated, merely
+    // unused): one memory round trip instead of two
     ncurr.x = row_ptr(a.nmap_curr, a.mstep, y)[x];
     ncurr.y = row_ptr(a.nmap_curr, a.mstep, y + a.rows)[x];
     ncurr.z = row_ptr(a.nmap_curr, a.mstep, y + 2 * a.rows)[x];
     vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
     vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
     vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
+}
+__device__ __forceinline__ bool search_loaded(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, const cfloat3 &ncurr, const cfloat3 &vcurr,
+                                              cfloat3 &n, cfloat3 &d, cfloat3 &s) {
     if (isnan(ncurr.x.re)) return false;
     const cfloat3 vcurr_g = Rcurr * vcurr + tcurr;
     const cfloat3 vcp = a.Rprev_inv * (vcurr_g - a.tprev);
@@ -80,6 +82,12 @@ __device__ __forceinline__ bool search(const IcpArgs &a, const MatS33 &Rcurr, co
     n = nprev_g; d = vprev_g; s = vcurr_g;
     return true;
 }
+__device__ __forceinline__ bool search(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, cfloat3 &n, cfloat3 &d,
+                                       cfloat3 &s) {
+    cfloat3 ncurr, vcurr;
+    load_current(a, x, y, ncurr, vcurr);
+    return search_loaded(a, Rcurr, tcurr, ncurr, vcurr, n, d, s);
+}
 constexpr int NS = 54;      // 27 complex sums
 constexpr int NP = 56;      // partial record: 54 sums + count + pad
 }  // namespace
@@ -89,6 +97,18 @@ __device__ __forceinline__ void publish_done(const IcpArgs &a) {
     __threadfence_system();
     __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// Phase stamps of every workgroup (experiment build -DXS_ICP_TRACE, profiles/tools/trace_icp.sh): 100 MHz wall clock at entry, pose ready,
+// pixels done, fold done, record stored, released, ticket back, (last workgroup:) acquired, gathered, result out.
+#ifdef XS_ICP_TRACE
+__device__ unsigned long long g_icp_trace[768 * 16];
+#define XS_STAMP(i) do { if (threadIdx.x == 0) g_icp_trace[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+extern "C" int xs_debug_icp_trace(unsigned long long *out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_icp_trace), sizeof(g_icp_trace));
+}
+#else
+#define XS_STAMP(i) do { } while (0)
+#endif
 
 // the per-wave partial sums of a workgroup, added in wave order
 template <int WAVES>
@@ -129,6 +149,18 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 template <int POSE_SRC, int WAVES, int PASSES>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 ? 2 : (PASSES == 2 ? 4 : 6)))) k_icp(const IcpArgs a) {
+    XS_STAMP(0);
+    // one tile per wave: the tile's current-frame values are on their way before the pose is (a pixel outside the image reads
+    // pixel (0, y0): resident, never used)
+    cfloat3 pre_n, pre_v;
+    bool pre_ok = false;
+    if constexpr (WAVES == 8) {
+        const int tiles_x0 = (a.cols + 63) / 64;
+        const int t0 = blockIdx.x * 8 + (threadIdx.x >> 6);
+        const int y = a.y0 + t0 / tiles_x0, x = (t0 % tiles_x0) * 64 + (threadIdx.x & 63);
+        pre_ok = t0 < tiles_x0 * (a.y1 - a.y0) && x < a.cols;
+        load_current(a, pre_ok ? x : 0, pre_ok ? y : a.y0, pre_n, pre_v);
+    }
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
     // (readfirstlane: the 24 floats are wave-uniform and belong in scalar registers, like the kernel
@@ -196,6 +228,7 @@ __global__ void __launch_bounds__(64 * WAVES)
         }
         tcurr.x = cfloat(word(18), word(19)); tcurr.y = cfloat(word(20), word(21)); tcurr.z = cfloat(word(22), word(23));
     }
+    XS_STAMP(1);
     // 64 consecutive columns per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_x = (a.cols + 63) / 64;
@@ -260,14 +293,9 @@ __global__ void __launch_bounds__(64 * WAVES)
     cfloat row[7];
     float one = 0.0f;
     {
-        const int t = blockIdx.x * 8 + wave;
         bool ok = false;
         cfloat3 n, d, s;
-        if (t < ntiles) {
-            const int y = a.y0 + t / tiles_x;
-            const int x = (t % tiles_x) * 64 + lane;
-            if (x < a.cols) ok = search(a, Rcurr, tcurr, x, y, n, d, s);
-        }
+        if (pre_ok) ok = search_loaded(a, Rcurr, tcurr, pre_n, pre_v, n, d, s);
         if (ok) {
             const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
             row[0] = cr.x; row[1] = cr.y; row[2] = cr.z;
@@ -279,6 +307,7 @@ __global__ void __launch_bounds__(64 * WAVES)
             for (int i = 0; i < 7; ++i) row[i] = cfloat(0.0f, 0.0f);   // ICP.cu:262: a rejected pixel contributes zeros
         }
     }
+    XS_STAMP(2);
     constexpr int PV = (NS + 1 + PASSES - 1) / PASSES;   // 28 or 19 values per pass
     __shared__ float tile[8][PV][65];
 #pragma unroll
@@ -301,14 +330,20 @@ __global__ void __launch_bounds__(64 * WAVES)
         __syncthreads();
         const int kk = threadIdx.x >> 3, q = threadIdx.x & 7;
         if (kk < PV && pass * PV + kk <= NS) {
-            double sacc = 0.0;
-#pragma unroll 8
-            for (int i = 0; i < 64; ++i) sacc += (double)tile[q][kk][i];
-            smem[q][pass * PV + kk] = sacc;
+            // four interleaved partial sums (lanes i, i + 4, ... each), then ((s0 + s1) + (s2 + s3)): the same fixed association
+            // every launch, a quarter of the dependent-add chain
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 64; i += 4) {
+                s0 += (double)tile[q][kk][i]; s1 += (double)tile[q][kk][i + 1];
+                s2 += (double)tile[q][kk][i + 2]; s3 += (double)tile[q][kk][i + 3];
+            }
+            smem[q][pass * PV + kk] = (s0 + s1) + (s2 + s3);
         }
     }
     }
     __syncthreads();
+    XS_STAMP(3);
     if (a.host_records) {
         // Host fold: the record goes straight to host-coherent pinned memory (28 16-byte stores of wave 0), then — once
         // those stores are acknowledged and released at system scope — its last word receives the launch's sequence
@@ -345,17 +380,21 @@ __global__ void __launch_bounds__(64 * WAVES)
     // publish: every storing wave drains its stores, the workgroup meets, one lane takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    XS_STAMP(4);
     __shared__ unsigned s_last;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XS_STAMP(5);
         const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+        XS_STAMP(6);
         if (s_last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             // the ticket re-arms itself: the next launch on this stream starts from zero
             __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // holds the barrier until the invalidate has completed
+            XS_STAMP(7);
         }
     }
     __syncthreads();
@@ -397,6 +436,7 @@ __global__ void __launch_bounds__(64 * WAVES)
             s_red[g][q] = acc2;
         }
         __syncthreads();
+        XS_STAMP(8);
         if (threadIdx.x < 28) {
             d2 t = s_red[0][threadIdx.x];
 #pragma unroll
@@ -411,6 +451,8 @@ __global__ void __launch_bounds__(64 * WAVES)
             __syncthreads();
             if (threadIdx.x == 0) publish_done(a);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XS_STAMP(9);
     }
 }
 
