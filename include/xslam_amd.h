@@ -223,6 +223,13 @@ int xs_icp_accumulate_records(const float *Rcurr18, const float *tcurr6, const v
                               const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,
                               double *records_host, unsigned long long seq, void *stream);
 int xs_icp_sum_records(const double *records_host, int count, unsigned long long seq, double *sums55, long long max_spins);
+
+/* Test hook for the gate shortcut of the correspondence search: the two rejection tests of ICP.cu:232-241 use only the real
+ * part of a complex square root, which the kernel settles from bounds on it unless the value sits on the threshold (then it
+ * runs the square root).  Compares that decision with the full evaluation on n complex values (device memory, re / im
+ * interleaved): counts_dev[0] = disagreements (must stay 0), counts_dev[1] = values that needed the square root.
+ * counts_dev = two zeroed 32-bit words in device memory.  No synchronisation. */
+int xs_icp_gate_selftest(const float *z2n_dev, int n, float thres, int or_equal, unsigned *counts_dev, void *stream);
 /* estimateCombined with the pose posted AFTER the launch (same reference interface as above; it
  * replaces the launch latency between two iterations of KinectFusionReconstruction.cpp:187-225).
  * The call is made while the previous iteration is still running; the launch becomes resident behind

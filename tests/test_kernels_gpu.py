@@ -571,6 +571,41 @@ def test_icp_all_invalid(dev):
     assert inl == 0 and not A.any() and not b.any()
 
 
+@pytest.mark.parametrize("thres,or_equal", [(0.1, False), (0.2, True), (np.sin(np.radians(20.0)), True), (3e-3, False)])
+def test_icp_gate_shortcut_decides_like_the_square_root(dev, thres, or_equal):
+    """The two rejection tests of the ICP search (ICP.cu:232-241) settled from bounds on Re sqrt z: the same boolean as the
+    full complex square root for values on, next to and far from the threshold, inside and outside the short form's cone,
+    for negative, zero, huge, infinite and NaN arguments."""
+    torch, capi = dev
+    rng = np.random.default_rng(11)
+    t2 = np.float64(np.float32(thres)) ** 2
+    rel = np.concatenate([[0.0], np.logspace(-8, -1, 57)])
+    rel = np.concatenate([rel, -rel])
+    a = (t2 * (1.0 + rel))[:, None]
+    brel = np.concatenate([[0.0], np.logspace(-9, 1, 41)])
+    brel = np.concatenate([brel, -brel])[None, :]
+    grid = np.stack(np.broadcast_arrays(a, a * brel), -1).reshape(-1, 2)
+    # a within a few ulp of the threshold's square, b small: the values the full path must decide
+    ulps = np.nextafter(np.float32(t2), np.float32(np.inf)) - np.float32(t2)
+    near = np.stack([np.float32(t2) + ulps * rng.integers(-40, 41, 20000).astype(np.float32),
+                     (t2 * 10.0 ** rng.uniform(-9, -3, 20000) * rng.choice([-1, 1], 20000)).astype(np.float32)], -1)
+    wide = np.stack([10.0 ** rng.uniform(-12, 2, 50000) * rng.choice([-1, 1, 1, 1], 50000),
+                     10.0 ** rng.uniform(-14, 2, 50000) * rng.choice([-1, 1], 50000)], -1)
+    special = np.array([[0, 0], [-0.0, 0], [0, 1e-9], [-t2, 0], [-t2, 1e-9], [np.inf, 0], [-np.inf, 0], [1, np.inf], [np.nan, 0],
+                        [0, np.nan], [1e38, 1e38], [3e38, 3e38], [1e-45, 0], [1e-45, 1e-45], [t2, np.inf]], np.float64)
+    z = np.concatenate([grid, near, wide, special]).astype(np.float32)
+    zt = torch.from_numpy(np.ascontiguousarray(z)).cuda()
+    zc = torch.view_as_complex(zt)
+    bad, full = capi.icp_gate_selftest(zc, thres, or_equal)
+    assert bad == 0
+    # the near-threshold block reaches the square root; values far from the threshold with a >= 0 and small |b| never do
+    # (a < 0 or |b| > a leaves the bounds too far apart to decide: the wide block has a share of those)
+    assert 20000 <= full < 0.75 * len(z)
+    far = z[(z[:, 0] > 0) & (np.abs(z[:, 1]) < 1e-3 * z[:, 0]) & (np.abs(z[:, 0] / np.float32(t2) - 1) > 1e-2)]
+    assert len(far) > 10000
+    assert capi.icp_gate_selftest(torch.view_as_complex(torch.from_numpy(np.ascontiguousarray(far)).cuda()), thres, or_equal) == (0, 0)
+
+
 # ---- dual-complex Hessian / loss -----------------------------------------------------------
 def test_tsdf_hessian_and_loss_golden(dev, oracle):
     torch, capi = dev

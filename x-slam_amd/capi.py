@@ -91,6 +91,7 @@ _SIGS = {
     "xs_icp_accumulate_records": (C.c_int, [_f32p, _f32p, _vp, C.c_uint, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                             C.c_float, C.c_int, C.c_int, _vp, C.c_ulonglong, _vp]),
     "xs_icp_sum_records": (C.c_int, [_vp, C.c_int, C.c_ulonglong, _f64p, C.c_longlong]),
+    "xs_icp_gate_selftest": (C.c_int, [_vp, C.c_int, C.c_float, C.c_int, _vp, _vp]),
     "xs_icp_iterate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                  C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_estimate_combined": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -414,6 +415,18 @@ def icp_sum_records(records, count, seq, max_spins=2000000000):
     out = np.zeros(55, np.float64)
     rc = _lib.xs_icp_sum_records(_ptr(records), count, seq, out.ctypes.data_as(_f64p), max_spins)
     return rc, out
+
+
+def icp_gate_selftest(z, thres, or_equal, stream=None):
+    """Gate shortcut of the ICP search against the full complex square root on the complex64 tensor `z` (device).
+    Returns (disagreements, values that needed the square root)."""
+    import torch
+    zz = torch.view_as_real(z.contiguous()).contiguous()
+    counts = torch.zeros(2, dtype=torch.int32, device=z.device)
+    check(_lib.xs_icp_gate_selftest(_ptr(zz), z.numel(), float(thres), int(bool(or_equal)), _ptr(counts), _stream(stream)))
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().astype(np.int64)
+    return int(c[0]), int(c[1])
 
 
 def icp_mailbox_bytes():

@@ -57,6 +57,23 @@ __device__ __forceinline__ void load_current(const IcpArgs &a, int x, int y, cfl
     vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
     vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
 }
+// The two gates of ICP.cu:232-241 compare the REAL part of a complex square root with a threshold and use nothing else of
+// it.  For z = a + ib, Re sqrt z = sqrt((|z| + a) / 2) lies in [sqrt(max(a, 0)), sqrt(|a| + |b|)], and the float sequence
+// the reference runs (hypot, sqrt, atan2, cos, one product — or the short form of xs_complex.h) lands within a few ulp of it:
+// with a margin three hundred times that (1e-5 relative on the squares) the comparison is settled from a and b alone unless
+// the value sits on the threshold, and only then does the lane run the square root itself (~330 instructions when the
+// argument is outside the short form's cone, which is where matched pixels live: |d| of a millimetre, sine ~ 0).  The same
+// booleans as the full evaluation for every input (xs_icp_gate_selftest sweeps the neighbourhood of the threshold).
+__device__ __forceinline__ bool re_sqrt_exceeds(cfloat z, float thres, bool or_equal) {
+    const float lo2 = fmaxf(z.re, 0.0f), hi2 = fabsf(z.re) + fabsf(z.im), t2 = thres * thres;
+    constexpr float M = 1e-5f;
+    if (thres > 0x1p-60f && thres < 0x1p60f) {   // NaN operands fail both tests and take the full path
+        if (hi2 * (1.0f + M) < t2) return false;
+        if (lo2 > t2 * (1.0f + M)) return true;
+    }
+    const float r = sqrt(z).re;
+    return or_equal ? r >= thres : r > thres;
+}
 __device__ __forceinline__ bool search_loaded(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, const cfloat3 &ncurr, const cfloat3 &vcurr,
                                               cfloat3 &n, cfloat3 &d, cfloat3 &s) {
     if (isnan(ncurr.x.re)) return false;
@@ -74,11 +91,9 @@ __device__ __forceinline__ bool search_loaded(const IcpArgs &a, const MatS33 &Rc
     vprev_g.y = row_ptr(a.vmap_g_prev, a.mstep, uy + a.rows)[ux];
     vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
     if (isnan(nprev_g.x.re)) return false;
-    const cfloat dist = norm(vprev_g - vcurr_g);
-    if (dist.re > a.distThres) return false;
+    if (re_sqrt_exceeds(squarednorm(vprev_g - vcurr_g), a.distThres, false)) return false;   // norm(...).re > distThres
     const cfloat3 ncurr_g = Rcurr * ncurr;
-    const cfloat sine = norm(cross(ncurr_g, nprev_g));
-    if (sine.re >= a.angleThres) return false;
+    if (re_sqrt_exceeds(squarednorm(cross(ncurr_g, nprev_g)), a.angleThres, true)) return false;   // norm(...).re >= angleThres
     n = nprev_g; d = vprev_g; s = vcurr_g;
     return true;
 }
@@ -109,6 +124,14 @@ extern "C" int xs_debug_icp_trace(unsigned long long *out_host) {
 #else
 #define XS_STAMP(i) do { } while (0)
 #endif
+
+// the value held by the neighbouring lane (lane ^ 1): two quad-permute moves, no LDS
+__device__ __forceinline__ double pair_swap(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);          // quad_perm [1, 0, 3, 2]
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 
 // the per-wave partial sums of a workgroup, added in wave order
 template <int WAVES>
@@ -148,7 +171,8 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 // at six waves per SIMD, i.e. 85 VGPRs, which costs three spilled registers — up to 768 resident: level 0's 600).
 template <int POSE_SRC, int WAVES, int PASSES>
 __global__ void __launch_bounds__(64 * WAVES)
-    __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 ? 2 : (PASSES == 2 ? 4 : 6)))) k_icp(const IcpArgs a) {
+    __attribute__((amdgpu_waves_per_eu(WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6))))
+    k_icp(const IcpArgs a) {
     XS_STAMP(0);
     // one tile per wave: the tile's current-frame values are on their way before the pose is (a pixel outside the image reads
     // pixel (0, y0): resident, never used)
@@ -234,6 +258,11 @@ __global__ void __launch_bounds__(64 * WAVES)
     const int tiles_x = (a.cols + 63) / 64;
     const int ntiles = tiles_x * (a.y1 - a.y0);
     __shared__ double smem[WAVES][NP];
+    // one LDS buffer for the fold's tile and, afterwards, the last workgroup's row-group sums
+    constexpr int PV = (NS + 1 + PASSES - 1) / PASSES;   // eight-wave instance: 55, 28 or 19 values per pass
+    constexpr int RS = 68;                               // ... in rows 68 floats apart
+    constexpr int TILE_BYTES = WAVES == 4 ? 4 * 28 * 65 * 8 : 8 * PV * RS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_tile[TILE_BYTES];
     if constexpr (WAVES == 4) {
     double acc[NS];
 #pragma unroll
@@ -268,7 +297,7 @@ __global__ void __launch_bounds__(64 * WAVES)
     // threads per value each add one wave's 64 entries in lane order and the four results are
     // added in wave order — fixed association, no cross-lane shuffles (55 dependent 6-step
     // ds_bpermute chains cost ~20 us here).  Two passes of 28 values keep the tile at 58 KB.
-    __shared__ double tile[4][28][65];
+    double (*tile)[28][65] = reinterpret_cast<double (*)[28][65]>(lds_tile);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
@@ -289,7 +318,7 @@ __global__ void __launch_bounds__(64 * WAVES)
     }
     } else {
     // one tile per wave: the row's 27 complex products (complex<f32>, ICP.cu:273) go to the LDS tile as they are formed —
-    // floats, [wave][value][lane], two passes of 28 values — and are added in double, lane order then wave order, as above
+    // floats, one row per (wave, value), in one, two or three passes — and are added in double, lane order then wave order, as above
     cfloat row[7];
     float one = 0.0f;
     {
@@ -308,8 +337,12 @@ __global__ void __launch_bounds__(64 * WAVES)
         }
     }
     XS_STAMP(2);
-    constexpr int PV = (NS + 1 + PASSES - 1) / PASSES;   // 28 or 19 values per pass
-    __shared__ float tile[8][PV][65];
+    // Rows of 64 floats, one per (wave, value), 68 floats apart: 16-byte aligned with an odd number of 16-byte chunks between
+    // rows, so the wave's row-wise stores and the adders' 128-bit loads (eight consecutive lanes = eight consecutive rows, or
+    // four rows x two halves) are both free of bank conflicts.  A row is added by two lanes, 32 entries each, when the
+    // workgroup has the threads for it (two or three passes), by one otherwise.
+    constexpr int SPLIT = 16 * PV <= 512 ? 2 : 1;
+    float *tile = reinterpret_cast<float *>(lds_tile);
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         if (pass) __syncthreads();
@@ -321,24 +354,42 @@ __global__ void __launch_bounds__(64 * WAVES)
                 const int kre = 2 * shift, kim = 2 * shift + 1;
                 if (kre / PV == pass || kim / PV == pass) {
                     const cfloat p = row[i] * row[j];
-                    if (kre / PV == pass) tile[wave][kre % PV][lane] = p.re;
-                    if (kim / PV == pass) tile[wave][kim % PV][lane] = p.im;
+                    if (kre / PV == pass) tile[(wave * PV + kre % PV) * RS + lane] = p.re;
+                    if (kim / PV == pass) tile[(wave * PV + kim % PV) * RS + lane] = p.im;
                 }
                 ++shift;
             }
-        if (pass == NS / PV) tile[wave][NS % PV][lane] = one;
+        if (pass == NS / PV) tile[(wave * PV + NS % PV) * RS + lane] = one;
         __syncthreads();
-        const int kk = threadIdx.x >> 3, q = threadIdx.x & 7;
-        if (kk < PV && pass * PV + kk <= NS) {
-            // four interleaved partial sums (lanes i, i + 4, ... each), then ((s0 + s1) + (s2 + s3)): the same fixed association
-            // every launch, a quarter of the dependent-add chain
+        const int r = threadIdx.x / SPLIT, h = threadIdx.x % SPLIT;
+        if (r < 8 * PV) {
+            // four interleaved partial sums (entries i, i + 4, ... each) per lane; with two lanes per row the halves are added
+            // partial by partial, then ((s0 + s1) + (s2 + s3)): the same fixed association every launch.  The second lane
+            // walks its eight chunks starting from the fifth, which keeps the pair on different banks.
+            const float4 *p = reinterpret_cast<const float4 *>(tile + r * RS);
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            if constexpr (SPLIT == 1) {
 #pragma unroll
-            for (int i = 0; i < 64; i += 4) {
-                s0 += (double)tile[q][kk][i]; s1 += (double)tile[q][kk][i + 1];
-                s2 += (double)tile[q][kk][i + 2]; s3 += (double)tile[q][kk][i + 3];
+                for (int c = 0; c < 16; ++c) {
+                    const float4 f = p[c];
+                    s0 += (double)f.x; s1 += (double)f.y; s2 += (double)f.z; s3 += (double)f.w;
+                }
+            } else {
+                const float4 *pa = p + 12 * h, *pb = p + 4 + 4 * h;   // lane 0: chunks 0-3 then 4-7; lane 1: 12-15 then 8-11
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 f = pa[c];
+                    s0 += (double)f.x; s1 += (double)f.y; s2 += (double)f.z; s3 += (double)f.w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 f = pb[c];
+                    s0 += (double)f.x; s1 += (double)f.y; s2 += (double)f.z; s3 += (double)f.w;
+                }
+                s0 += pair_swap(s0); s1 += pair_swap(s1); s2 += pair_swap(s2); s3 += pair_swap(s3);
             }
-            smem[q][pass * PV + kk] = (s0 + s1) + (s2 + s3);
+            const int w = r / PV, v = r % PV;
+            if (h == 0 && pass * PV + v <= NS) smem[w][pass * PV + v] = (s0 + s1) + (s2 + s3);
         }
     }
     }
@@ -408,7 +459,8 @@ __global__ void __launch_bounds__(64 * WAVES)
         // (eight waves: twice the threads, so eighteen row groups with sixteen loads each in flight — the same bytes in
         // flight per workgroup at half the registers per lane, which is what lets this instance run at four waves per SIMD)
         constexpr int G = WAVES == 8 ? 18 : 9, DEPTH = WAVES == 8 ? 16 : 32;
-        __shared__ d2 s_red[G][28];
+        static_assert(TILE_BYTES >= G * 28 * 16, "row-group sums live in the fold's tile");
+        d2 (*s_red)[28] = reinterpret_cast<d2 (*)[28]>(lds_tile);   // every wave is past the fold (barriers above)
         const int q = threadIdx.x % 28, g = threadIdx.x / 28;
         if (g < G) {
             const d2 *p = reinterpret_cast<const d2 *>(a.partials) + q;
@@ -580,7 +632,8 @@ static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
 }
 template <int POSE_SRC>
 static void icp_dispatch(int waves, int blocks, hipStream_t st, const IcpArgs &a) {
-    if (waves == 8 && blocks <= 512) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2>), dim3(blocks), dim3(512), 0, st, a);
+    if (waves == 8 && blocks <= 256) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 1>), dim3(blocks), dim3(512), 0, st, a);
+    else if (waves == 8 && blocks <= 512) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2>), dim3(blocks), dim3(512), 0, st, a);
     else if (waves == 8) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 3>), dim3(blocks), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((k_icp<POSE_SRC, 4, 2>), dim3(blocks), dim3(256), 0, st, a);
 }
@@ -831,4 +884,27 @@ extern "C" void xs_icp_unpack(const double *sums54, double *A72, double *b12) {
                 A72[2 * (i * 6 + j)] = re; A72[2 * (i * 6 + j) + 1] = im;
             }
         }
+}
+
+// ---- self-test of the gate shortcut ---------------------------------------------------------
+__global__ void k_icp_gate_check(const float *z2n, int n, float thres, int or_equal, unsigned *counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cfloat z(z2n[2 * i], z2n[2 * i + 1]);
+    const bool fast = re_sqrt_exceeds(z, thres, or_equal != 0);
+    const float r = sqrt(z).re;
+    const bool full = or_equal ? r >= thres : r > thres;
+    if (fast != full) atomicAdd(&counts[0], 1u);
+    const float lo2 = fmaxf(z.re, 0.0f), hi2 = fabsf(z.re) + fabsf(z.im), t2 = thres * thres;
+    if (!(hi2 * (1.0f + 1e-5f) < t2) && !(lo2 > t2 * (1.0f + 1e-5f))) atomicAdd(&counts[1], 1u);
+}
+/* Gate shortcut of the ICP search (re_sqrt_exceeds) against the full complex square root on n complex values (device, re / im
+ * interleaved): counts_dev[0] = values on which the two disagree (must be 0), counts_dev[1] = values the shortcut could not
+ * settle from its bounds.  counts_dev: two zeroed 32-bit words of device memory.  Test hook; no synchronisation. */
+extern "C" int xs_icp_gate_selftest(const float *z2n_dev, int n, float thres, int or_equal, unsigned *counts_dev, void *stream) {
+    if (!z2n_dev || !counts_dev || n < 0) return xs_set_error(hipErrorInvalidValue, "xs_icp_gate_selftest: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_icp_gate_check, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, z2n_dev, n, thres, or_equal, counts_dev);
+    XS_CHECK(hipGetLastError());
+    return 0;
 }
