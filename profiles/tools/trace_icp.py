@@ -20,6 +20,7 @@ for l in (2, 1, 0):
         torch.cuda.synchronize()
     tr = np.zeros(768 * 16, np.uint64)
     assert capi._lib.xs_debug_icp_trace(tr.ctypes.data) == 0
+    where = tr.reshape(768, 16)[:blocks, 10]                      # XCC_ID << 32 | HW_ID of the workgroup's first wave
     tr = tr.reshape(768, 16)[:blocks, :10].astype(np.int64)
     base = tr[:, 0].min()
     last = int(np.argmax(tr[:, 9]))            # only the last workgroup stamps 7..9 in this launch (older stamps are smaller)
@@ -28,3 +29,13 @@ for l in (2, 1, 0):
     for i, nme in enumerate(names):
         col = rel[:, i] if i <= 6 else rel[last:last + 1, i]
         print(f"   {nme:14s} last wg {rel[last, i]:7.2f} us   all wgs min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f}")
+    # the same per workgroup: how long each phase took, and how that goes with the number of workgroups sharing its CU
+    cu = ((where >> 32) & 0xF) * 4096 + ((where >> 8) & 0xFF)       # (XCC, SE / SH / CU fields of HW_ID)
+    _, inv, cnt = np.unique(cu, return_inverse=True, return_counts=True)
+    share = cnt[inv]
+    dur = np.diff(rel[:, :7], axis=1)
+    print(f"   workgroups per CU: " + ", ".join(f"{c} on {int((cnt == c).sum())} CUs" for c in sorted(set(cnt))))
+    for i in range(6):
+        d = dur[:, i]
+        by = "  ".join(f"[{c}/CU] {np.median(d[share == c]):5.2f}" for c in sorted(set(cnt)))
+        print(f"   {names[i]:>13s} -> {names[i + 1]:14s} median {np.median(d):5.2f}  p90 {np.percentile(d, 90):5.2f}  max {d.max():5.2f} us   medians {by}")

@@ -117,7 +117,8 @@ __device__ __forceinline__ void publish_done(const IcpArgs &a) {
 // pixels done, fold done, record stored, released, ticket back, (last workgroup:) acquired, gathered, result out.
 #ifdef XS_ICP_TRACE
 __device__ unsigned long long g_icp_trace[768 * 16];
-#define XS_STAMP(i) do { if (threadIdx.x == 0) g_icp_trace[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define XS_STAMP(i) do { if (threadIdx.x == 0) { g_icp_trace[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    if ((i) == 0) g_icp_trace[blockIdx.x * 16 + 10] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | __builtin_amdgcn_s_getreg(0xF804); } } while (0)
 extern "C" int xs_debug_icp_trace(unsigned long long *out_host) {
     return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_icp_trace), sizeof(g_icp_trace));
 }
@@ -419,23 +420,23 @@ __global__ void __launch_bounds__(64 * WAVES)
         return;
     }
     if (threadIdx.x < NP / 2) {
-        // one 16-byte store per lane (a record is 28 of them; the pad entry is written as zero).  Plain
-        // stores: the agent-scope release below carries them out of this XCD's L2.
-        struct alignas(16) d2 { double x, y; };
+        // The record: 28 lanes of wave 0 store two doubles each (the pad entry is written as zero) with agent-scope
+        // write-through stores — they go through this XCD's L2 to memory on their own, so nothing is left for a write-back of
+        // the whole L2 (what an agent-scope release fence does here: 0.6 us when one workgroup does it, up to 3 us when
+        // six hundred do).
         const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
-        d2 v;
-        v.x = wave_order_sum<WAVES>(smem, k0);
-        v.y = k1 <= NS ? wave_order_sum<WAVES>(smem, k1) : 0.0;
-        reinterpret_cast<d2 *>(a.partials)[(size_t)blockIdx.x * (NP / 2) + threadIdx.x] = v;
+        double *rec = a.partials + (size_t)blockIdx.x * NP;
+        __hip_atomic_store(rec + k0, wave_order_sum<WAVES>(smem, k0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + k1, k1 <= NS ? wave_order_sum<WAVES>(smem, k1) : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // publish: every storing wave drains its stores, the workgroup meets, one lane takes a ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    XS_STAMP(4);
+    // publish: the storing wave waits until its write-through stores are acknowledged, then its first lane takes a ticket
+    // (same wave, program order: no barrier in between); the atomic is performed at agent scope after the records are in memory
     __shared__ unsigned s_last;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x < 64) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XS_STAMP(4);
+    }
+    if (threadIdx.x == 0) {
         XS_STAMP(5);
         const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == gridDim.x - 1) ? 1u : 0u;
@@ -454,7 +455,8 @@ __global__ void __launch_bounds__(64 * WAVES)
         // come from memory (other XCDs wrote them), so the sum is latency-bound: a record is 28 16-byte
         // chunks; thread (g, q) adds chunk q of records g, g+9, g+18, ... in that order with 32 loads in
         // flight, and the row groups are then added in group order — a fixed association, so
-        // deterministic — leaving two or three memory round trips where a plain loop had sixteen.
+        // deterministic — leaving two or three memory round trips where a plain loop had sixteen.  (Level 0's 600 records
+        // are 269 KB through one CU's 64 B / clk: ~1.8 us of the 3.4 us this takes is that, whatever the depth.)
         struct alignas(16) d2 { double x, y; };
         // (eight waves: twice the threads, so eighteen row groups with sixteen loads each in flight — the same bytes in
         // flight per workgroup at half the registers per lane, which is what lets this instance run at four waves per SIMD)
