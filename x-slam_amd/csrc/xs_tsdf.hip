@@ -224,12 +224,18 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Voxe
     const int coo_y = __float2int_rd(o.image_y.re - 0.5f);
     if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return false;
     const int near_x = __float2int_rn(o.image_x.re), near_y = __float2int_rn(o.image_y.re);
-    cfloat Dp(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
+    cfloat Dp;
     if (BILINEAR) {
-        const float d00 = row_ptr(a.depth, a.dstep, coo_y)[coo_x];
-        const float d10 = row_ptr(a.depth, a.dstep, coo_y)[coo_x + 1];
-        const float d01 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x];
-        const float d11 = row_ptr(a.depth, a.dstep, coo_y + 1)[coo_x + 1];
+        // the four corners as two 8-byte loads (the pair (coo_x, coo_x + 1) is contiguous; 4-byte alignment is all a
+        // global load needs); the nearest pixel is always one of them — coo = floor(image - 0.5), so rn(image) is coo or
+        // coo + 1 on each axis (ties included) — and is picked from the registers instead of being gathered a fifth time:
+        // two address-unit trips per voxel where there were five
+        struct __attribute__((packed, aligned(4))) pair { float a, b; };
+        const pair r0 = *reinterpret_cast<const pair *>(row_ptr(a.depth, a.dstep, coo_y) + coo_x);
+        const pair r1 = *reinterpret_cast<const pair *>(row_ptr(a.depth, a.dstep, coo_y + 1) + coo_x);
+        const float d00 = r0.a, d10 = r0.b, d01 = r1.a, d11 = r1.b;
+        const float n0 = near_x == coo_x ? d00 : d10, n1 = near_x == coo_x ? d01 : d11;
+        Dp = cfloat(near_y == coo_y ? n0 : n1, 0.0f);
         const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
         const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
         if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
@@ -239,6 +245,7 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Voxe
             Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
         }
     }
+    else Dp = cfloat(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
     o.Dp = Dp;
     return Dp.re > 0;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
 }
@@ -404,13 +411,20 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
     const float far = far_limit(a);
+    // The column clip's 20 plane scalars are used once per brick, outside the voxel loop.  Held in scalar registers for the
+    // whole kernel they push the voxel loop's own operands out (99 spilled scalars, ~30 v_readlane per voxel to fetch them
+    // back — VALU slots, and this kernel is bound by VALU issue: 101 M wave instructions per S2 launch): they live in LDS.
+    __shared__ ClipPlanes s_cp;
+    if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4))
+        reinterpret_cast<float *>(&s_cp)[threadIdx.x] = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
+    __syncthreads();
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
         const int b = a.brick_list[e];
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int x = bx * BRICK_X + threadIdx.x, y = by * BRICK_Y + threadIdx.y;
         if (x < a.X && y < a.Y) {
             int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
-            clip_column(a.cp, far, x, y, zb, ze);
+            clip_column(s_cp, far, x, y, zb, ze);
             if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
         }
     }
@@ -637,11 +651,12 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
         const double s = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
         __hip_atomic_store(&partials[(size_t)bid * STRIDE + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // The record went out with agent-scope write-through stores from lanes of wave 0 (NV <= 64): once they are acknowledged the
+    // record is in memory, and the same wave's first lane takes the ticket — no release fence, whose write-back of the whole
+    // L2 per workgroup is what used to cap the grid at 1024 workgroups (xs_icp.hip has the measurements)
+    static_assert(NV <= 64, "the record is stored by one wave");
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == nblocks - 1) ? 1u : 0u;
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -929,7 +944,7 @@ __global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, con
     block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out);
 }
 
-enum { XS_TSDF_REDUCE_MAX_BLOCKS = 1024 };  // workgroups per launch (they stride over the tiles); records of up to 32 doubles
+enum { XS_TSDF_REDUCE_MAX_BLOCKS = 4096 };  // workgroups per launch (they stride over the tiles); records of up to 32 doubles
 extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_REDUCE_MAX_BLOCKS * 32 * sizeof(double) + 256; }
 
 static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
@@ -944,14 +959,21 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     a.gt = gt; a.ticket = (unsigned *)workspace; a.partials = (double *)((char *)workspace + 256); a.out = out_dev;
     // One column per lane.  (Four columns per lane with 16-byte reads streamed no faster and made the Hessian
     // kernel slower: four times the band voxels per lane, worse balance.)  Tiles of 64 x 4 columns x zchunk
-    // planes; at most 1024 workgroups stride over them — with 4096 workgroups the per-workgroup L2 write-back
-    // of the release fence halved the streaming rate (2.3 instead of 4.6 TB/s at 512^3).
+    // planes; the workgroups stride over them.  (While every workgroup paid an L2 write-back for its record, 4096 of them
+    // halved the streaming rate against 1024; the records now leave with write-through stores: block_fold_and_finish.)
+    static const int env_blocks = getenv("XS_HESS_BLOCKS") ? atoi(getenv("XS_HESS_BLOCKS")) : 0;  // tuning aid
     int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
-    while ((long long)gx * gy * zsplit < 1024 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
+    // one workgroup per column of tiles while that gives 1024 .. 4096 of them (512^3: 1024, 1024^3: 4096 — measured best:
+    // the Gauss-Newton pass at 1024^3 runs 15 % faster with 4096 workgroups walking one column each than with 1024 walking
+    // four); fewer columns are split along z, more are strided over
+    const long long cols_xy = (long long)gx * gy;
+    const int cap = env_blocks > 0 && env_blocks <= XS_TSDF_REDUCE_MAX_BLOCKS ? env_blocks
+                    : (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy));
+    while ((long long)gx * gy * zsplit < cap && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
     a.zchunk = div_up(nz, zsplit);
     a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = div_up(nz, a.zchunk);
     const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.tiles_z;
-    grid = dim3((unsigned)(ntiles < 1024 ? ntiles : 1024));
+    grid = dim3((unsigned)(ntiles < cap ? ntiles : cap));
     if ((long long)grid.x * grid.y * grid.z > XS_TSDF_REDUCE_MAX_BLOCKS) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: volume too large for the reduce workspace");
     XS_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
     return 0;
