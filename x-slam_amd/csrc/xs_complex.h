@@ -121,7 +121,7 @@ template <class T> XS_HD cplx<T> operator/(cplx<T> z, cplx<T> w) {
     T mw = fmax(fabs(w.re), fabs(w.im));
     T mz = fmax(fabs(z.re), fabs(z.im));
     typedef detail::lim<T> L;
-    if (mw >= L::lo() && mw <= L::hi() && mz >= L::lo() && mz <= L::hi()) {
+    if (__builtin_expect(mw >= L::lo() && mw <= L::hi() && mz >= L::lo() && mz <= L::hi(), 1)) {   // (likely: the scaled path is laid out of line)
         T denom = w.re * w.re + w.im * w.im;
         return cplx<T>((z.re * w.re + z.im * w.im) / denom, (z.im * w.re - z.re * w.im) / denom);
     }
@@ -169,7 +169,7 @@ template <class T> XS_HD cplx<T> sqrt_general(cplx<T> x) {
 template <class T> XS_HD cplx<T> sqrt(cplx<T> x) {
     typedef detail::lim<T> L;
     T a = x.re, b = x.im;
-    if (a >= L::lo() && a <= L::hi() && fabs(b) <= a * L::cone()) {
+    if (__builtin_expect(a >= L::lo() && a <= L::hi() && fabs(b) <= a * L::cone(), 1)) {
         T s = detail::xsqrt(a);
         return cplx<T>(s, s * ((b / a) / T(2)));
     }

@@ -45,7 +45,7 @@ __device__ __forceinline__ int cvt_flr(float v) {  // (int)floorf(v) in one inst
 }
 __device__ __forceinline__ int voxel_index(float p, float vs, float r_lo, float r_hi) {
     const int f_lo = cvt_flr(p * r_lo), f_hi = cvt_flr(p * r_hi);
-    if (f_lo == f_hi) return f_lo;
+    if (__builtin_expect(f_lo == f_hi, 1)) return f_lo;
     return __float2int_rd(p / vs);
 }
 
@@ -96,10 +96,30 @@ struct Vol {
         const cfloat c0 = (p.z - (gz + 0.5f) * vs) / vs;
         const cfloat one(1.0f, 0.0f);
         const cfloat a1 = one - a0, b1 = one - b0, c1 = one - c0;
-        return read(gx + 0, gy + 0, gz + 0) * a1 * b1 * c1 + read(gx + 0, gy + 0, gz + 1) * a1 * b1 * c0 +
-               read(gx + 0, gy + 1, gz + 0) * a1 * b0 * c1 + read(gx + 0, gy + 1, gz + 1) * a1 * b0 * c0 +
-               read(gx + 1, gy + 0, gz + 0) * a0 * b1 * c1 + read(gx + 1, gy + 0, gz + 1) * a0 * b1 * c0 +
-               read(gx + 1, gy + 1, gz + 0) * a0 * b0 * c1 + read(gx + 1, gy + 1, gz + 1) * a0 * b0 * c0;
+        // the corners (gx, ·, ·) and (gx + 1, ·, ·) are neighbours in memory: one 8-byte load per array fetches both (a global
+        // load needs 4-byte alignment only) — 8 address-unit trips per sample instead of 16
+        cfloat lo00, hi00, lo01, hi01, lo10, hi10, lo11, hi11;
+        read2(gx, gy + 0, gz + 0, lo00, hi00); read2(gx, gy + 0, gz + 1, lo01, hi01);
+        read2(gx, gy + 1, gz + 0, lo10, hi10); read2(gx, gy + 1, gz + 1, lo11, hi11);
+        return lo00 * a1 * b1 * c1 + lo01 * a1 * b1 * c0 + lo10 * a1 * b0 * c1 + lo11 * a1 * b0 * c0 +
+               hi00 * a0 * b1 * c1 + hi01 * a0 * b1 * c0 + hi10 * a0 * b0 * c1 + hi11 * a0 * b0 * c0;
+    }
+    // read(x, y, z) and read(x + 1, y, z)
+    __device__ __forceinline__ void read2(int x, int y, int z, cfloat &lo, cfloat &hi) const {
+        struct __attribute__((packed, aligned(4))) pair { float a, b; };
+        z = min(max(z, zs0), zs1 - 1);
+        const pair *pv, *pg;
+        if (OFF32) {
+            const unsigned off = offset32(x, y, z);
+            pv = reinterpret_cast<const pair *>(reinterpret_cast<const char *>(value) + off);
+            pg = reinterpret_cast<const pair *>(reinterpret_cast<const char *>(grad) + off);
+        } else {
+            pv = reinterpret_cast<const pair *>(row_ptr(value, vstep, Y * (z - zs0) + y) + x);
+            pg = reinterpret_cast<const pair *>(row_ptr(grad, vstep, Y * (z - zs0) + y) + x);
+        }
+        const pair v = *pv, g = *pg;
+        lo = unpack_tsdf(v.a, g.a); lo += 1e-5f;
+        hi = unpack_tsdf(v.b, g.b); hi += 1e-5f;
     }
 };
 }  // namespace
