@@ -236,6 +236,9 @@ int xs_icp_gate_selftest(const float *z2n_dev, int n, float thres, int or_equal,
  * it, polls `mailbox` — xs_icp_mailbox_bytes() (128) bytes, 64-byte aligned, that the host can write and
  * the device read coherently (xs_icp_mailbox_alloc), zero before first use — and starts on the pixels once xs_icp_post_pose(mailbox, Rcurr18, tcurr6, mailbox_seq, 0)
  * has been called; cmd = 1 makes the launch return without touching anything (the host left the loop).
+ * Several launches may be queued behind one another, with mailbox sequence numbers that increase in launch order (compared
+ * as signed 32-bit distances): each waits for its own number; an abandon command (cmd = 1) posted with a LATER launch's number
+ * releases every queued launch up to that one, so one post empties the queue.
  * A launch whose pose never arrives gives up after about a second and stores done_seq | 1<<63 to
  * done_flag; call xs_icp_workspace_init again after that.  One mailbox serves one stream: post
  * sequence numbers in launch order, each only after the previous launch's sums were consumed. */

@@ -438,6 +438,33 @@ def test_icp_posted_pose_mailbox(dev, oracle, where):
         capi.icp_accumulate(R, tt, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, again)
         torch.cuda.synchronize()
         assert np.array_equal(again.cpu().numpy(), ref.cpu().numpy())
+        # a queue of launches (the orchestrator keeps icp_lookahead of them ahead of the one it waits for): each takes the
+        # post with its own number, in order; then one abandon command carrying the LAST number empties a queue of three
+        outs = [torch.full((55,), 7.0, dtype=torch.float64, device="cuda") for _ in range(3)]
+        evs = [torch.cuda.Event() for _ in range(3)]
+        for i in range(3):
+            capi.icp_accumulate_posted(mailbox, 20 + i, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, outs[i])
+            evs[i].record()
+        time.sleep(0.01)
+        assert not evs[0].query()
+        for i in range(3):   # (no copies from this stream in between: they would queue behind the waiting launches)
+            capi.icp_post_pose(mailbox, R, tt, 20 + i)
+            evs[i].synchronize()
+            if i < 2:
+                time.sleep(0.005)
+                assert not evs[i + 1].query(), "the next launch in the queue waits for its own number"
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), ref.cpu().numpy())
+        outs = [torch.full((55,), 7.0, dtype=torch.float64, device="cuda") for _ in range(3)]
+        for i in range(3):
+            capi.icp_accumulate_posted(mailbox, 30 + i, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, outs[i])
+        capi.icp_post_pose(mailbox, None, None, 32, cmd=1)
+        torch.cuda.synchronize()
+        assert all(np.all(o.cpu().numpy() == 7.0) for o in outs)
+        capi.icp_accumulate(R, tt, dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], W * 8, H, W, 0.10, angle, ws, again)
+        torch.cuda.synchronize()
+        assert np.array_equal(again.cpu().numpy(), ref.cpu().numpy())
     finally:
         torch.cuda.synchronize()
         free()

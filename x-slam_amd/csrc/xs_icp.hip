@@ -216,7 +216,9 @@ __global__ void __launch_bounds__(64 * WAVES)
             for (int polls = 0;; ++polls) {
                 v = __hip_atomic_load(a.mailbox + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
-                if (s0 == a.mailbox_seq && s1 == a.mailbox_seq) break;
+                // this launch's number — or a later one: the host has moved past this launch (an abandon command releases
+                // every launch in the queue with one post: see below)
+                if (s0 == s1 && (int)(s0 - a.mailbox_seq) >= 0) break;
                 if (polls >= MAILBOX_MAX_POLLS) { cmd_override = 2; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -229,8 +231,10 @@ __global__ void __launch_bounds__(64 * WAVES)
             // system-scope and bypass the caches).  The sequence words are checked again on the way.
             if (!cmd_override) {
                 v = __hip_atomic_load(a.mailbox + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
-                if (s0 != a.mailbox_seq || s1 != a.mailbox_seq) cmd_override = 2;   // the host broke the one-post-per-launch contract
+                const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 1);
+                if (s0 == a.mailbox_seq && s1 == a.mailbox_seq) { /* this launch's post: pose or command as posted */ }
+                else if (s0 == s1 && (int)(s0 - a.mailbox_seq) > 0 && c == 1) cmd_override = 1;   // abandon, addressed to a later launch: leave too
+                else cmd_override = 2;   // the host broke the one-post-per-launch contract
             }
             if (threadIdx.x < MAILBOX_WORDS) s_mail[threadIdx.x] = threadIdx.x == 1 && cmd_override ? cmd_override : v;
         }

@@ -85,6 +85,7 @@ public:
     // order).  Applies when this rank evaluates whole images (not with icp_shard_rows).  YAML key
     // icp_post_pose.
     bool icp_post_pose = true;
+    int icp_lookahead = 1;   // posted launches kept in the queue ahead of the one the host waits for (>= 1; more measured the same)
     // The final addition of an ICP reduction on the host (xs_icp_accumulate_records / xs_icp_sum_records): every
     // workgroup writes its record of 55 partial sums straight into pinned host memory and leaves; the host — which is
     // spinning for the result anyway — adds the records in index order.  Takes the cross-XCD gather (write-back, ticket,
