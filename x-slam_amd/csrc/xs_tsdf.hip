@@ -102,7 +102,10 @@ extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows
 // ------------------------------------------------------------------------------------------
 // Brick geometry: 64 (x) x 4 (y) x 8 (z) voxels = one 256-thread workgroup, lane = x, so every
 // volume access of a wave is one 256-byte row segment.
-enum { BRICK_X = 64, BRICK_Y = 4, BRICK_Z = 8 };
+#ifndef XS_BRICK_X
+#define XS_BRICK_X 32
+#endif
+enum { BRICK_X = XS_BRICK_X, BRICK_Y = 4 * (64 / XS_BRICK_X), BRICK_Z = 8 };   // a wave covers BRICK_X columns x 64 / BRICK_X rows
 
 // Half-spaces of the (padded) view frustum in the volume's voxel-index space, built on the
 // host and passed as kernel arguments (wave-uniform: they live in scalar registers).  Along any
@@ -382,7 +385,9 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
 // ---- path 2: brick work list ------------------------------------------------------------------
 // Phase A: one thread per brick tests it against the padded frustum (and the far limit) and
 // appends survivors to a list — a wave ballots, one atomic per wave.  Phase B: resident
-// workgroups stride over the list; each handles one 64x4x8 brick.  The voxels that can be
+// workgroups stride over the list; each handles one 32x8x8 brick (a wave: 32 columns x 2 rows — 128-byte row segments;
+// 64x4 bricks list 15 % more of them on the benchmark scene, 2 224 against 1 892, i.e. more than the 2 048 resident workgroups,
+// and 16x16 ones stream a quarter slower: profiles/tools/ab_brick_shape.sh).  The voxels that can be
 // written (a few % of an ICL-like volume) are thereby spread over every CU instead of being
 // concentrated in the few columns that cross the frustum.
 __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) {
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
         const int b = a.brick_list[e];
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
-        const int x = bx * BRICK_X + threadIdx.x, y = by * BRICK_Y + threadIdx.y;
+        const int x = bx * BRICK_X + (int)(threadIdx.x % BRICK_X), y = by * BRICK_Y + (int)threadIdx.y * (64 / BRICK_X) + (int)(threadIdx.x / BRICK_X);
         if (x < a.X && y < a.Y) {
             int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
             clip_column(s_cp, far, x, y, zb, ze);
