@@ -5,12 +5,12 @@
 // Reference shape: one pixel per thread, 27 complex products each pushed through an LDS tree
 // (27 x 2 barriers + 8 steps), 518 KB of per-block partials, and a second 27-block launch to
 // add them up; the tree's tail relies on 32-wide warp-synchronous execution (ICP.cu:40-65).
-// Here: each lane owns a strip of pixels and keeps the 27 complex sums (54 doubles) in
-// registers — products in complex float, accumulation in double, as the reference
-// (ICP.cu:273-274).  A wave folds its 64 lanes with cross-lane shuffles, the four waves of a
-// workgroup meet once in LDS, and the workgroup writes one 54-double partial.  The last
-// workgroup to arrive (agent-scope ticket) adds the partials in index order, so the result is
-// deterministic and there is no second launch.
+// Here: one 64-pixel tile per wave, eight waves per workgroup (every level of a 640 x 480 frame; larger images fall back to four
+// waves striding over the tiles with the sums in registers).  The 27 complex products of a pixel (complex float, ICP.cu:273) go
+// to an LDS tile as floats and are added there in double — lanes in a fixed interleaved order, then the waves in order — as the
+// reference accumulates in double (ICP.cu:274); the workgroup writes one 448-byte record with write-through stores and takes a
+// ticket; the last workgroup to arrive adds the records in a fixed order, so the result is deterministic and there is no
+// second launch.  How each phase was measured: profiles/tools/trace_icp.sh, profiles/r02_icp_phases.txt.
 #include <string.h>
 #include "xs_device.h"
 #include "xs_icp_solve.h"
@@ -162,14 +162,12 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 #else
 #define XS_ICP_OCC
 #endif
-// WAVES = 4: lanes stride over the tiles and carry the 27 complex sums in registers (54 doubles: two waves per SIMD) — any
-// image size.  WAVES = 8: one tile per wave, chosen whenever the image has few enough tiles (a 640 x 480 level 0 has 4 800):
-// nothing is carried from tile to tile, so the products go straight from the row to the LDS fold as floats, the kernel needs
-// half the registers and runs at four waves per SIMD with every tile resident at once (the pixel loop is latency-bound:
-// profiles/r02_icp_occupancy.txt), and a launch writes an eighth as many records as it has tiles instead of a quarter.
-// PASSES (eight-wave instance only): the LDS fold takes the 55 values in two passes of 28 (70 KB per workgroup: two workgroups
-// per CU, 105 VGPRs, four waves per SIMD — up to 512 workgroups resident: levels 1 and 2) or in three of 19 (51 KB: three per CU
-// at six waves per SIMD, i.e. 85 VGPRs, which costs three spilled registers — up to 768 resident: level 0's 600).
+// WAVES = 4: lanes stride over the tiles and carry the 27 complex sums in registers (54 doubles, 190 VGPRs: two waves per SIMD) —
+// any image size.  WAVES = 8: one tile per wave, chosen whenever all tiles can be resident at once (a 640 x 480 level 0 has
+// 4 800): nothing is carried from tile to tile, so the products go straight from the row to the LDS fold as floats and the kernel
+// needs 80-104 registers.  PASSES: the LDS tile holds all 55 values of the eight waves at once (123 KB: one workgroup per CU —
+// launches of up to 256 workgroups: levels 1 and 2), 28 in two passes (64 KB, two per CU at four waves per SIMD, up to 512) or 19
+// in three (45 KB, three per CU at six waves per SIMD, 80 VGPRs: up to 768 — level 0's 600).
 template <int POSE_SRC, int WAVES, int PASSES>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu(WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6))))
