@@ -186,15 +186,17 @@ def test_device_pose_solve_matches_host_solve(dev):
     a.close(); b.close()
 
 
-def test_posted_pose_loop_is_bit_identical_to_launch_after_solve(dev):
-    """icp_post_pose (default: every iteration's launch enqueued before its pose is known, pose delivered
+@pytest.mark.parametrize("lookahead", [1, 4])
+def test_posted_pose_loop_is_bit_identical_to_launch_after_solve(dev, lookahead):
+    """icp_post_pose (default: every iteration's launch enqueued before its pose is known — one launch ahead, or a
+    queue of icp_lookahead of them, which a lost frame's abandon command must empty in one post —, pose delivered
     through the BAR mailbox) against the reference's order (launch after the solve): the same kernel
     arithmetic on the same inputs — every sum of every iteration, every pose and the volume must be the
     same bits; and the frame after a lost frame (all-zero depth: no inliers, singular system, ProcessFrame
     returns 0 while a posted launch is still in flight) is processed normally."""
     torch, pl = dev
     prm = synth.s1_params(96)
-    a = pl.KinectFusion(dict(prm, icp_post_pose=True))
+    a = pl.KinectFusion(dict(prm, icp_post_pose=True, icp_lookahead=lookahead))
     b = pl.KinectFusion(dict(prm, icp_post_pose=False))
     for k in range(5):
         d = upload(torch, synth.s1_frame(k))
