@@ -104,6 +104,42 @@ struct Vol {
         return lo00 * a1 * b1 * c1 + lo01 * a1 * b1 * c0 + lo10 * a1 * b0 * c1 + lo11 * a1 * b0 * c0 +
                hi00 * a0 * b1 * c1 + hi01 * a0 * b1 * c0 + hi10 * a0 * b0 * c1 + hi11 * a0 * b0 * c0;
     }
+    // Two samples at once: both cells are located first, then the sixteen 8-byte loads of the two go out together and the
+    // two blends follow — one memory round trip where two calls of interp() make two (the crossing kernel is a chain of
+    // eight dependent samples per pixel: Ft / Ftdt, then the three central differences of the normal).  Same values as
+    // interp(p), interp(q): a sample outside [1, N-2] is NaN; its loads go to a resident cell instead and are not used.
+    struct Cell { int gx, gy, gz; bool ok; cfloat a0, b0, c0; };
+    __device__ __forceinline__ Cell locate(const cfloat3 &p) const {
+        Cell c;
+        int gx = __float2int_rd(p.x.re / vs), gy = __float2int_rd(p.y.re / vs), gz = __float2int_rd(p.z.re / vs);
+        c.ok = !(gx <= 0 || gx >= X - 1) && !(gy <= 0 || gy >= Y - 1) && !(gz <= 0 || gz >= Z - 1);
+        const float vx = (gx + 0.5f) * vs, vy = (gy + 0.5f) * vs, vz = (gz + 0.5f) * vs;
+        gx += -(sgn(vx - p.x.re) + 1) >> 1;
+        gy += -(sgn(vy - p.y.re) + 1) >> 1;
+        gz += -(sgn(vz - p.z.re) + 1) >> 1;
+        c.a0 = (p.x - (gx + 0.5f) * vs) / vs;
+        c.b0 = (p.y - (gy + 0.5f) * vs) / vs;
+        c.c0 = (p.z - (gz + 0.5f) * vs) / vs;
+        c.gx = c.ok ? gx : 0; c.gy = c.ok ? gy : 0; c.gz = c.ok ? gz : zs0;
+        return c;
+    }
+    __device__ __forceinline__ cfloat blend(const Cell &c, const cfloat (&lo)[4], const cfloat (&hi)[4]) const {
+        const cfloat one(1.0f, 0.0f);
+        const cfloat a1 = one - c.a0, b1 = one - c.b0, c1 = one - c.c0;
+        const cfloat r = lo[0] * a1 * b1 * c1 + lo[1] * a1 * b1 * c.c0 + lo[2] * a1 * c.b0 * c1 + lo[3] * a1 * c.b0 * c.c0 +
+                         hi[0] * c.a0 * b1 * c1 + hi[1] * c.a0 * b1 * c.c0 + hi[2] * c.a0 * c.b0 * c1 + hi[3] * c.a0 * c.b0 * c.c0;
+        return c.ok ? r : cfloat(qnan_f(), 0.f);
+    }
+    __device__ __forceinline__ void interp2(const cfloat3 &p, const cfloat3 &q, cfloat &Fp, cfloat &Fq) const {
+        const Cell cp = locate(p), cq = locate(q);
+        cfloat lp[4], hp[4], lq[4], hq[4];
+        read2(cp.gx, cp.gy + 0, cp.gz + 0, lp[0], hp[0]); read2(cp.gx, cp.gy + 0, cp.gz + 1, lp[1], hp[1]);
+        read2(cp.gx, cp.gy + 1, cp.gz + 0, lp[2], hp[2]); read2(cp.gx, cp.gy + 1, cp.gz + 1, lp[3], hp[3]);
+        read2(cq.gx, cq.gy + 0, cq.gz + 0, lq[0], hq[0]); read2(cq.gx, cq.gy + 0, cq.gz + 1, lq[1], hq[1]);
+        read2(cq.gx, cq.gy + 1, cq.gz + 0, lq[2], hq[2]); read2(cq.gx, cq.gy + 1, cq.gz + 1, lq[3], hq[3]);
+        Fp = blend(cp, lp, hp);
+        Fq = blend(cq, lq, hq);
+    }
     // read(x, y, z) and read(x + 1, y, z)
     __device__ __forceinline__ void read2(int x, int y, int z, cfloat &lo, cfloat &hi) const {
         struct __attribute__((packed, aligned(4))) pair { float a, b; };
@@ -128,8 +164,11 @@ struct Vol {
 // time; 3: crossing only (trilinear samples, vertex, normal) for the pixels MODE 2 marked; 4 / 5: the slab march and
 // the slab crossing as two kernels (what xs_raycast_slab launches: the march then runs at eight waves per SIMD with
 // eight gathers in flight, like MODE 2).
+// (crossing kernels: five waves per SIMD — a 640 x 480 frame is 4 800 waves on 1 024 SIMDs, all resident at once; the
+// two-samples-per-round-trip form would otherwise take 104 registers, i.e. four)
+constexpr int raycast_min_waves(int mode) { return mode == 3 || mode == 5 ? 5 : 1; }
 template <int MODE, bool OFF32>
-__global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycast_min_waves(MODE)))) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1 || MODE == 4 || MODE == 5;
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
     // round-robin over the 8 XCDs (each with its own 4 MB L2): the linear id is remapped so that
@@ -180,10 +219,16 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
         gx = max(0, min(gx, a.X - 1)); gy = max(0, min(gy, a.Y - 1)); gz = max(0, min(gz, a.Z - 1));
         // zero crossing between time_curr and tn (RayCaster.cu:247-306): returns 1 if a vertex was written
         auto crossing = [&](float tc, float tn) -> int {
-            const cfloat Ftdt = vol.interp(ray_start + ray_dir * tn);
-            if (isnan(Ftdt.re)) return 0;
-            const cfloat Ft = vol.interp(ray_start + ray_dir * tc);
-            if (isnan(Ft.re)) return 0;
+            cfloat Ftdt, Ft;
+            if (MODE == 3 || MODE == 5) {   // the crossing kernels: both samples in one round trip
+                vol.interp2(ray_start + ray_dir * tn, ray_start + ray_dir * tc, Ftdt, Ft);
+                if (isnan(Ftdt.re) || isnan(Ft.re)) return 0;
+            } else {
+                Ftdt = vol.interp(ray_start + ray_dir * tn);
+                if (isnan(Ftdt.re)) return 0;
+                Ft = vol.interp(ray_start + ray_dir * tc);
+                if (isnan(Ft.re)) return 0;
+            }
             const cfloat coef = Ft / (Ftdt - Ft);
             if (Ft.re < 0.0f || Ftdt.re > 0.0f) return 0;
             const cfloat Ts = tc - time_step * coef;
@@ -199,6 +244,17 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
             if (vx > 1 && vy > 1 && vz > 1 && vx < a.X - 2 && vy < a.Y - 2 && vz < a.Z - 2) {
                 cfloat3 t, n;
                 const float half = vs * 0.5f;
+                if (MODE == 3 || MODE == 5) {
+                    cfloat3 u;
+                    cfloat F1, F2;
+                    // (one pair at a time: left to itself the scheduler issues all 48 loads of the six samples at once and
+                    // keeps their 96 values and 36 weights live — 284 registers, one wave per SIMD)
+                    t = vertex_found; t.x += half; u = vertex_found; u.x -= half; vol.interp2(t, u, F1, F2); n.x = F1 - F2;
+                    asm volatile("" : "+v"(n.x.re), "+v"(n.x.im) :: "memory");
+                    t = vertex_found; t.y += half; u = vertex_found; u.y -= half; vol.interp2(t, u, F1, F2); n.y = F1 - F2;
+                    asm volatile("" : "+v"(n.y.re), "+v"(n.y.im) :: "memory");
+                    t = vertex_found; t.z += half; u = vertex_found; u.z -= half; vol.interp2(t, u, F1, F2); n.z = F1 - F2;
+                } else {
                 t = vertex_found; t.x += half; const cfloat Fx1 = vol.interp(t);
                 t = vertex_found; t.x -= half; const cfloat Fx2 = vol.interp(t);
                 n.x = Fx1 - Fx2;
@@ -208,6 +264,7 @@ __global__ void __launch_bounds__(256) k_raycast(const RaycastArgs a) {
                 t = vertex_found; t.z += half; const cfloat Fz1 = vol.interp(t);
                 t = vertex_found; t.z -= half; const cfloat Fz2 = vol.interp(t);
                 n.z = Fz1 - Fz2;
+                }
                 if (squarednorm(n).re == 0) return 1;
                 const cfloat3 n_g = a.Rv2w * normalized(n);
                 row_ptr(a.nmap, a.mstep, y)[x] = n_g.x;
