@@ -47,15 +47,21 @@ namespace {
 // ICP.cu:196-244
 // the six current-frame values of a pixel: they depend on nothing but the pixel, so the one-tile-per-wave instance requests them
 // before it even has its pose (a posted launch spends ~3 us waiting for it)
-__device__ __forceinline__ void load_current(const IcpArgs &a, int x, int y, cfloat3 &ncurr, cfloat3 &vcurr) {
-    // all six are requested before the sentinel is looked at (the y / z planes of an invalid pixel are allocated, merely
+__device__ __forceinline__ void load_vertex(const IcpArgs &a, int x, int y, cfloat3 &vcurr) {
+    vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
+    vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
+    vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
+}
+__device__ __forceinline__ void load_normal(const IcpArgs &a, int x, int y, cfloat3 &ncurr) {
+    // all three are requested before the sentinel is looked at (the y / z planes of an invalid pixel are allocated, merely
     // unused): one memory round trip instead of two
     ncurr.x = row_ptr(a.nmap_curr, a.mstep, y)[x];
     ncurr.y = row_ptr(a.nmap_curr, a.mstep, y + a.rows)[x];
     ncurr.z = row_ptr(a.nmap_curr, a.mstep, y + 2 * a.rows)[x];
-    vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
-    vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
-    vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
+}
+__device__ __forceinline__ void load_current(const IcpArgs &a, int x, int y, cfloat3 &ncurr, cfloat3 &vcurr) {
+    load_normal(a, x, y, ncurr);
+    load_vertex(a, x, y, vcurr);
 }
 // The two gates of ICP.cu:232-241 compare the REAL part of a complex square root with a threshold and use nothing else of
 // it.  For z = a + ib, Re sqrt z = sqrt((|z| + a) / 2) lies in [sqrt(max(a, 0)), sqrt(|a| + |b|)], and the float sequence
@@ -90,6 +96,36 @@ __device__ __forceinline__ bool search_loaded(const IcpArgs &a, const MatS33 &Rc
     vprev_g.x = row_ptr(a.vmap_g_prev, a.mstep, uy)[ux];
     vprev_g.y = row_ptr(a.vmap_g_prev, a.mstep, uy + a.rows)[ux];
     vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    if (isnan(nprev_g.x.re)) return false;
+    if (re_sqrt_exceeds(squarednorm(vprev_g - vcurr_g), a.distThres, false)) return false;   // norm(...).re > distThres
+    const cfloat3 ncurr_g = Rcurr * ncurr;
+    if (re_sqrt_exceeds(squarednorm(cross(ncurr_g, nprev_g)), a.angleThres, true)) return false;   // norm(...).re >= angleThres
+    n = nprev_g; d = vprev_g; s = vcurr_g;
+    return true;
+}
+// The same search for a wave that already holds its pixel's vertex (requested before the pose was known): the three normal
+// values are requested here, and their sentinel is looked at only after the model-map gather — they are not needed before,
+// and asking for them up front with the vertices doubled the burst of requests (14.7 MB at level 0) that the workgroups'
+// mailbox polls then queued behind.  Same outcome for every pixel: the gate only moves past statements without side effects
+// (a NaN vertex converts to pixel (0, 0), which is in range).
+__device__ __forceinline__ bool search_vertex_loaded(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, const cfloat3 &vcurr,
+                                                     cfloat3 &n, cfloat3 &d, cfloat3 &s) {
+    cfloat3 ncurr;
+    load_normal(a, x, y, ncurr);
+    const cfloat3 vcurr_g = Rcurr * vcurr + tcurr;
+    const cfloat3 vcp = a.Rprev_inv * (vcurr_g - a.tprev);
+    const float cpx = vcp.x.re, cpy = vcp.y.re, cpz = vcp.z.re;
+    const int ux = __float2int_rn(cpx * a.intr.fx / cpz + a.intr.cx);
+    const int uy = __float2int_rn(cpy * a.intr.fy / cpz + a.intr.cy);
+    if (ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || cpz < 0) return false;
+    cfloat3 nprev_g, vprev_g;
+    nprev_g.x = row_ptr(a.nmap_g_prev, a.mstep, uy)[ux];
+    nprev_g.y = row_ptr(a.nmap_g_prev, a.mstep, uy + a.rows)[ux];
+    nprev_g.z = row_ptr(a.nmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    vprev_g.x = row_ptr(a.vmap_g_prev, a.mstep, uy)[ux];
+    vprev_g.y = row_ptr(a.vmap_g_prev, a.mstep, uy + a.rows)[ux];
+    vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    if (isnan(ncurr.x.re)) return false;      // ICP.cu:202-204
     if (isnan(nprev_g.x.re)) return false;
     if (re_sqrt_exceeds(squarednorm(vprev_g - vcurr_g), a.distThres, false)) return false;   // norm(...).re > distThres
     const cfloat3 ncurr_g = Rcurr * ncurr;
@@ -173,16 +209,20 @@ __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu(WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6))))
     k_icp(const IcpArgs a) {
     XS_STAMP(0);
-    // one tile per wave: the tile's current-frame values are on their way before the pose is (a pixel outside the image reads
+    // one tile per wave: the tile's current-frame vertices are on their way before the pose is (a pixel outside the image reads
     // pixel (0, y0): resident, never used)
-    cfloat3 pre_n, pre_v;
+    cfloat3 pre_v;
     bool pre_ok = false;
+    int pre_x = 0, pre_y = a.y0;
     if constexpr (WAVES == 8) {
         const int tiles_x0 = (a.cols + 63) / 64;
         const int t0 = blockIdx.x * 8 + (threadIdx.x >> 6);
         const int y = a.y0 + t0 / tiles_x0, x = (t0 % tiles_x0) * 64 + (threadIdx.x & 63);
         pre_ok = t0 < tiles_x0 * (a.y1 - a.y0) && x < a.cols;
-        load_current(a, pre_ok ? x : 0, pre_ok ? y : a.y0, pre_n, pre_v);
+        if (pre_ok) { pre_x = x; pre_y = y; }
+#ifndef XS_ICP_NO_PREFETCH
+        load_vertex(a, pre_x, pre_y, pre_v);
+#endif
     }
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
@@ -327,7 +367,10 @@ __global__ void __launch_bounds__(64 * WAVES)
     {
         bool ok = false;
         cfloat3 n, d, s;
-        if (pre_ok) ok = search_loaded(a, Rcurr, tcurr, pre_n, pre_v, n, d, s);
+#ifdef XS_ICP_NO_PREFETCH
+        load_vertex(a, pre_x, pre_y, pre_v);
+#endif
+        if (pre_ok) ok = search_vertex_loaded(a, Rcurr, tcurr, pre_x, pre_y, pre_v, n, d, s);
         if (ok) {
             const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
             row[0] = cr.x; row[1] = cr.y; row[2] = cr.z;
