@@ -283,6 +283,43 @@ def test_icp_normal_equations(dev, oracle, level):
     assert np.array_equal(A, A2) and np.array_equal(b, b2)
 
 
+@pytest.mark.parametrize("shape", ["crop_150x200", "double_960x1280"])
+def test_icp_other_image_sizes(dev, oracle, shape):
+    """The reduction kernel away from 640 x 480: a ragged crop (200 columns = three full 64-pixel tiles and one of eight
+    lanes; 600 tiles: the single-pass eight-wave instance) and a frame of twice the size (19 200 tiles: more than can be
+    resident, i.e. the four-wave instance that strides over the tiles with its sums in registers) against the oracle."""
+    torch, capi = dev
+    prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
+    k = np.asarray(intr_of(prm), np.float32).copy()
+    planes = lambda m: m.reshape(3, H, W, 2)
+    if shape.startswith("crop"):
+        rows, cols = 150, 200
+        f = lambda m: np.ascontiguousarray(planes(m)[:, :rows, :cols]).reshape(3 * rows, cols, 2)
+    else:
+        rows, cols = 2 * H, 2 * W
+        f = lambda m: np.ascontiguousarray(np.repeat(np.repeat(planes(m), 2, axis=1), 2, axis=2)).reshape(3 * rows, cols, 2)
+        k = (k * 2).astype(np.float32)
+    cv, cn, pv, pn = f(cv), f(cn), f(pv), f(pn)
+    Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    osum, oA, ob, oinl = oracle.icp_combined(T0["Rc2w"], T0["tc2w"], cv, cn, Rprev_inv, T0["tc2w"], k, pv, pn, 0.10, angle)
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    sums = torch.zeros(55, dtype=torch.float64, device="cuda")
+    A, b, inl = capi.estimate_combined(T0["Rc2w"], T0["tc2w"], to_dev(torch, cv), to_dev(torch, cn), Rprev_inv, T0["tc2w"], k,
+                                       to_dev(torch, pv), to_dev(torch, pn), cols * 8, rows, cols, 0.10, angle, ws, sums)
+    assert oinl > 0.3 * rows * cols
+    assert abs(inl - oinl) <= max(2, 2e-5 * oinl)
+    s_ = sums.cpu().numpy()[:54]
+    assert np.all(np.abs(s_[0::2] - osum[0::2]) <= 1e-6 * np.abs(osum[0::2]).max())
+    assert np.abs(osum[1::2]).max() > 0
+    assert np.all(np.abs(s_[1::2] - osum[1::2]) <= 1e-6 * np.abs(osum[1::2]).max())
+    assert np.allclose(A, oA, rtol=0, atol=1e-6 * np.abs(oA).max()) and np.allclose(b, ob, rtol=0, atol=1e-6 * np.abs(ob).max())
+    A2, b2, _ = capi.estimate_combined(T0["Rc2w"], T0["tc2w"], to_dev(torch, cv), to_dev(torch, cn), Rprev_inv, T0["tc2w"], k,
+                                       to_dev(torch, pv), to_dev(torch, pn), cols * 8, rows, cols, 0.10, angle, ws, sums)
+    assert np.array_equal(A, A2) and np.array_equal(b, b2)
+    assert capi.icp_records_count(cols, 0, rows) == (75 if shape.startswith("crop") else 512)
+
+
 def test_icp_row_shards_add_up(dev, oracle):
     """Pixel rows sharded across GPUs: per-shard sums add to the whole (the 432-byte all-reduce)."""
     torch, capi = dev
