@@ -115,6 +115,23 @@ def test_integrate_far_clip_changes_nothing(dev, oracle, n, threshold):
     compare(b, run_cpu(oracle, prm, [0, 5, 9], res, threshold=threshold))
 
 
+def test_integrate_non_cubic_pitched_volume(dev, oracle):
+    """A volume of 96 x 64 x 80 voxels in rows of 112 (a pitch wider than the row): the column walk, the brick list with
+    the far clip, and the same over three z-slabs — against the oracle and against each other."""
+    torch, capi = dev
+    prm = synth.s1_params(96)
+    res = [96, 64, 80]
+    cpu = run_cpu(oracle, prm, [0, 3, 6], res)
+    a = run_gpu(torch, capi, prm, [0, 3, 6], res, pitch_elems=112)
+    compare(a, cpu)
+    for kw in (dict(far_clip=True, bricks=True), dict(far_clip=True, bricks=True, slabs=3)):
+        b = run_gpu(torch, capi, prm, [0, 3, 6], res, pitch_elems=112, **kw)
+        for u, v in zip(a[:3], b[:3]):
+            assert np.array_equal(u, v), kw
+        assert a[3] == b[3], kw
+    assert cpu[3][-1] > 1000
+
+
 def test_integrate_rotated_and_inside_out_views(dev, oracle):
     """Column clipping under strong rotations (every sign of the half-space slopes), a camera
     outside the volume and a view from the far side."""

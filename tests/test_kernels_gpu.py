@@ -232,6 +232,39 @@ def test_raycast_empty_volume(dev, oracle):
     assert np.isnan(vm.cpu().numpy()[:H, :, 0]).all() and np.isnan(nm.cpu().numpy()[:H, :, 0]).all()
 
 
+def test_raycast_non_cubic_pitched_volume(dev, oracle):
+    """Raycast through a 96 x 64 x 80 volume stored in rows of 112 floats: hit set, vertices and normals against the oracle."""
+    torch, capi = dev
+    prm = synth.s1_params(96)
+    res = [96, 64, 80]
+    v, w, g = oracle.new_volume(res)
+    for k in (0, 1):
+        T = s1_transforms(k, prm)
+        oracle.integrate(oracle.scale_depth(synth.s1_frame(k)), v, w, g, res, tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm),
+                         prm["tsdf_voxel_size"])
+    T = s1_transforms(2, prm)
+    ov, on, ohits = oracle.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], v, g, H, W)
+    pad = lambda a: np.ascontiguousarray(np.pad(a.reshape(res[2] * res[1], res[0]), ((0, 0), (0, 16)), constant_values=9.0))
+    vm = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    nm = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    hits = torch.zeros(1, dtype=torch.int64, device="cuda")
+    capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"],
+                 to_dev(torch, pad(v)), to_dev(torch, pad(g)), 112 * 4, vm, nm, W * 8, H, W, hits=hits)
+    torch.cuda.synchronize()
+    assert ohits > 1000 and abs(int(hits.item()) - ohits) <= 3
+    cmap_close(vm.cpu().numpy(), ov, H, budget=1e-4)
+    cmap_close(nm.cpu().numpy(), on, H, budget=1e-4)
+    # and through the march + crossing pair of kernels (the orchestrator's path)
+    vm2 = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    nm2 = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"],
+                 to_dev(torch, pad(v)), to_dev(torch, pad(g)), 112 * 4, vm2, nm2, W * 8, H, W, hits=hits, workspace=ws)
+    torch.cuda.synchronize()
+    cmap_close(vm2.cpu().numpy(), ov, H, budget=1e-4)
+    cmap_close(nm2.cpu().numpy(), on, H, budget=1e-4)
+
+
 # ---- ICP --------------------------------------------------------------------------------
 def icp_inputs(oracle, n=96):
     prm = synth.s1_params(n)
