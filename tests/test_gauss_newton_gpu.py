@@ -145,6 +145,62 @@ def test_relocalize_recovers_a_perturbed_pose(dev):
     kf.close()
 
 
+def test_residual_kernels_non_cubic_volume(dev, oracle):
+    """The three residual kernels (dual-complex Hessian, real loss, six-pose Gauss-Newton terms) over a 96 x 64 x 80 map —
+    two columns of 64-wide tiles, the second a half one; planes that are not a multiple of the 32-plane batches — against
+    the oracle, whole and as two unequal slabs."""
+    torch, capi, _ = dev
+    prm = synth.s1_params(96)
+    res = [96, 64, 80]
+    X, Y, Z = res
+    v, w, g = oracle.new_volume(res)
+    for k in (0, 1, 2):
+        T = s1_transforms(k, prm)
+        oracle.integrate(oracle.scale_depth(synth.s1_frame(k)), v, w, g, res, tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm),
+                         prm["tsdf_voxel_size"])
+    T3 = s1_transforms(3, prm)
+    ds = oracle.scale_depth(synth.s1_frame(3))
+    dds, gt = torch.from_numpy(ds).cuda(), torch.from_numpy(v).cuda()
+    ws = torch.zeros(capi.tsdf_reduce_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    trunc, vs, k4 = tranc_dist(prm), prm["tsdf_voxel_size"], intr_of(prm)
+    # dual-complex pose: value, seed 1e-6 on t_x in both first-order slots
+    Rd = np.zeros((3, 3, 4), np.float32); td = np.zeros((3, 4), np.float32)
+    Rd[..., 0] = np.asarray(T3["Rv2c"])[..., 0]; td[..., 0] = np.asarray(T3["tv2c"])[..., 0]; td[0, 1] = 1e-6; td[0, 2] = 1e-6
+    want4 = oracle.tsdf_hessian(ds, res, vs, Rd, td, trunc, k4, v)
+    want4 = want4[0] if isinstance(want4, tuple) else want4
+    out4 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    def hess(z0, z1):
+        out4.zero_()
+        capi.compute_local_tsdf_hessian(dds, W * 4, H, W, k4, res, vs, Rd, td, trunc, gt[z0 * X * Y:], ws, out4, z0=z0, z1=z1)
+        torch.cuda.synchronize()
+        return out4.cpu().numpy().copy()
+    got4 = hess(0, Z)
+    assert want4[3] > 1000 and got4[3] == want4[3]
+    assert abs(got4[0] - want4[0]) <= 1e-6 * abs(want4[0]) and abs(got4[1] - want4[1]) <= 1e-6 * abs(want4[1])
+    assert abs(got4[2] - want4[2]) <= 1e-5 * abs(want4[2])
+    parts = hess(0, 37) + hess(37, Z)
+    assert parts[3] == got4[3] and np.allclose(parts, got4, rtol=1e-11)
+    # real loss
+    R9, t3 = Rd[..., 0].reshape(9), td[..., 0].reshape(3)
+    wl = oracle.tsdf_loss(ds, res, vs, R9, t3, trunc, k4, v)
+    out2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    capi.compute_local_tsdf_loss(dds, W * 4, H, W, k4, res, vs, R9, t3, trunc, gt, ws, out2)
+    torch.cuda.synchronize()
+    gl = out2.cpu().numpy()
+    assert gl[1] == wl[1] and abs(gl[0] - wl[0]) <= 1e-6 * abs(wl[0])
+    # Gauss-Newton terms
+    v2c = np.eye(4); v2c[:3, :3] = Rd[..., 0]; v2c[:3, 3] = td[..., 0]
+    Rs, ts = seeded_poses(np.linalg.inv(v2c))
+    want = oracle.tsdf_gn_terms(ds, res, vs, Rs, ts, trunc, k4, v)
+    out = torch.zeros(32, dtype=torch.float64, device="cuda")
+    capi.tsdf_gauss_newton_terms(dds, W * 4, H, W, k4, res, vs, Rs, ts, trunc, gt, ws, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()[:29]
+    assert got[28] == want[28] > 1000 and np.allclose(got[27], want[27], rtol=1e-9)
+    assert np.all(np.abs(got[:21] - want[:21]) <= 1e-6 * np.abs(want[:21]).max())
+    assert np.all(np.abs(got[21:27] - want[21:27]) <= 1e-6 * np.abs(want[21:27]).max())
+
+
 def test_gn_terms_full_size_1024_eight_slabs(dev):
     """BASELINE config 5's size: a 1024^3 volume (two S1 frames fused into it on the GPU), then the
     Gauss-Newton terms of the next frame over the whole volume and over the eight z-slabs an 8-GPU run
