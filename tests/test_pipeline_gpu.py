@@ -163,6 +163,32 @@ def test_pipeline_against_live_oracle_128(dev, oracle):
     kf.close()
 
 
+def test_pipeline_quarter_size_sensor_against_live_oracle(dev, oracle):
+    """A 320 x 240 sensor (pyramid 320 / 160 / 80 columns: 2.5 and 1.25 tiles per row at the coarse levels) through the whole
+    pipeline, side by side with the oracle pipeline."""
+    torch, pl = dev
+    from oracle.oracle import OracleKinFu, params_from_dict
+    w2, h2 = W // 2, H // 2
+    cam = dict(width=w2, height=h2, fx=synth.FX / 2, fy=synth.FY / 2, cx=synth.CX / 2, cy=synth.CY / 2)
+    prm = dict(synth.s1_params(96), depth_width=w2, depth_height=h2, fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"])
+    kf = pl.KinectFusion(prm)
+    ok_ = OracleKinFu(oracle, params_from_dict(prm))
+    for k in range(4):
+        d = synth.s1_frame(k, **cam)
+        assert d.shape == (h2, w2)
+        assert kf.process_frame(upload(torch, d)) == 1 and ok_.process_frame(d) == 1
+        pose_close(kf.world2camera(), ok_.world2camera(), value_tol=1e-6 if k <= 1 else 5e-5, deriv_rel=1e-6 if k <= 1 else 3e-3)
+        assert abs(kf.last_U() - ok_.last_U()) <= max(3, 1e-4 * ok_.last_U())
+        if k >= 1:
+            la, lb = kf.icp_log(), ok_.icp_log()
+            assert la.shape == lb.shape and la.shape[0] == 12
+            assert abs(la[0, 54] - lb[0, 54]) <= max(2, 1e-4 * lb[0, 54]) and lb[0, 54] > 0.5 * (w2 // 4) * (h2 // 4)
+    v, w, g = kf.volume()
+    ov, ow, og = ok_.volume()
+    assert mismatch_fraction(w, ow) <= 1e-4
+    kf.close()
+
+
 def test_device_pose_solve_matches_host_solve(dev):
     """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
     the reference's one host solve per iteration — on the same frames: identical first-iteration sums,
