@@ -189,6 +189,25 @@ def test_pipeline_quarter_size_sensor_against_live_oracle(dev, oracle):
     kf.close()
 
 
+@pytest.mark.parametrize("levels", [1, 2])
+def test_pipeline_fewer_pyramid_levels_against_live_oracle(dev, oracle, levels):
+    """num_levels 1 and 2 (the model-map pyramid then goes through the separate resize launches, the ICP runs 5 or 5 + 4
+    iterations) side by side with the oracle pipeline."""
+    torch, pl = dev
+    from oracle.oracle import OracleKinFu, params_from_dict
+    prm = dict(synth.s1_params(96), num_levels=levels)
+    kf = pl.KinectFusion(prm)
+    ok_ = OracleKinFu(oracle, params_from_dict(prm))
+    for k in range(4):
+        d = synth.s1_frame(k)
+        assert kf.process_frame(upload(torch, d)) == 1 and ok_.process_frame(d) == 1
+        pose_close(kf.world2camera(), ok_.world2camera(), value_tol=1e-6 if k <= 1 else 5e-5, deriv_rel=1e-6 if k <= 1 else 3e-3)
+        assert abs(kf.last_U() - ok_.last_U()) <= max(3, 1e-4 * ok_.last_U())
+        if k >= 1:
+            assert kf.icp_log().shape == ok_.icp_log().shape == ((5, 9)[levels - 1], 55)
+    kf.close()
+
+
 def test_device_pose_solve_matches_host_solve(dev):
     """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
     the reference's one host solve per iteration — on the same frames: identical first-iteration sums,
