@@ -145,7 +145,8 @@ constexpr int NP = 56;      // partial record: 54 sums + count + pad
 
 // host-visible completion word: push everything out, then publish the sequence number
 __device__ __forceinline__ void publish_done(const IcpArgs &a) {
-    __threadfence_system();
+    // (a system-scope release store is the write-back of what precedes it + the store; a __threadfence_system() in front of it
+    // wrote back a second time and invalidated for nothing)
     __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
