@@ -115,8 +115,11 @@ __device__ __forceinline__ bool search_vertex_loaded(const IcpArgs &a, const Mat
     const cfloat3 vcurr_g = Rcurr * vcurr + tcurr;
     const cfloat3 vcp = a.Rprev_inv * (vcurr_g - a.tprev);
     const float cpx = vcp.x.re, cpy = vcp.y.re, cpz = vcp.z.re;
-    const int ux = __float2int_rn(cpx * a.intr.fx / cpz + a.intr.cx);
-    const int uy = __float2int_rn(cpy * a.intr.fy / cpz + a.intr.cy);
+    // (an invalid pixel's vertex is NaN and its normal's sentinel has not been looked at yet: the conversion of a NaN is
+    // kept out of the picture — such a pixel reads model pixel (0, 0) and is rejected below)
+    const float fu = cpx * a.intr.fx / cpz + a.intr.cx, fv = cpy * a.intr.fy / cpz + a.intr.cy;
+    const int ux = fu == fu ? __float2int_rn(fu) : 0;
+    const int uy = fv == fv ? __float2int_rn(fv) : 0;
     if (ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || cpz < 0) return false;
     cfloat3 nprev_g, vprev_g;
     nprev_g.x = row_ptr(a.nmap_g_prev, a.mstep, uy)[ux];
