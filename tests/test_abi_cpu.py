@@ -47,6 +47,26 @@ def test_ctypes_tables_cover_the_headers():
     assert A[0, 0, 0] == 0 and A[0, 1, 0] == 2 and b[0] == 12 and b[1] == 13 and A[5, 5, 0] == 50 and b[10] == 52
 
 
+def test_pose_mailbox_layout_host_side():
+    """xs_icp_post_pose is host code: the 128-byte mailbox it writes — two 64-byte lines, each led by the sequence number,
+    command in word 1, the 18 floats of Rcurr then the 6 of tcurr in words 2..15 and 18..27 — is what k_icp<POSE_POSTED> reads;
+    an abandon command carries no pose."""
+    import ctypes as C
+    import numpy as np
+    capi = importlib.import_module("x-slam_amd.capi")
+    assert capi.icp_mailbox_bytes() == 128
+    buf = np.full(40, 0xDEADBEEF, np.uint32)                      # 32 words + guard
+    R = (np.arange(18, dtype=np.float32) + 1).reshape(3, 3, 2)
+    t = (np.arange(6, dtype=np.float32) + 101).reshape(3, 2)
+    capi.icp_post_pose(buf.ctypes.data, R, t, 77, cmd=0)
+    f = np.concatenate([R.reshape(-1), t.reshape(-1)]).view(np.uint32)
+    assert buf[0] == 77 and buf[16] == 77 and buf[1] == 0 and buf[17] == 0
+    assert np.array_equal(buf[2:16], f[:14]) and np.array_equal(buf[18:28], f[14:])
+    assert np.all(buf[32:] == 0xDEADBEEF)
+    capi.icp_post_pose(buf.ctypes.data, None, None, 78, cmd=1)
+    assert buf[0] == 78 and buf[16] == 78 and buf[1] == 1 and not buf[2:16].any() and not buf[18:28].any()
+
+
 def test_product_never_imports_the_oracle():
     """The product package must not include, import, link or load anything under oracle/
     (the checker is test infrastructure; comments may mention it)."""
