@@ -67,6 +67,27 @@ def test_pose_mailbox_layout_host_side():
     assert buf[0] == 78 and buf[16] == 78 and buf[1] == 1 and not buf[2:16].any() and not buf[18:28].any()
 
 
+def test_host_fold_of_records_host_side():
+    """xs_icp_sum_records is host code: records of 56 doubles (54 sums, count, sequence word) added in index order once each
+    carries the launch's sequence number; a record that never arrives ends the wait (-1), one marked as given up returns 1."""
+    import numpy as np
+    capi = importlib.import_module("x-slam_amd.capi")
+    rng = np.random.default_rng(5)
+    n, seq = 7, 123456789
+    rec = np.zeros((n, 56), np.float64)
+    rec[:, :55] = rng.normal(size=(n, 55)) * 10.0 ** rng.integers(-8, 8, size=(n, 55))
+    rec[:, 55] = np.array([seq] * n, np.uint64).view(np.float64)
+    rc, sums = capi.icp_sum_records(rec.ctypes.data, n, seq, max_spins=10)
+    want = np.zeros(55)
+    for i in range(n):
+        want += rec[i, :55]          # the same association: record 0 first
+    assert rc == 0 and np.array_equal(sums, want)
+    late = rec.copy(); late[4, 55] = np.array([seq - 1], np.uint64).view(np.float64)[0]
+    assert capi.icp_sum_records(late.ctypes.data, n, seq, max_spins=1000)[0] == -1
+    gone = rec.copy(); gone[2, 55] = np.array([seq | (1 << 63)], np.uint64).view(np.float64)[0]
+    assert capi.icp_sum_records(gone.ctypes.data, n, seq, max_spins=1000)[0] == 1
+
+
 def test_product_never_imports_the_oracle():
     """The product package must not include, import, link or load anything under oracle/
     (the checker is test infrastructure; comments may mention it)."""
