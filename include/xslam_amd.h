@@ -124,6 +124,13 @@ int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, int rows, in
  * (already divided per level); level l is (rows0 >> l) x (cols0 >> l); pointer / pitch arrays per level. */
 int xs_create_vnmaps(int levels, const float *intr4s, const float *const *depths, const size_t *depth_steps, int rows0, int cols0,
                      float *const *vmaps, float *const *nmaps, const size_t *map_steps, void *stream);
+/* xs_create_vnmaps that also writes the real parts of both maps as float planes (vreal[l] / nreal[l]: 3 x rows(l) rows of cols(l)
+ * floats, pitch real_steps[l] bytes, NaN sentinel in the x plane).  The current-frame maps come from a real depth image, so their
+ * imaginary parts are zeros, and the ICP reduction can read these planes instead (xs_icp_accumulate_real /
+ * xs_icp_accumulate_posted_real: half the bytes of its current-frame reads).  The three arrays are all given or all NULL. */
+int xs_create_vnmaps_real(int levels, const float *intr4s, const float *const *depths, const size_t *depth_steps, int rows0, int cols0,
+                          float *const *vmaps, float *const *nmaps, const size_t *map_steps, float *const *vreal, float *const *nreal,
+                          const size_t *real_steps, void *stream);
 /* resizeVMap / resizeNMap(const MapArr& in, MapArr& out); src_rows = rows of one input plane
  *                                                                            Map.cu:105-152, 233-259 */
 int xs_resize_vmap(const float *in, size_t in_step, int src_rows, int src_cols, float *out, size_t out_step, void *stream);
@@ -253,6 +260,20 @@ int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_seq, const fl
                              int y1, void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq,
                              void *stream);
 void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const float *tcurr6, unsigned mailbox_seq, int cmd);
+/* xs_icp_accumulate / xs_icp_accumulate_posted reading the current-frame maps' real parts from float planes (xs_create_vnmaps_real;
+ * 3 x rows rows of cols floats, pitch real_step bytes) instead of the complex maps, whose imaginary parts must be zeros — true for
+ * maps made from a real depth image, i.e. always in this pipeline.  Half the bytes of the kernel's current-frame reads; the same sums
+ * (an imaginary part that was -0 in the complex map is +0 here).  vmap_curr / nmap_curr may be NULL. */
+int xs_icp_accumulate_real(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                           const float *vmap_curr_real, const float *nmap_curr_real, size_t real_step, const float *Rprev_inv18,
+                           const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev, size_t map_step,
+                           int rows, int cols, float distThres, float angleThres, int y0, int y1, void *workspace, double *sums_dev,
+                           unsigned long long *done_flag, unsigned long long done_seq, void *stream);
+int xs_icp_accumulate_posted_real(const void *mailbox, unsigned mailbox_seq, const float *vmap_curr, const float *nmap_curr,
+                                  const float *vmap_curr_real, const float *nmap_curr_real, size_t real_step, const float *Rprev_inv18,
+                                  const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev,
+                                  size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1, void *workspace,
+                                  double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq, void *stream);
 /* One whole ICP iteration without leaving the device: estimateCombined followed by the pose update
  * the reference's host performs before the next launch (KinectFusionReconstruction.cpp:203-224:
  * A.real().determinant() gate, complex<double> llt().solve, cast to complex<float>, AngleAxis

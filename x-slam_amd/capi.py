@@ -61,6 +61,8 @@ _SIGS = {
     "xs_create_nmap": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_create_vnmaps": (C.c_int, [C.c_int, _f32p, C.POINTER(_vp), C.POINTER(_sz), C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                                    C.POINTER(_sz), _vp]),
+    "xs_create_vnmaps_real": (C.c_int, [C.c_int, _f32p, C.POINTER(_vp), C.POINTER(_sz), C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
+                                        C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), _vp]),
     "xs_resize_vmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_resize_nmap": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "xs_raycast": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
@@ -86,6 +88,10 @@ _SIGS = {
     "xs_icp_accumulate_posted": (C.c_int, [_vp, C.c_uint, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
                                            C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_icp_post_pose": (None, [_vp, _f32p, _f32p, C.c_uint, C.c_int]),
+    "xs_icp_accumulate_real": (C.c_int, [_f32p, _f32p, _vp, _vp, _vp, _vp, _sz, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
+                                         C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
+    "xs_icp_accumulate_posted_real": (C.c_int, [_vp, C.c_uint, _vp, _vp, _vp, _vp, _sz, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int,
+                                                C.c_float, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_ulonglong, _vp]),
     "xs_icp_records_bytes": (_sz, []),
     "xs_icp_records_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "xs_icp_accumulate_records": (C.c_int, [_f32p, _f32p, _vp, C.c_uint, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -249,15 +255,20 @@ def create_vmap(intr, depth, depth_step, rows, cols, vmap, vmap_step, stream=Non
     check(_lib.xs_create_vmap(k.ctypes.data_as(_f32p), _ptr(depth), depth_step, rows, cols, _ptr(vmap), vmap_step, _stream(stream)))
 
 
-def create_vnmaps(intrs, depths, depth_steps, rows0, cols0, vmaps, nmaps, map_steps, stream=None):
-    """Vertex + normal maps of all pyramid levels in one launch.  intrs: per-level [fx, fy, cx, cy]."""
+def create_vnmaps(intrs, depths, depth_steps, rows0, cols0, vmaps, nmaps, map_steps, stream=None, vreal=None, nreal=None, real_steps=None):
+    """Vertex + normal maps of all pyramid levels in one launch.  intrs: per-level [fx, fy, cx, cy].  vreal / nreal / real_steps:
+    optionally the real parts again as float planes (xs_create_vnmaps_real)."""
     n = len(depths)
     k = np.ascontiguousarray(intrs, dtype=np.float32).reshape(-1)
     assert k.size == 4 * n
     P = lambda ts: (_vp * n)(*[_ptr(t) for t in ts])
     S = lambda xs: (_sz * n)(*[int(x) for x in xs])
-    check(_lib.xs_create_vnmaps(n, k.ctypes.data_as(_f32p), P(depths), S(depth_steps), rows0, cols0, P(vmaps), P(nmaps), S(map_steps),
-                                _stream(stream)))
+    if vreal is None:
+        check(_lib.xs_create_vnmaps(n, k.ctypes.data_as(_f32p), P(depths), S(depth_steps), rows0, cols0, P(vmaps), P(nmaps), S(map_steps),
+                                    _stream(stream)))
+    else:
+        check(_lib.xs_create_vnmaps_real(n, k.ctypes.data_as(_f32p), P(depths), S(depth_steps), rows0, cols0, P(vmaps), P(nmaps), S(map_steps),
+                                         P(vreal), P(nreal), S(real_steps), _stream(stream)))
 
 
 def tsdf_gauss_newton_terms(depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c6, tv2c6, tranc_dist, gt, workspace, out29,
@@ -350,6 +361,26 @@ def icp_accumulate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, v
     y1 = rows if y1 is None else y1
     check(_lib.xs_icp_accumulate(P(a), P(b), _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
                                  map_step, rows, cols, distThres, angleThres, y0, y1, _ptr(workspace), _ptr(sums), None, 0, _stream(stream)))
+
+
+def icp_accumulate_real(Rcurr, tcurr, vmap_curr_real, nmap_curr_real, real_step, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows,
+                        cols, distThres, angleThres, workspace, sums, y0=0, y1=None, stream=None, vmap_curr=None, nmap_curr=None):
+    """icp_accumulate reading the current-frame maps' real parts from float planes (create_vnmaps(..., vreal=, nreal=))."""
+    a, b, c, d, k = _fa(Rcurr, 18), _fa(tcurr, 6), _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    y1 = rows if y1 is None else y1
+    check(_lib.xs_icp_accumulate_real(P(a), P(b), _ptr(vmap_curr), _ptr(nmap_curr), _ptr(vmap_curr_real), _ptr(nmap_curr_real), real_step, P(c), P(d),
+                                      P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev), map_step, rows, cols, distThres, angleThres, y0, y1,
+                                      _ptr(workspace), _ptr(sums), None, 0, _stream(stream)))
+
+
+def icp_accumulate_posted_real(mailbox, mailbox_seq, vmap_curr_real, nmap_curr_real, real_step, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev,
+                               map_step, rows, cols, distThres, angleThres, workspace, sums, y0=0, y1=None, stream=None, done_flag=None, done_seq=0):
+    c, d, k = _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    check(_lib.xs_icp_accumulate_posted_real(_ptr(mailbox), mailbox_seq, None, None, _ptr(vmap_curr_real), _ptr(nmap_curr_real), real_step, P(c), P(d),
+                                             P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev), map_step, rows, cols, distThres, angleThres, y0,
+                                             rows if y1 is None else y1, _ptr(workspace), _ptr(sums), _ptr(done_flag), done_seq, _stream(stream)))
 
 
 def icp_iterate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,

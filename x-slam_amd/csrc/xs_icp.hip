@@ -21,6 +21,9 @@ using namespace xs;
 struct IcpArgs {
     MatS33 Rcurr; cfloat3 tcurr;
     const cfloat *vmap_curr; const cfloat *nmap_curr;
+    // optional: the same two maps' real parts as float planes (their imaginary parts are zeros when the depth image is real:
+    // xs_create_vnmaps_real) — read instead of the complex maps, half the bytes
+    const float *vreal; const float *nreal; size_t rstep;
     MatS33 Rprev_inv; cfloat3 tprev;
     Intr intr;
     const cfloat *vmap_g_prev; const cfloat *nmap_g_prev;
@@ -48,6 +51,12 @@ namespace {
 // the six current-frame values of a pixel: they depend on nothing but the pixel, so the one-tile-per-wave instance requests them
 // before it even has its pose (a posted launch spends ~3 us waiting for it)
 __device__ __forceinline__ void load_vertex(const IcpArgs &a, int x, int y, cfloat3 &vcurr) {
+    if (a.vreal) {   // wave-uniform
+        vcurr.x = cfloat(row_ptr(a.vreal, a.rstep, y)[x], 0.0f);
+        vcurr.y = cfloat(row_ptr(a.vreal, a.rstep, y + a.rows)[x], 0.0f);
+        vcurr.z = cfloat(row_ptr(a.vreal, a.rstep, y + 2 * a.rows)[x], 0.0f);
+        return;
+    }
     vcurr.x = row_ptr(a.vmap_curr, a.mstep, y)[x];
     vcurr.y = row_ptr(a.vmap_curr, a.mstep, y + a.rows)[x];
     vcurr.z = row_ptr(a.vmap_curr, a.mstep, y + 2 * a.rows)[x];
@@ -55,6 +64,12 @@ __device__ __forceinline__ void load_vertex(const IcpArgs &a, int x, int y, cflo
 __device__ __forceinline__ void load_normal(const IcpArgs &a, int x, int y, cfloat3 &ncurr) {
     // all three are requested before the sentinel is looked at (the y / z planes of an invalid pixel are allocated, merely
     // unused): one memory round trip instead of two
+    if (a.nreal) {
+        ncurr.x = cfloat(row_ptr(a.nreal, a.rstep, y)[x], 0.0f);
+        ncurr.y = cfloat(row_ptr(a.nreal, a.rstep, y + a.rows)[x], 0.0f);
+        ncurr.z = cfloat(row_ptr(a.nreal, a.rstep, y + 2 * a.rows)[x], 0.0f);
+        return;
+    }
     ncurr.x = row_ptr(a.nmap_curr, a.mstep, y)[x];
     ncurr.y = row_ptr(a.nmap_curr, a.mstep, y + a.rows)[x];
     ncurr.z = row_ptr(a.nmap_curr, a.mstep, y + 2 * a.rows)[x];
@@ -695,7 +710,7 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
                       int cols, float distThres, float angleThres, int y0, int y1, void *workspace, double *sums_dev,
                       unsigned long long *done_flag, unsigned long long done_seq, IcpPoseState *pose, IcpPoseState *pose_host, double *sums_host,
                       void *stream, const char *who, const void *mailbox = nullptr, unsigned mailbox_seq = 0, double *host_records = nullptr,
-                      unsigned long long record_seq = 0) {
+                      unsigned long long record_seq = 0, const float *vreal = nullptr, const float *nreal = nullptr, size_t rstep = 0) {
     if ((!pose && !mailbox && (!Rcurr18 || !tcurr6)) || !vmap_curr || !nmap_curr || !Rprev_inv18 || !tprev6 || !intr4 || !vmap_g_prev || !nmap_g_prev ||
         (!host_records && (!workspace || !sums_dev)))
         return xs_set_error(hipErrorInvalidValue, who);
@@ -707,6 +722,7 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
     a.vmap_curr = (const cfloat *)vmap_curr; a.nmap_curr = (const cfloat *)nmap_curr;
     a.vmap_g_prev = (const cfloat *)vmap_g_prev; a.nmap_g_prev = (const cfloat *)nmap_g_prev;
     a.mstep = map_step; a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.vreal = vreal; a.nreal = nreal; a.rstep = rstep;
     a.distThres = distThres; a.angleThres = angleThres; a.cols = cols; a.rows = rows; a.y0 = y0; a.y1 = y1;
     a.ticket = (unsigned *)workspace;
     a.partials = workspace ? (double *)((char *)workspace + 256) : nullptr;
@@ -755,6 +771,35 @@ extern "C" int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, cons
     return icp_launch(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
                       distThres, angleThres, y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream,
                       "xs_icp_accumulate: null pointer");
+}
+
+/* xs_icp_accumulate with the current-frame maps' real parts given as float planes too (xs_create_vnmaps_real: 3 x rows rows of
+ * cols floats, pitch real_step bytes): the kernel reads those instead of vmap_curr / nmap_curr — whose imaginary parts must be
+ * zeros, as they are for maps made from a real depth image — and forms (value, 0).  Same sums (an imaginary part that was -0 in the
+ * complex map is +0 here).  vmap_curr / nmap_curr may be NULL when the planes are given. */
+extern "C" int xs_icp_accumulate_real(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
+                                      const float *vmap_curr_real, const float *nmap_curr_real, size_t real_step, const float *Rprev_inv18,
+                                      const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev, size_t map_step,
+                                      int rows, int cols, float distThres, float angleThres, int y0, int y1, void *workspace, double *sums_dev,
+                                      unsigned long long *done_flag, unsigned long long done_seq, void *stream) {
+    if (!Rcurr18 || !tcurr6) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_real: null pointer");
+    if (!vmap_curr_real || !nmap_curr_real || real_step < (size_t)cols * 4) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_real: real planes");
+    const float *vc = vmap_curr ? vmap_curr : vmap_curr_real, *nc = nmap_curr ? nmap_curr : nmap_curr_real;   // (only tested for null)
+    return icp_launch(Rcurr18, tcurr6, vc, nc, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols, distThres, angleThres,
+                      y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream, "xs_icp_accumulate_real: null pointer",
+                      nullptr, 0, nullptr, 0, vmap_curr_real, nmap_curr_real, real_step);
+}
+extern "C" int xs_icp_accumulate_posted_real(const void *mailbox, unsigned mailbox_seq, const float *vmap_curr, const float *nmap_curr,
+                                             const float *vmap_curr_real, const float *nmap_curr_real, size_t real_step, const float *Rprev_inv18,
+                                             const float *tprev6, const float *intr4, const float *vmap_g_prev, const float *nmap_g_prev,
+                                             size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1, void *workspace,
+                                             double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq, void *stream) {
+    if (!mailbox) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_posted_real: null pointer");
+    if (!vmap_curr_real || !nmap_curr_real || real_step < (size_t)cols * 4) return xs_set_error(hipErrorInvalidValue, "xs_icp_accumulate_posted_real: real planes");
+    const float *vc = vmap_curr ? vmap_curr : vmap_curr_real, *nc = nmap_curr ? nmap_curr : nmap_curr_real;
+    return icp_launch(nullptr, nullptr, vc, nc, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols, distThres, angleThres,
+                      y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream, "xs_icp_accumulate_posted_real: null pointer",
+                      mailbox, mailbox_seq, nullptr, 0, vmap_curr_real, nmap_curr_real, real_step);
 }
 
 /* estimateCombined with the pose posted after the launch.  The launch is enqueued while the previous

@@ -225,6 +225,7 @@ extern "C" int xs_create_nmap(const float *vmap, float *nmap, size_t map_step, i
 struct VnLevel {
     const cfloat *depth; size_t dstep; cfloat *vmap; cfloat *nmap; size_t mstep;
     int rows, cols; float fx_inv, fy_inv, cx, cy;
+    float *vreal, *nreal; size_t rstep;   // optional: the real parts again, as float planes (xs_create_vnmaps_real)
 };
 struct VnArgs { VnLevel lv[3]; int levels; };
 __device__ __forceinline__ bool vertex_of(const VnLevel &L, int u, int v, cfloat3 &p) {
@@ -247,18 +248,36 @@ __global__ void __launch_bounds__(256) k_vnmaps(const VnArgs a) {
         row_ptr(L.vmap, L.mstep, v)[u] = v00.x;
         row_ptr(L.vmap, L.mstep, v + L.rows)[u] = v00.y;
         row_ptr(L.vmap, L.mstep, v + L.rows * 2)[u] = v00.z;
-    } else
+        if (L.vreal) {
+            row_ptr(L.vreal, L.rstep, v)[u] = v00.x.re;
+            row_ptr(L.vreal, L.rstep, v + L.rows)[u] = v00.y.re;
+            row_ptr(L.vreal, L.rstep, v + L.rows * 2)[u] = v00.z.re;
+        }
+    } else {
         row_ptr(L.vmap, L.mstep, v)[u] = cfloat(qnan_f(), 0.f);
+        if (L.vreal) row_ptr(L.vreal, L.rstep, v)[u] = qnan_f();
+    }
     const cfloat nan_c(qnan_f(), 0.f);
-    if (u == L.cols - 1 || v == L.rows - 1) { row_ptr(L.nmap, L.mstep, v)[u] = nan_c; return; }
+    if (u == L.cols - 1 || v == L.rows - 1) {
+        row_ptr(L.nmap, L.mstep, v)[u] = nan_c;
+        if (L.nreal) row_ptr(L.nreal, L.rstep, v)[u] = qnan_f();
+        return;
+    }
     cfloat3 v01, v10;
     if (ok00 && vertex_of(L, u + 1, v, v01) && vertex_of(L, u, v + 1, v10)) {
         const cfloat3 r = normalized(cross(v01 - v00, v10 - v00));
         row_ptr(L.nmap, L.mstep, v)[u] = r.x;
         row_ptr(L.nmap, L.mstep, v + L.rows)[u] = r.y;
         row_ptr(L.nmap, L.mstep, v + 2 * L.rows)[u] = r.z;
-    } else
+        if (L.nreal) {
+            row_ptr(L.nreal, L.rstep, v)[u] = r.x.re;
+            row_ptr(L.nreal, L.rstep, v + L.rows)[u] = r.y.re;
+            row_ptr(L.nreal, L.rstep, v + 2 * L.rows)[u] = r.z.re;
+        }
+    } else {
         row_ptr(L.nmap, L.mstep, v)[u] = nan_c;
+        if (L.nreal) row_ptr(L.nreal, L.rstep, v)[u] = qnan_f();
+    }
 }
 /* Vertex and normal maps of all pyramid levels (1..3) in one launch: what createVMap(intr(level), depth[level],
  * vmap[level]) followed by createNMap(vmap[level], nmap[level]) produce for level = 0 .. levels-1 (Map.h:31-44).
@@ -266,8 +285,19 @@ __global__ void __launch_bounds__(256) k_vnmaps(const VnArgs a) {
  * (rows0 >> l) x (cols0 >> l); steps in bytes per level. */
 extern "C" int xs_create_vnmaps(int levels, const float *intr4s, const float *const *depths, const size_t *depth_steps, int rows0, int cols0,
                                 float *const *vmaps, float *const *nmaps, const size_t *map_steps, void *stream) {
+    return xs_create_vnmaps_real(levels, intr4s, depths, depth_steps, rows0, cols0, vmaps, nmaps, map_steps, nullptr, nullptr, nullptr, stream);
+}
+/* The same launch, additionally writing the real parts of both maps as float planes (vreal[l] / nreal[l]: 3 x rows(l) rows of
+ * cols(l) floats, row pitch real_steps[l] bytes; NaN sentinel in the x plane as in the complex maps).  A depth image is real, so
+ * the imaginary parts of the current-frame maps are zeros: the ICP reduction can read half the bytes (xs_icp_accumulate*_real).
+ * All three arrays NULL = xs_create_vnmaps. */
+extern "C" int xs_create_vnmaps_real(int levels, const float *intr4s, const float *const *depths, const size_t *depth_steps, int rows0, int cols0,
+                                     float *const *vmaps, float *const *nmaps, const size_t *map_steps, float *const *vreal, float *const *nreal,
+                                     const size_t *real_steps, void *stream) {
     if (levels < 1 || levels > 3 || !intr4s || !depths || !depth_steps || !vmaps || !nmaps || !map_steps)
         return xs_set_error(hipErrorInvalidValue, "xs_create_vnmaps: bad arguments");
+    if ((vreal == nullptr) != (nreal == nullptr) || (vreal == nullptr) != (real_steps == nullptr))
+        return xs_set_error(hipErrorInvalidValue, "xs_create_vnmaps_real: pass all three real-plane arrays or none");
     if (rows0 <= 0 || cols0 <= 0) return 0;
     VnArgs a;
     a.levels = levels;
@@ -278,6 +308,8 @@ extern "C" int xs_create_vnmaps(int levels, const float *intr4s, const float *co
         L.vmap = (cfloat *)vmaps[l]; L.nmap = (cfloat *)nmaps[l]; L.mstep = map_steps[l];
         L.rows = rows0 >> l; L.cols = cols0 >> l;
         L.fx_inv = 1.f / intr4s[4 * l]; L.fy_inv = 1.f / intr4s[4 * l + 1]; L.cx = intr4s[4 * l + 2]; L.cy = intr4s[4 * l + 3];
+        L.vreal = vreal ? vreal[l] : nullptr; L.nreal = nreal ? nreal[l] : nullptr; L.rstep = real_steps ? real_steps[l] : 0;
+        if (vreal && (!L.vreal || !L.nreal)) return xs_set_error(hipErrorInvalidValue, "xs_create_vnmaps_real: null pointer");
     }
     for (int l = levels; l < 3; ++l) a.lv[l] = a.lv[0];
     dim3 block(64, 4), grid(div_up(cols0, 64), div_up(rows0, 4), levels);

@@ -110,6 +110,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_solve_on_device = config.as<bool>("icp_solve_on_device", false);
     icp_shard_rows = config.as<bool>("icp_shard_rows", false);
     icp_post_pose = config.as<bool>("icp_post_pose", true);
+    icp_real_current_maps = config.as<bool>("icp_real_current_maps", true);
     icp_lookahead = config.as<int>("icp_lookahead", 1);
     icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
@@ -179,6 +180,9 @@ void KinectFusionReconstruction::ReleaseBuffers() {
     g_buf.release();
     sum_buf.release();
     depthRawScaled_d.release();
+    for (auto &m : vreal_curr_d) m.release();
+    for (auto &m : nreal_curr_d) m.release();
+    real_maps_valid_ = false;
     delete tsdf_volume_d_ptr;
     tsdf_volume_d_ptr = nullptr;
 }
@@ -301,10 +305,21 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                      "estimateCombined (records)");
             return seq;
         }
-        if (R)
+        const bool real = real_maps_valid_ && level < (int)vreal_curr_d.size();
+        if (R && real)
+            check_rc(xs_icp_accumulate_real(&R->data[0].x.re, &t->x.re, &vc.ptr()->re, &nc.ptr()->re, vreal_curr_d[level].ptr(), nreal_curr_d[level].ptr(),
+                                            vreal_curr_d[level].step(), &device_Rprev_inv.data[0].x.re, &device_tprev.x.re, &k.fx, &vp.ptr()->re,
+                                            &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, 0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq,
+                                            current_stream()), "estimateCombined");
+        else if (R)
             check_rc(xs_icp_accumulate(&R->data[0].x.re, &t->x.re, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
                                        &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres,
                                        0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq, current_stream()), "estimateCombined");
+        else if (real)
+            check_rc(xs_icp_accumulate_posted_real(mailbox, mail_seq, &vc.ptr()->re, &nc.ptr()->re, vreal_curr_d[level].ptr(), nreal_curr_d[level].ptr(),
+                                                   vreal_curr_d[level].step(), &device_Rprev_inv.data[0].x.re, &device_tprev.x.re, &k.fx,
+                                                   &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, 0, rows, icp_ws_.ptr(),
+                                                   pinned_sums_, flag, seq, current_stream()), "estimateCombined (posted)");
         else
             check_rc(xs_icp_accumulate_posted(mailbox, mail_seq, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
                                               &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres,
@@ -683,7 +698,23 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
             uniform = depths_curr_d[i].rows() == (depth_height >> i) && depths_curr_d[i].cols() == (depth_width >> i) &&
                       nmaps_curr_d[i].step() == ms[i];
         }
-        if (uniform)
+        real_maps_valid_ = false;
+        if (uniform && icp_real_current_maps) {
+            float *vr[3], *nr[3]; size_t rs[3];
+            vreal_curr_d.resize(num_levels); nreal_curr_d.resize(num_levels);
+            for (int i = 0; i < num_levels; ++i) {
+                vreal_curr_d[i].create(depths_curr_d[i].rows() * 3, depths_curr_d[i].cols());
+                nreal_curr_d[i].create(depths_curr_d[i].rows() * 3, depths_curr_d[i].cols());
+                vr[i] = vreal_curr_d[i].ptr(); nr[i] = nreal_curr_d[i].ptr(); rs[i] = vreal_curr_d[i].step();
+                uniform = uniform && nreal_curr_d[i].step() == rs[i];
+            }
+            if (uniform) {
+                check_rc(xs_create_vnmaps_real(num_levels, &ks[0].fx, dp, ds, depth_height, depth_width, vp, np_, ms, vr, nr, rs, current_stream()), "createVMap");
+                real_maps_valid_ = true;
+            }
+        }
+        if (real_maps_valid_) {
+        } else if (uniform)
             check_rc(xs_create_vnmaps(num_levels, &ks[0].fx, dp, ds, depth_height, depth_width, vp, np_, ms, current_stream()), "createVMap");
         else
             for (int i = 0; i < num_levels; ++i) {

@@ -50,6 +50,11 @@ public:
 
     std::vector<DeviceArray2D<devComplex>> depths_curr_d, vmaps_curr_d, nmaps_curr_d, vmaps_g_prev_d, nmaps_g_prev_d;
     DeviceArray2D<float> depthRawScaled_d;
+    // the current-frame maps' real parts as float planes (their imaginary parts are zeros: the depth image is real) — what the
+    // ICP reduction reads (half the bytes); YAML icp_real_current_maps, default true
+    std::vector<DeviceArray2D<float>> vreal_curr_d, nreal_curr_d;
+    bool icp_real_current_maps = true;
+    bool real_maps_valid_ = false;
 
     bool use_gtPose = false;
 
