@@ -74,12 +74,26 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
  * the counting.  flags = 0 is xs_integrate_scaled. */
 #define XS_INTEGRATE_HEADER_IS_CLEAR 1u
 #define XS_INTEGRATE_NO_FOLD 2u
+#define XS_INTEGRATE_LIST_IS_READY 4u   /* xs_integrate_classify has produced the brick list on this stream (see there) */
 int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
                            int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
                            unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, unsigned flags, void *stream);
 int xs_integrate_workspace_clear(void *workspace, void *stream);
 int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, void *stream);
+/* The brick classification of an integrate call ahead of the call, for a pose that is only NEARLY the final one (the orchestrator
+ * enqueues it behind the last ICP launch with the pose that launch starts from: the list is there when the final pose is, and
+ * the classification's launch latency leaves the frame's critical path).  The frustum's slack is multiplied by slack_scale (>= 1);
+ * xs_integrate_list_covers (host only) says whether such a list holds every brick the final pose would list — if so, call
+ * xs_integrate_scaled_ex with XS_INTEGRATE_LIST_IS_READY (| XS_INTEGRATE_HEADER_IS_CLEAR) on the same stream / workspace / slab /
+ * image size, else clear the header again (xs_integrate_workspace_clear) and call it without.  flags of xs_integrate_classify:
+ * XS_INTEGRATE_HEADER_IS_CLEAR as above.  Results are those of the plain call, bit for bit (the list is a superset; every voxel
+ * still takes the exact tests with the final pose). */
+int xs_integrate_classify(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
+                          float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale, unsigned flags,
+                          void *stream);
+int xs_integrate_list_covers(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18_list,
+                             const float *tv2c6_list, float slack_scale, const float *Rv2c18, const float *tv2c6);
 /* Device workspace for xs_integrate_scaled's brick work list, for a slab of nz planes.  With a
  * workspace the kernel first lists the 64x4x8-voxel bricks that can intersect the frustum and
  * then spreads them over all CUs; without one (NULL) each column walks its own clipped range. */

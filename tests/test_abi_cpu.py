@@ -88,6 +88,28 @@ def test_host_fold_of_records_host_side():
     assert capi.icp_sum_records(gone.ctypes.data, n, seq, max_spins=1000)[0] == 1
 
 
+def test_brick_list_coverage_host_side():
+    """xs_integrate_list_covers is host code: a list classified for a pose with doubled slack covers the same pose, poses a
+    last-ICP-update away, and not poses centimetres or a hundredth of a radian away."""
+    import numpy as np
+    capi = importlib.import_module("x-slam_amd.capi")
+    synth = importlib.import_module("x-slam_amd.synth")
+    prm = synth.s1_params(512)
+    T = synth.s1_transforms(7, prm)
+    res, vs, k4 = [512, 512, 512], prm["tsdf_voxel_size"], synth.intr_of(prm)
+    R = np.array(T["Rv2c"], np.float32).reshape(3, 3, 2); t = np.array(T["tv2c"], np.float32).reshape(3, 2)
+    cov = lambda R2, t2, s=2.0: capi.integrate_list_covers(synth.HEIGHT, synth.WIDTH, k4, res, vs, R, t, s, R2, t2)
+    assert cov(R, t) and not cov(R, t, 1.0 - 1e-3)
+    t2 = t.copy(); t2[:, 0] += [2e-4, -1e-4, 3e-4]
+    assert cov(R, t2)
+    t3 = t.copy(); t3[2, 0] += 0.08
+    assert not cov(R, t3)
+    a = 0.01
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    R4 = R.copy(); R4[..., 0] = Rz @ R[..., 0]
+    assert not cov(R4, t)
+
+
 def test_product_never_imports_the_oracle():
     """The product package must not include, import, link or load anything under oracle/
     (the checker is test infrastructure; comments may mention it)."""

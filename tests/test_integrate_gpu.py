@@ -132,6 +132,49 @@ def test_integrate_non_cubic_pitched_volume(dev, oracle):
     assert cpu[3][-1] > 1000
 
 
+def test_integrate_with_the_brick_list_classified_ahead(dev):
+    """xs_integrate_classify for the pose the last ICP launch starts from + xs_integrate_scaled_ex(LIST_IS_READY) for the final
+    pose: the same volume and count, bit for bit, as the plain call — for a final pose a last ICP update away (covered) —, and
+    xs_integrate_list_covers refuses a pose centimetres away."""
+    torch, capi = dev
+    n = 128
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    Hh, Ww = synth.HEIGHT, synth.WIDTH
+    scaled = torch.empty((Hh, Ww), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+
+    def fresh():
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        return v, w, g
+    a, b = fresh(), fresh()
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+    ca, cb = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    k4, vs, trunc = intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm)
+    for k in (0, 4, 8):
+        depth = torch.from_numpy(synth.s1_frame(k).astype(np.int16)).cuda()
+        capi.scale_depth_max(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax)
+        T = s1_transforms(k, prm)
+        # the pose the classification sees: the final one moved by a last-iteration-sized update (0.3 mm, 2e-5 rad about y)
+        Rl = np.array(T["Rv2c"], np.float32).reshape(3, 3, 2).copy(); tl = np.array(T["tv2c"], np.float32).reshape(3, 2).copy()
+        c_, s_ = np.cos(2e-5), np.sin(2e-5)
+        Ry = np.array([[c_, 0, s_], [0, 1, 0], [-s_, 0, c_]], np.float32)
+        Rl[..., 0] = Ry @ Rl[..., 0]; tl[:, 0] = Ry @ tl[:, 0] + np.array([3e-4, -2e-4, 1e-4], np.float32)
+        assert capi.integrate_list_covers(Hh, Ww, k4, res, vs, Rl, tl, 2.0, T["Rv2c"], T["tv2c"])
+        capi.integrate_scaled(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, *a, n * 4, updated=ca, depth_max=dmax, workspace=ws)
+        capi.integrate_classify(Hh, Ww, k4, res, vs, Rl, tl, trunc, ws, slack_scale=2.0, depth_max=dmax)
+        capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, *b, n * 4, 1 | 4, updated=cb, depth_max=dmax,
+                                 workspace=ws)
+        torch.cuda.synchronize()
+        assert int(ca.item()) == int(cb.item()) > 1000
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        far_t = tl.copy(); far_t[0, 0] += 0.05
+        assert not capi.integrate_list_covers(Hh, Ww, k4, res, vs, Rl, far_t, 2.0, T["Rv2c"], T["tv2c"])
+
+
 def test_integrate_rotated_and_inside_out_views(dev, oracle):
     """Column clipping under strong rotations (every sign of the half-space slopes), a camera
     outside the volume and a view from the far side."""

@@ -208,6 +208,30 @@ def test_pipeline_fewer_pyramid_levels_against_live_oracle(dev, oracle, levels):
     kf.close()
 
 
+def test_brick_list_classified_ahead_changes_nothing(dev):
+    """integrate_classify_ahead (the integrate call's brick list built behind the last ICP launch, from the pose that launch
+    starts from) against the plain order, and against a list slack of 1 — with which no final pose is ever covered, so every
+    frame takes the fall-back (header cleared again, classification repeated): the same poses, counts and volume, bit for bit."""
+    torch, pl = dev
+    prm = synth.s1_params(128)
+    runs = [pl.KinectFusion(dict(prm, integrate_classify_ahead=False)), pl.KinectFusion(dict(prm, integrate_classify_ahead=True)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_slack=1.0))]
+    blank = upload(torch, np.zeros_like(synth.s1_frame(0)))
+    for k in list(range(6)) + ["blank", 6, 7]:
+        d = blank if k == "blank" else upload(torch, synth.s1_frame(k))
+        rcs = [r.process_frame(d) for r in runs]
+        assert rcs[0] == rcs[1] == rcs[2] == (0 if k == "blank" else 1)
+        for r in runs[1:]:
+            assert np.array_equal(r.world2camera(), runs[0].world2camera())
+            assert r.last_U() == runs[0].last_U() and r.last_hits() == runs[0].last_hits()
+    v0, w0, g0 = runs[0].volume()
+    for r in runs[1:]:
+        v, w, g = r.volume()
+        assert np.array_equal(w, w0) and np.array_equal(v, v0) and np.array_equal(g, g0)
+    for r in runs:
+        r.close()
+
+
 def test_device_pose_solve_matches_host_solve(dev):
     """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
     the reference's one host solve per iteration — on the same frames: identical first-iteration sums,

@@ -47,6 +47,9 @@ _SIGS = {
                                         _sz, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.c_uint, _vp]),
     "xs_integrate_workspace_clear": (C.c_int, [_vp, _vp]),
     "xs_integrate_fold_counts": (C.c_int, [_vp, _vp, _vp]),
+    "xs_integrate_classify": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _vp, _vp,
+                                        C.c_float, C.c_uint, _vp]),
+    "xs_integrate_list_covers": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
     "xs_integrate_set_timing_events": (None, [_vp, _vp]),
     "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
@@ -201,6 +204,24 @@ def integrate_scaled_ex(depth_scaled, scaled_step, rows, cols, intr, max_weight,
                                       r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
                                       _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _ptr(depth_max),
                                       _ptr(workspace), flags, _stream(stream)))
+
+
+def integrate_classify(rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, workspace, slack_scale=2.0, flags=0, z0=0, z1=None,
+                       depth_max=None, stream=None):
+    """The brick classification of an integrate call on its own, for a pose near the final one (xs_integrate_classify)."""
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
+    check(_lib.xs_integrate_classify(rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p),
+                                     t.ctypes.data_as(_f32p), tranc_dist, z0, int(r[2]) if z1 is None else z1, _ptr(depth_max), _ptr(workspace),
+                                     slack_scale, flags, _stream(stream)))
+
+
+def integrate_list_covers(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_list, slack_scale, Rv2c, tv2c):
+    r = _ia(res, 3)
+    k = _fa(intr, 4)
+    a, b, c, d = _fa(Rv2c_list, 18), _fa(tv2c_list, 6), _fa(Rv2c, 18), _fa(tv2c, 6)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    return bool(_lib.xs_integrate_list_covers(rows, cols, P(k), r.ctypes.data_as(_i32p), voxel_size, P(a), P(b), slack_scale, P(c), P(d)))
 
 
 def integrate_workspace_clear(workspace, stream=None):

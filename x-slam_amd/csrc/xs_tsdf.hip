@@ -16,6 +16,7 @@
 // (u*fx vs c*(bound)), before the two IEEE divides; anything within a pixel of the border
 // takes the exact path.  Only voxels that pass the reference's predicate touch memory.
 #include <hip/hip_ext.h>
+#include <string.h>
 #include "xs_device.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -523,6 +524,66 @@ extern "C" int xs_integrate_fold_counts(void *workspace, unsigned long long *upd
     XS_CHECK(hipGetLastError());
     return 0;
 }
+// the pose-dependent part of the arguments the classification needs (what xs_integrate_scaled_ex sets up for it)
+static void classify_args(IntegrateArgs &a, int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18,
+                          const float *tv2c6, float tranc_dist, int z0, int z1, const float *depth_max_dev) {
+    memset(&a, 0, sizeof(a));
+    a.drows = rows; a.dcols = cols;
+    a.X = res[0]; a.Y = res[1]; a.Z = res[2]; a.z0 = z0; a.z1 = z1;
+    a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist;
+    load_mat(Rv2c18, a.R); load_vec(tv2c6, a.t);
+    a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.voxel_size = voxel_size; a.depth_max = depth_max_dev;
+    host_frustum(a);
+    static const int env_bz = getenv("XS_BRICK_Z") ? atoi(getenv("XS_BRICK_Z")) : 0;  // tuning aid (as in xs_integrate_scaled_ex)
+    a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
+    a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(z1 - z0, a.brick_z);
+}
+/* The brick classification of an integrate call on its own, for a pose that is only NEARLY the one the call will be made with — the
+ * orchestrator enqueues it behind the last ICP launch, with the pose that launch started from, so that the list is there when the
+ * final pose is: the launch latency of the classification (and half of the integrate kernel's) leaves the frame's critical path.
+ * The frustum's slack is multiplied by slack_scale (> 1): the list then holds every brick any pose covered by
+ * xs_integrate_list_covers(..., this pose, slack_scale, that pose) would list.  Clears the workspace header first unless flags has
+ * XS_INTEGRATE_HEADER_IS_CLEAR.  Follow with xs_integrate_scaled_ex(..., XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR, ...)
+ * on the same stream, workspace, volume slab and image size.  No synchronisation. */
+extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
+                                     float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale, unsigned flags,
+                                     void *stream) {
+    if (!intr4 || !res || !Rv2c18 || !tv2c6 || !workspace || !(slack_scale >= 1.0f))
+        return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify: bad argument");
+    if (z0 < 0 || z1 > res[2] || z1 <= z0 || res[0] <= 0 || res[1] <= 0) return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify: bad slab");
+    IntegrateArgs a;
+    classify_args(a, rows, cols, intr4, res, voxel_size, Rv2c18, tv2c6, tranc_dist, z0, z1, depth_max_dev);
+    if (!(a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047)) return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify: volume too large for the brick list");
+    for (int p = 0; p < 6; ++p) a.fr.slack[p] *= slack_scale;
+    a.brick_count = (unsigned *)workspace;
+    a.brick_list = (int *)((char *)workspace + 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
+    const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
+    hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+/* Host only: 1 if a list classified with (Rv2c18_list, tv2c6_list, slack_scale) holds every brick the classification of
+ * (Rv2c18, tv2c6) with the standard slack would — each half-space of the second pose, anywhere in the volume, lies inside the
+ * first one's widened half-space — else 0 (then classify again: xs_integrate_scaled_ex without XS_INTEGRATE_LIST_IS_READY). */
+extern "C" int xs_integrate_list_covers(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18_list,
+                                        const float *tv2c6_list, float slack_scale, const float *Rv2c18, const float *tv2c6) {
+    if (!intr4 || !res || !Rv2c18_list || !tv2c6_list || !Rv2c18 || !tv2c6) return 0;
+    IntegrateArgs l, f;
+    classify_args(l, rows, cols, intr4, res, voxel_size, Rv2c18_list, tv2c6_list, 1.0f, 0, res[2], nullptr);
+    classify_args(f, rows, cols, intr4, res, voxel_size, Rv2c18, tv2c6, 1.0f, 0, res[2], nullptr);
+    for (int p = 0; p < 6; ++p) {
+        // a brick passes plane p when max over the brick of (alpha + b . index) >= -1.5 slack (box_may_pass); the two maxima differ
+        // by at most the largest pointwise difference of the two affine forms over the volume
+        const double d = fabs((double)l.fr.alpha[p] - f.fr.alpha[p]) + fabs((double)l.fr.bx[p] - f.fr.bx[p]) * res[0] +
+                         fabs((double)l.fr.by[p] - f.fr.by[p]) * res[1] + fabs((double)l.fr.bz[p] - f.fr.bz[p]) * res[2];
+        const double room = 1.5 * ((double)slack_scale * l.fr.slack[p] - f.fr.slack[p]);
+        if (!(d <= 0.9 * room)) return 0;   // (a tenth of the room left for the kernel's float evaluation of the forms)
+    }
+    return 1;
+}
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                                    float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
@@ -536,7 +597,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
                                       unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, unsigned flags, void *stream) {
     if (!depth_scaled || !intr4 || !res || !Rv2c18 || !tv2c6 || !value || !weight || !grad)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: null pointer");
-    if ((flags & (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD)) && !workspace)
+    if ((flags & (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD | XS_INTEGRATE_LIST_IS_READY)) && !workspace)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: the flags concern the workspace path");
     if (z0 < 0 || z1 > res[2] || z1 < z0 || (vol_step % 4) != 0 || vol_step < (size_t)res[0] * 4)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: bad slab or pitch");
@@ -562,9 +623,11 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         a.brick_count = (unsigned *)workspace;
         a.brick_list = (int *)((char *)workspace + 256);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-        if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR))
-            XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // brick count + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
-        hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+        if (!(flags & XS_INTEGRATE_LIST_IS_READY)) {   // (else: xs_integrate_classify has run on this stream for a covering pose)
+            if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR))
+                XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // brick count + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
+            hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+        }
         // resident workgroups stride over the list: 256 CUs x 8
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
         const int gmax = env_g > 0 ? env_g : 8192;

@@ -111,6 +111,8 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_shard_rows = config.as<bool>("icp_shard_rows", false);
     icp_post_pose = config.as<bool>("icp_post_pose", true);
     icp_real_current_maps = config.as<bool>("icp_real_current_maps", true);
+    integrate_classify_ahead = config.as<bool>("integrate_classify_ahead", true);
+    integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
     icp_lookahead = config.as<int>("icp_lookahead", 1);
     icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
@@ -273,6 +275,7 @@ int KinectFusionReconstruction::AlignDepthToReconstruction(const DeviceArray2D<u
 // reference :177-235
 int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, Matrix3frm Rprev_inv, Vector3cf tprev) {
     icp_log.clear();
+    list_ready_ = false;
     if (frame_id == 0) return 0;
     Matrix4cf c2w_prev = inverse(world2camera_record.back());
     Matrix4cf c2w_curr = c2w_prev;
@@ -357,6 +360,9 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 // frame's first ones are enqueued while the GPU still works on the previous frame's raycast — measured the same
                 // 2 900-2 950 frames/s as one: those gaps are the profiler's.)
                 enqueue_through(n + std::max(1, icp_lookahead), &device_Rcurr, &device_tcurr);
+                // the last launch is in the queue: the integrate call's brick classification goes in behind it, for the pose that
+                // launch starts from — the final one differs by the last level-0 update, which IntegrateFrame checks is covered
+                if (n == total_iters - 1 && integrate_classify_ahead && integrate_split()) ClassifyAhead(Rcurr, tcurr);
                 const unsigned long long seq = seq_of[n];
                 if (n + 1 < total_iters) {
                     next_mail_seq = mail_of[n + 1];
@@ -560,6 +566,30 @@ void KinectFusionReconstruction::flush_pending_fold(hipStream_t st) {
 }
 
 // reference :237-278
+// xs_integrate_classify for the camera pose (Rcurr, tcurr) = camera-to-world, on the main stream (behind the ICP launches)
+void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr) {
+    Matrix4cf c2w;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) c2w(i, j) = hostComplex(i == j ? 1.f : 0.f, 0.f);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c2w(i, j) = Rcurr(i, j);
+        c2w(i, 3) = tcurr[i];
+    }
+    Matrix4cf v2c = inverse(world2volume * c2w);
+    Matrix3frm Rv2c = GetRotation(v2c);
+    Vector3cf tv2c = GetTranslation(v2c);
+    std::memcpy(list_Rv2c_, &device_cast<MatS33>(Rv2c).data[0].x.re, sizeof(list_Rv2c_));
+    std::memcpy(list_tv2c_, &device_cast<devComplex3>(tv2c).x.re, sizeof(list_tv2c_));
+    hipStream_t st = current_stream();
+    // the scaled depth's maximum and the cleared header come from the auxiliary stream
+    if (scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
+    const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
+    check_rc(xs_integrate_classify(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
+                                   tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
+                                   integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
+    list_ready_ = true;
+}
+
 int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d) {
     if (use_gtPose) {
         Matrix4cf c2w = gt_poses[frame_id];
@@ -619,11 +649,22 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             const size_t off = (size_t)(za - zs0) * res[1];
             // header cleared and count folded on the auxiliary stream (SurfaceMeasure) when there is one call per frame
             const bool split = integrate_split() && integrate_header_clear_ && i == 0;
+            unsigned list_flag = 0;
+            if (i == 0 && list_ready_) {
+                list_ready_ = false;
+                if (xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
+                                             integrate_classify_slack,
+                                             &device_Rv2c.data[0].x.re, &device_tv2c.x.re))
+                    list_flag = XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR;
+                else   // the last update moved the frustum further than the widened list allows for (never seen): start over
+                    check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
+            }
             check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
                                             &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
                                             &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
                                             grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters : nullptr,
-                                            depth_max_dev, integrate_ws_.ptr(), split ? (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD) : 0u, st),
+                                            depth_max_dev, integrate_ws_.ptr(),
+                                            (split ? (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD) : 0u) | list_flag, st),
                      "integrateTsdfVolume");
             if (split) { integrate_header_clear_ = false; pending_fold_ = counters; }
             if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);

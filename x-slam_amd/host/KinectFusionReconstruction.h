@@ -54,6 +54,13 @@ public:
     // ICP reduction reads (half the bytes); YAML icp_real_current_maps, default true
     std::vector<DeviceArray2D<float>> vreal_curr_d, nreal_curr_d;
     bool icp_real_current_maps = true;
+    // the integrate call's brick classification enqueued behind the last ICP launch, with the pose that launch starts from (YAML
+    // integrate_classify_ahead, default true; single GPU with the posted ICP loop): IntegrateFrame then finds the list ready
+    bool integrate_classify_ahead = true;
+    float integrate_classify_slack = 2.0f;   // YAML integrate_classify_slack: how much wider than its own the list's frustum slack is (1 = every frame falls back)
+    bool list_ready_ = false;
+    float list_Rv2c_[18]{}, list_tv2c_[6]{};
+    void ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr);
     bool real_maps_valid_ = false;
 
     bool use_gtPose = false;
