@@ -74,6 +74,7 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
  * the counting.  flags = 0 is xs_integrate_scaled. */
 #define XS_INTEGRATE_HEADER_IS_CLEAR 1u
 #define XS_INTEGRATE_NO_FOLD 2u
+#define XS_INTEGRATE_ALWAYS_STORE 8u    /* store all three words of every updated voxel, also where their bits do not change (the default stores only words that change: same volume, fewer bytes) */
 #define XS_INTEGRATE_LIST_IS_READY 4u   /* xs_integrate_classify has produced the brick list on this stream (see there) */
 int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,

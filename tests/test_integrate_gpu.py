@@ -21,7 +21,8 @@ def dev():
     return torch, capi
 
 
-def run_gpu(torch, capi, prm, frames, res, pitch_elems=None, threshold=0.0, slabs=1, max_weight=None, depth_fn=None, far_clip=False, bricks=False):
+def run_gpu(torch, capi, prm, frames, res, pitch_elems=None, threshold=0.0, slabs=1, max_weight=None, depth_fn=None, far_clip=False, bricks=False,
+            always_store=False):
     X, Y, Z = res
     pitch = (pitch_elems or X)
     step = pitch * 4
@@ -46,10 +47,10 @@ def run_gpu(torch, capi, prm, frames, res, pitch_elems=None, threshold=0.0, slab
                 dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
                 capi.scale_depth_max(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, scaled, synth.WIDTH * 4, dmax)
                 ws = torch.zeros(capi.integrate_workspace_bytes(res, z1 - z0), dtype=torch.uint8, device="cuda") if bricks else None
-                capi.integrate_scaled(scaled, synth.WIDTH * 4, synth.HEIGHT, synth.WIDTH, intr_of(prm), mw, res, prm["tsdf_voxel_size"],
-                                      T["Rv2c"], T["tv2c"], tranc_dist(prm), value[off:], weight[off:], grad[off:], step,
-                                      threshold=threshold, z0=z0, z1=z1, updated=counter, depth_max=dmax if far_clip else None,
-                                      workspace=ws)
+                capi.integrate_scaled_ex(scaled, synth.WIDTH * 4, synth.HEIGHT, synth.WIDTH, intr_of(prm), mw, res, prm["tsdf_voxel_size"],
+                                         T["Rv2c"], T["tv2c"], tranc_dist(prm), value[off:], weight[off:], grad[off:], step,
+                                         8 if always_store else 0, threshold=threshold, z0=z0, z1=z1, updated=counter,
+                                         depth_max=dmax if far_clip else None, workspace=ws)
             else:
                 capi.integrate_tsdf_volume(depth, synth.WIDTH * 2, synth.HEIGHT, synth.WIDTH, intr_of(prm), mw, res,
                                            prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm),
@@ -258,6 +259,26 @@ def test_integrate_weight_saturation(dev, oracle):
     cpu = run_cpu(oracle, prm, [0, 0, 0, 0], res, max_weight=2)
     compare(gpu, cpu)
     assert gpu[1].max() == 2
+
+
+@pytest.mark.parametrize("threshold", [0.0, 0.02])
+def test_integrate_stores_only_words_that_change(dev, oracle, threshold):
+    """The kernels store only the words of an updated voxel whose bits change (free space in front of a surface keeps
+    (1, 0) from its second observation on; a saturated weight stays): the volume after six frames — the weight saturates
+    at three — is identical to the one XS_INTEGRATE_ALWAYS_STORE writes, on the brick path and on the column walk, and
+    equal to the oracle's."""
+    torch, capi = dev
+    prm = synth.s1_params(96, threshold=threshold)
+    res = [96, 96, 96]
+    frames = [0, 0, 1, 2, 2, 3]
+    for kw in (dict(far_clip=True, bricks=True), dict(far_clip=True)):
+        a = run_gpu(torch, capi, prm, frames, res, threshold=threshold, max_weight=3, always_store=True, **kw)
+        b = run_gpu(torch, capi, prm, frames, res, threshold=threshold, max_weight=3, **kw)
+        for u, v in zip(a[:3], b[:3]):
+            assert np.array_equal(u, v), kw
+        assert a[3] == b[3], kw
+    compare(b, run_cpu(oracle, prm, frames, res, threshold=threshold, max_weight=3))
+    assert b[1].max() == 3 and (b[0] == 1.0).sum() > 1000
 
 
 def test_integrate_empty_inputs(dev, oracle):

@@ -106,7 +106,7 @@ extern "C" int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows
 #ifndef XS_BRICK_X
 #define XS_BRICK_X 32
 #endif
-enum { BRICK_X = XS_BRICK_X, BRICK_Y = 4 * (64 / XS_BRICK_X), BRICK_Z = 8 };   // a wave covers BRICK_X columns x 64 / BRICK_X rows
+enum { BRICK_X = XS_BRICK_X, BRICK_Y = 256 / XS_BRICK_X, BRICK_Z = 8 };   // thread t of the workgroup: column t % BRICK_X, row t / BRICK_X
 
 // Half-spaces of the (padded) view frustum in the volume's voxel-index space, built on the
 // host and passed as kernel arguments (wave-uniform: they live in scalar registers).  Along any
@@ -147,7 +147,9 @@ struct IntegrateArgs {
     const float *depth_max;       // optional: largest valid depth of the frame (device)
     int *brick_list; unsigned *brick_count;  // work list of the two-phase path
     int bricks_x, bricks_y, bricks_z, brick_z;  // brick_z: planes per brick (runtime; BRICK_Z by default)
+    unsigned kflags;              // KF_*
 };
+enum { KF_ALWAYS_STORE = 1u };    // write every updated voxel's three words even where the bits do not change (measurement aid)
 
 namespace {
 // device side of the frustum: add the far limit (see struct Frustum).  Behind the farthest
@@ -206,9 +208,30 @@ struct VoxelCtx {
 struct VoxelProj {  // what the projection hands to the update
     cfloat3 v_c; cfloat image_x, image_y, Dp; float c;
 };
+// how project_voxel reads the scaled depth image: plain global loads (64-bit per-lane addresses), or buffer loads through a
+// wave-uniform descriptor with a 32-bit per-lane byte offset (no 64-bit multiply-add per gather)
+struct DepthGlobal {
+    const float *depth; size_t dstep;
+    struct __attribute__((packed, aligned(4))) pair { float a, b; };
+    __device__ __forceinline__ float one(int y, int x) const { return row_ptr(depth, dstep, y)[x]; }
+    __device__ __forceinline__ void two(int y, int x, float &a, float &b) const {
+        const pair r = *reinterpret_cast<const pair *>(row_ptr(depth, dstep, y) + x); a = r.a; b = r.b;
+    }
+};
+struct DepthBuffer {
+    __amdgpu_buffer_rsrc_t rsrc; int dstep;
+    __device__ __forceinline__ float one(int y, int x) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, y * dstep + x * 4, 0, 0));
+    }
+    __device__ __forceinline__ void two(int y, int x, float &a, float &b) const {
+        const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, y * dstep + x * 4, 0, 0);
+        a = __builtin_bit_cast(float, r[0]); b = __builtin_bit_cast(float, r[1]);
+    }
+};
+enum { BUFFER_RSRC_FLAGS = 0x00020000 };   // gfx9 raw buffer, dword 3: 32-bit data format
 // phase 1 (TsdfFusion.cu:110-143): project the voxel, fetch its depth.  false = not written.
-template <bool BILINEAR>
-__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, VoxelProj &o) {
+template <bool BILINEAR, class Depth>
+__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, VoxelProj &o, const Depth &dimg) {
     const float vgz = (z + 0.5f) * a.voxel_size;
     o.v_c.x = (k.base[0] + a.R.data[0].z * vgz) + a.t.x;
     o.v_c.y = (k.base[1] + a.R.data[1].z * vgz) + a.t.y;
@@ -234,10 +257,9 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Voxe
         // global load needs); the nearest pixel is always one of them — coo = floor(image - 0.5), so rn(image) is coo or
         // coo + 1 on each axis (ties included) — and is picked from the registers instead of being gathered a fifth time:
         // two address-unit trips per voxel where there were five
-        struct __attribute__((packed, aligned(4))) pair { float a, b; };
-        const pair r0 = *reinterpret_cast<const pair *>(row_ptr(a.depth, a.dstep, coo_y) + coo_x);
-        const pair r1 = *reinterpret_cast<const pair *>(row_ptr(a.depth, a.dstep, coo_y + 1) + coo_x);
-        const float d00 = r0.a, d10 = r0.b, d01 = r1.a, d11 = r1.b;
+        float d00, d10, d01, d11;
+        dimg.two(coo_y, coo_x, d00, d10);
+        dimg.two(coo_y + 1, coo_x, d01, d11);
         const float n0 = near_x == coo_x ? d00 : d10, n1 = near_x == coo_x ? d01 : d11;
         Dp = cfloat(near_y == coo_y ? n0 : n1, 0.0f);
         const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
@@ -249,7 +271,11 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Voxe
             Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
         }
     }
-    else Dp = cfloat(row_ptr(a.depth, a.dstep, near_y)[near_x], 0.0f);
+#if defined(XS_PROBE_NODEPTH)   // measurement only: no depth gather either
+    else { float d = 4.5f + 1e-9f * near_x * near_y; asm volatile("" : "+v"(d)); Dp = cfloat(d, 0.0f); }
+#else
+    else Dp = cfloat(dimg.one(near_y, near_x), 0.0f);
+#endif
     o.Dp = Dp;
     return Dp.re > 0;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
 }
@@ -291,11 +317,42 @@ __device__ __forceinline__ bool update_voxel(const IntegrateArgs &a, const Voxel
     out_w = min(pre_w + 1, a.max_weight);
     return true;
 }
+// update_voxel in two halves, for the kernel that decides first and touches the volume afterwards.
+// voxel_tsdf is everything of TsdfFusion.cu:144-159 — it needs no voxel state: false = not written, else the frame's tsdf;
+// running_mean is :161-167 on the loaded state.  Same operations in the same order as update_voxel.
+__device__ __forceinline__ bool voxel_tsdf(const IntegrateArgs &a, const VoxelCtx &k, const VoxelProj &p, cfloat &tsdf) {
+    const float depth_diff = p.Dp.re - p.c;
+    const float band = a.tranc_dist * 1.001f + 1e-5f;
+    if (depth_diff < -band) return false;
+    tsdf = cfloat(1.0f, 0.0f);
+    if (!(depth_diff > band)) {
+        const cfloat xl = (p.image_x - k.cx) / k.fx;
+        const cfloat yl = (p.image_y - k.cy) / k.fy;
+        const cfloat3 v_c_1 = mk3(p.Dp * xl, p.Dp * yl, p.Dp);
+        const cfloat sdf = norm(v_c_1) - norm(p.v_c);
+        if (!(sdf.re >= -a.tranc_dist)) return false;
+        if (!(sdf.re > a.tranc_dist)) tsdf = sdf * a.tranc_dist_inv;
+    }
+    return true;
+}
+__device__ __forceinline__ void running_mean(const IntegrateArgs &a, cfloat tsdf, float pre_v, float pre_g, int pre_w, float &out_v,
+                                             float &out_g, int &out_w) {
+    const cfloat tsdf_prev = unpack_tsdf(pre_v, pre_g);
+    const cfloat num = tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf;
+    const float den = __int2float_rn(pre_w + 1);
+    const bool div_v = !(num.re == den), div_g = !(num.im == 0.0f);
+    out_v = 1.0f; out_g = num.im;
+    if (__builtin_amdgcn_ballot_w64(div_v || div_g) != 0) {  // (see update_voxel)
+        if (div_v) out_v = num.re / den;
+        if (div_g) out_g = num.im / den;
+    }
+    out_w = min(pre_w + 1, a.max_weight);
+}
 template <bool BILINEAR>
 __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
                                                 float &out_v, float &out_g, int &out_w) {
     VoxelProj p;
-    if (!project_voxel<BILINEAR>(a, k, z, p)) return false;
+    if (!project_voxel<BILINEAR>(a, k, z, p, DepthGlobal{a.depth, a.dstep})) return false;
     return update_voxel(a, k, p, pre_v, pre_g, pre_w, out_v, out_g, out_w);
 }
 
@@ -321,20 +378,36 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
     int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
     float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
     const size_t zstride = (size_t)a.Y * (a.vstep / 4);
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
     // (Requesting the state of voxel z+1 one trip ahead, in front of or behind the depth gather, was
     // measured slower: loads return in issue order and the extra live registers cost a wave.)
     for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
+#if defined(XS_PROBE_NOMEM)   // measurement only: the walk without its state loads and stores (profiles/tools/probe_integrate_floor.sh)
+        float v0 = 1.0f, g0 = 0.0f; int w0 = 5;
+        asm volatile("" : "+v"(v0), "+v"(g0), "+v"(w0));
+        float ov, og; int ow;
+        if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) { asm volatile("" ::"v"(ov), "v"(og), "v"(ow)); ++n_upd; }
+#else
         const float v0 = *pos, g0 = *gpos;
         const int w0 = *wpos;
         float ov, og; int ow;
-        if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) { *pos = ov; *wpos = ow; *gpos = og; ++n_upd; }
+        if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) {
+            // only the words whose bits change are stored (same volume, fewer bytes: in free space in front of a surface the running
+            // mean of (1, 0) with (1, 0) is (1, 0) again, and a saturated weight stays)
+            if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
+            if ((unsigned)(ow ^ w0) | always) *wpos = ow;
+            if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
+            ++n_upd;
+        }
         else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
+#endif
         // (the empty asm consumes the three loads on the paths that left early: without it they are
         // still in flight at the loop head, and the wait the compiler puts there to protect their
         // registers also waits for the previous trip's stores to be acknowledged)
     }
     return n_upd;
 }
+
 }  // namespace
 
 // One atomic per workgroup (a same-address atomic costs ~12 ns on this chip: one per wave of a
@@ -427,7 +500,8 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
         const int b = a.brick_list[e];
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
-        const int x = bx * BRICK_X + (int)(threadIdx.x % BRICK_X), y = by * BRICK_Y + (int)threadIdx.y * (64 / BRICK_X) + (int)(threadIdx.x / BRICK_X);
+        const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
+        const int x = bx * BRICK_X + t256 % BRICK_X, y = by * BRICK_Y + t256 / BRICK_X;
         if (x < a.X && y < a.Y) {
             int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
             clip_column(s_cp, far, x, y, zb, ze);
@@ -436,6 +510,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     }
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
 }
+
 
 static void load_mat(const float *p, MatS33 &m) {
     for (int r = 0; r < 3; ++r) {
@@ -610,7 +685,9 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     load_mat(Rv2c18, a.R); load_vec(tv2c6, a.t);
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev; a.depth_max = depth_max_dev;
-    a.brick_list = nullptr; a.brick_count = nullptr;
+    a.brick_list = nullptr; a.brick_count = nullptr; a.kflags = 0;
+    static const bool env_always = getenv("XS_INTEGRATE_ALWAYS_STORE") != nullptr;   // measurement aid, as the flag
+    if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     host_frustum(a);
     const int nz = z1 - z0;
     static const int env_bz = getenv("XS_BRICK_Z") ? atoi(getenv("XS_BRICK_Z")) : 0;  // tuning aid
@@ -635,15 +712,10 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // profiling: the event pair rides on the dispatch packet itself (hipExtLaunchKernelGGL: start / stop are
         // the kernel's own begin / end timestamps), so it adds no marker packets to the stream and times what
         // rocprofv3 times
-        if (g_int_ev0 || g_int_ev1) {   // either may be null: a completion event alone lets another stream wait for this kernel without a marker packet
-            if (threshold > 0.0f)
-                hipExtLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
-            else
-                hipExtLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
-        } else if (threshold > 0.0f)
-            hipLaunchKernelGGL(k_integrate_bricks<true>, dim3(g), block, 0, st, a);
-        else
-            hipLaunchKernelGGL(k_integrate_bricks<false>, dim3(g), block, 0, st, a);
+        // (either event may be null: a completion event alone lets another stream wait for this kernel without a marker packet)
+        void (*kern)(const IntegrateArgs) = threshold > 0.0f ? k_integrate_bricks<true> : k_integrate_bricks<false>;
+        if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
+        else hipLaunchKernelGGL(kern, dim3(g), block, 0, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
             hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
     } else {
