@@ -394,9 +394,15 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
         if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) {
             // only the words whose bits change are stored (same volume, fewer bytes: in free space in front of a surface the running
             // mean of (1, 0) with (1, 0) is (1, 0) again, and a saturated weight stays)
+#if defined(XS_PROBE_NT_STORES)   // measurement only: non-temporal stores (profiles/tools/probe_integrate_nt.sh)
+            if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) __builtin_nontemporal_store(ov, pos);
+            if ((unsigned)(ow ^ w0) | always) __builtin_nontemporal_store(ow, wpos);
+            if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) __builtin_nontemporal_store(og, gpos);
+#else
             if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
             if ((unsigned)(ow ^ w0) | always) *wpos = ow;
             if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
+#endif
             ++n_upd;
         }
         else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
@@ -511,6 +517,136 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
 }
 
+
+// ---- path 2, round 3 experiment: the walk with its voxel state prefetched by LDS-DMA ----------
+// The walk asks for a voxel's state at the top of its trip and gathers the depth ~60 instructions later; a wave's vector-memory
+// operations complete in issue order, so the gather — an L1 / L2 hit — comes back behind the three HBM reads, and every trip of
+// every wave exposes one full memory latency (the eight waves of a SIMD cover for each other; 3 x 256 B per wave in flight).
+// Here the order is turned round: in trip j the gather goes out first, the state of plane j + 1 right behind it — by LDS-DMA
+// (global_load_lds_dword: no destination register; a per-wave ring of two slots) — and the wave waits with vmcnt(3): for the
+// gather and everything older, which includes plane j's state (requested a whole trip ago), but not for the three requests it has
+// just made.  One asm statement holds the gather, the three DMAs (with their own lane mask: the lanes whose column has plane
+// j + 1) and the wait, so the count is exact by construction.
+__device__ __forceinline__ void lds_dma3(unsigned voff, const void *pv, const void *pg, const void *pw, unsigned lds) {
+    unsigned keep;
+    const unsigned l1 = lds + 256, l2 = lds + 512;
+    // M0 holds the LDS address of lane 0's word; the compiler does not preserve it around a statement, so it is saved and put back.
+    // (s_nop 4 first: a base pointer the compiler has just fetched back from a spill lane (v_readlane) needs five wait states before a
+    // vector-memory instruction reads it, and the compiler pads nothing inside a statement)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(pv), "s"(pg), "s"(pw), "s"(lds), "s"(l1), "s"(l2) : "memory");
+}
+struct RingRefill {   // wave-uniform but for voff: the next plane's state -> the slot at lds, for the lanes in mask (never empty when has)
+    bool has; unsigned long long mask; const void *pv, *pg, *pw; unsigned lds, voff;
+};
+struct DepthRing {
+    const float *depth; int dstep; RingRefill rf;
+    __device__ __forceinline__ float one(int y, int x) const {
+        const unsigned goff = (unsigned)(y * dstep + x * 4);
+        float d;
+        if (rf.has) {
+            unsigned keep; unsigned long long ex;
+            const unsigned l1 = rf.lds + 256, l2 = rf.lds + 512;
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %3, %4\n\t"
+                         "s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\t"
+                         "s_mov_b32 %1, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                         "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dword %6, %7\n\t"
+                         "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dword %6, %8\n\t"
+                         "s_mov_b32 m0, %12\n\ts_nop 0\n\tglobal_load_lds_dword %6, %9\n\t"
+                         "s_mov_b32 m0, %1\n\ts_mov_b64 exec, %2\n\t"
+                         "s_waitcnt vmcnt(3)"
+                         : "=&v"(d), "=&s"(keep), "=&s"(ex)
+                         : "v"(goff), "s"(depth), "s"(rf.mask), "v"(rf.voff), "s"(rf.pv), "s"(rf.pg), "s"(rf.pw), "s"(rf.lds), "s"(l1), "s"(l2)
+                         : "memory");
+        } else
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(goff), "s"(depth) : "memory");
+        return d;
+    }
+    __device__ __forceinline__ void two(int y, int x, float &a, float &b) const { DepthGlobal{depth, (size_t)dstep}.two(y, x, a, b); }
+};
+template <bool BILINEAR>
+__global__ void __launch_bounds__(256, 8) k_integrate_bricks_ring(const IntegrateArgs a) {
+    const unsigned count = *a.brick_count;
+    unsigned n_upd = 0;
+    __shared__ ClipPlanes s_cp;
+    __shared__ unsigned s_ring[4][2][3][64];   // per wave: two slots of (value, grad, weight) rows
+    const int tid = threadIdx.y * 64 + threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[tid] = reinterpret_cast<const float *>(&a.cp)[tid];
+    __syncthreads();
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&s_ring[wave][0][0][0]);
+    const int lx = tid % BRICK_X, ly = tid / BRICK_X;
+    const unsigned lane_off = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u;
+    const size_t plane_bytes = (size_t)a.Y * a.vstep;
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+        const int b = __builtin_amdgcn_readfirstlane(a.brick_list[e]);
+        const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
+        const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
+        const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
+        int zb = zb0, ze = ze0;
+        asm volatile("" ::: "memory");
+        if (x < a.X && y < a.Y) clip_column(s_cp, far_limit(a), x, y, zb, ze);
+        else ze = zb;
+        if (__builtin_amdgcn_ballot_w64(zb < ze) == 0) continue;
+        VoxelCtx k;
+        {
+            const float vgx = (x + 0.5f) * a.voxel_size, vgy = (y + 0.5f) * a.voxel_size;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) k.base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
+            k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
+            k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
+            k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
+        }
+        const size_t brick_off = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
+        const char *pv = reinterpret_cast<const char *>(a.value) + brick_off;
+        const char *pg = reinterpret_cast<const char *>(a.grad) + brick_off;
+        const char *pw = reinterpret_cast<const char *>(a.weight) + brick_off;
+        const int nz = ze0 - zb0;
+        if (zb0 >= zb && zb0 < ze) lds_dma3(lane_off, pv, pg, pw, ring_lds);   // plane 0 -> slot 0
+#pragma unroll 1
+        for (int j = 0; j < nz; ++j) {
+            const int z = zb0 + j, slot = j & 1;
+            const bool in = z >= zb && z < ze;
+            // plane j + 1 -> the other slot (its previous tenant, plane j - 1, was consumed in the previous trip)
+            DepthRing dimg{a.depth, (int)a.dstep, {}};
+            const unsigned long long m2 = (j + 1 < nz) ? __builtin_amdgcn_ballot_w64(z + 1 >= zb && z + 1 < ze) : 0ull;
+            dimg.rf.has = m2 != 0; dimg.rf.mask = m2;
+            dimg.rf.pv = pv + (j + 1) * plane_bytes; dimg.rf.pg = pg + (j + 1) * plane_bytes; dimg.rf.pw = pw + (j + 1) * plane_bytes;
+            dimg.rf.lds = ring_lds + (slot ^ 1) * 768; dimg.rf.voff = lane_off;
+            bool wr = false, gathered = false;
+            cfloat tsdf(1.0f, 0.0f);
+            if (in) {
+                VoxelProj p;
+                p.Dp = cfloat(-1.0f, 0.0f);
+                const bool vis = project_voxel<BILINEAR>(a, k, z, p, dimg);
+                gathered = p.Dp.re >= 0.0f;   // (the fetch ran: a depth is never negative)
+                wr = vis && voxel_tsdf(a, k, p, tsdf);
+            }
+            if (__builtin_amdgcn_ballot_w64(gathered) == 0) {   // no lane gathered: the refill has not gone out, and nothing is consumed
+                if (dimg.rf.has) {
+                    if (z + 1 >= zb && z + 1 < ze) lds_dma3(lane_off, dimg.rf.pv, dimg.rf.pg, dimg.rf.pw, dimg.rf.lds);
+                    // plane j + 1's state must have landed when trip j + 1 consumes it: its wait leaves only that trip's own three requests out
+                }
+                continue;
+            }
+            if (wr) {
+                const unsigned v0 = s_ring[wave][slot][0][lane], g0 = s_ring[wave][slot][1][lane], w0 = s_ring[wave][slot][2][lane];
+                float ov, og; int ow;
+                running_mean(a, tsdf, __uint_as_float(v0), __uint_as_float(g0), (int)w0, ov, og, ow);
+                char *qv = const_cast<char *>(pv) + j * plane_bytes, *qg = const_cast<char *>(pg) + j * plane_bytes, *qw = const_cast<char *>(pw) + j * plane_bytes;
+                if ((__float_as_uint(ov) ^ v0) | always) *reinterpret_cast<float *>(qv + lane_off) = ov;
+                if (((unsigned)ow ^ w0) | always) *reinterpret_cast<int *>(qw + lane_off) = ow;
+                if ((__float_as_uint(og) ^ g0) | always) *reinterpret_cast<float *>(qg + lane_off) = og;
+                ++n_upd;
+            }
+        }
+    }
+    if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
+}
 
 static void load_mat(const float *p, MatS33 &m) {
     for (int r = 0; r < 3; ++r) {
@@ -714,6 +850,9 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // rocprofv3 times
         // (either event may be null: a completion event alone lets another stream wait for this kernel without a marker packet)
         void (*kern)(const IntegrateArgs) = threshold > 0.0f ? k_integrate_bricks<true> : k_integrate_bricks<false>;
+        static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel
+        if (env_k && !strcmp(env_k, "ring") && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
+            kern = k_integrate_bricks_ring<false>;
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, 0, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
