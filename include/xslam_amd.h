@@ -29,6 +29,17 @@ extern "C" {
 #endif
 
 const char *xs_last_error(void);
+
+/* floor(p / voxel_size) in the raycast march without a divide (a reciprocal product with one fused residual correction), used ONLY
+ * for constants that xs_const_div_prepare has checked — on the device, every one of the 2^32 float operands against the divide (~2 ms
+ * and one synchronisation per new constant; the verdict is kept in a process-wide table).  Returns bit 1: floor(short form) ==
+ * floor(divide) for all |x| <= 2^60 (what the march uses), bit 0: the quotients are bit-identical for 2^-60 <= |x| <= 2^60 and +-0
+ * (recorded only); 0: no device / constant outside [2^-20, 2^20].  xs_raycast called with a voxel_size that was never prepared
+ * (xs_const_div_state == 0) brackets the quotient with two reciprocal products and divides where they disagree — same results.
+ * The orchestrator prepares voxel_size in AllocateBuffers. */
+unsigned xs_const_div_prepare(float c);
+unsigned xs_const_div_state(float c);
+int xs_const_div_enable(int on);   /* test aid: 0 = every launcher divides whatever has been prepared; returns the previous setting */
 /* ABI version, bumped on any signature change */
 int xs_abi_version(void);
 

@@ -235,6 +235,44 @@ def test_raycast(dev, oracle, n):
             assert np.array_equal(a_[p * H:(p + 1) * H][valid], b_[p * H:(p + 1) * H][valid])
 
 
+def test_short_division_in_the_march_is_the_divide(dev, oracle):
+    """xs_const_div_prepare checks a constant over all 2^32 operands on the device; the raycast march then takes floor(p / voxel_size)
+    with a reciprocal product + one fused residual (xs_device.h: ConstDiv).  Every voxel size and focal length the configurations use
+    passes both criteria, and the raycast (march + crossing, and the slab march) gives the SAME BITS with the short form switched off."""
+    torch, capi = dev
+    for c in (0.03, 0.015, 0.0075, 0.01, 0.02, 0.08, 481.2, -480.0, 585.0, 525.0, float(np.float32(7.68) / np.float32(96))):
+        assert capi.const_div_prepare(c) == 3, c
+        assert capi.const_div_state(c) == 3
+    assert capi.const_div_state(0.123456) == 0          # never prepared: the bracketed reciprocals
+    assert capi.const_div_prepare(0.0) == 0 and capi.const_div_prepare(float("nan")) == 0 and capi.const_div_prepare(1e-9) == 0
+    n = 96
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    v, w, g = build_volume(oracle, prm, n, [0, 1])
+    T = s1_transforms(2, prm)
+    out = {}
+    for on in (1, 0):
+        was = capi.const_div_enable(on)
+        try:
+            assert capi.const_div_state(prm["tsdf_voxel_size"]) == (3 if on else 0)
+            vm = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+            nm = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+            ws = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+            capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"],
+                         to_dev(torch, v), to_dev(torch, g), n * 4, vm, nm, W * 8, H, W, workspace=ws)
+            keys = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+            vs_, ns_ = torch.zeros_like(vm), torch.zeros_like(nm)
+            capi.raycast_slab(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"],
+                              to_dev(torch, v), to_dev(torch, g), n * 4, 0, n, 0, n, vs_, ns_, W * 8, H, W, keys)
+            torch.cuda.synchronize()
+            out[on] = [t.cpu().numpy() for t in (vm, nm, ws, keys, vs_, ns_)]
+        finally:
+            capi.const_div_enable(was)
+    for a_, b_ in zip(out[1], out[0]):
+        assert np.array_equal(a_.view(np.int32), b_.view(np.int32))      # bit patterns, NaN sentinels and signed zeros included
+    assert np.isfinite(out[1][0][:H, :, 0]).mean() > 0.5
+
+
 def test_raycast_empty_volume(dev, oracle):
     torch, capi = dev
     n = 64

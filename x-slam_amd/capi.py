@@ -109,6 +109,9 @@ _SIGS = {
     "xs_csfd_array_op": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
     "xs_dcsfd_f1": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     "xs_complex_table": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
+    "xs_const_div_prepare": (C.c_uint, [C.c_float]),
+    "xs_const_div_state": (C.c_uint, [C.c_float]),
+    "xs_const_div_enable": (C.c_int, [C.c_int]),
 }
 
 
@@ -120,6 +123,31 @@ def _bind():
 
 
 _bind()
+
+
+def const_div_prepare(c):
+    """xs_const_div_prepare: the exhaustive device check that lets the kernels divide by the constant c with the short form."""
+    return int(_lib.xs_const_div_prepare(float(c)))
+
+
+def const_div_state(c):
+    return int(_lib.xs_const_div_state(float(c)))
+
+
+def const_div_enable(on):
+    return int(_lib.xs_const_div_enable(int(bool(on))))
+
+
+_prepared = set()
+
+
+def _prep(*consts):
+    """The wrappers below prepare the constants their kernels divide by, as the C++ orchestrator does in AllocateBuffers."""
+    for c in consts:
+        c = float(np.float32(c))
+        if c not in _prepared:
+            _prepared.add(c)
+            _lib.xs_const_div_prepare(c)
 
 
 def check(rc):
@@ -344,6 +372,7 @@ def resize_nmap(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
 def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols,
             hits=None, workspace=None, stream=None):
     r = _ia(res, 3)
+    _prep(voxel_size)
     k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
@@ -353,6 +382,7 @@ def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, gr
 def raycast_slab(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap,
                  map_step, rows, cols, keys, stream=None):
     r = _ia(res, 3)
+    _prep(voxel_size)
     k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast_slab(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),

@@ -54,6 +54,36 @@ __host__ __device__ __forceinline__ float qnan_f() {  // cx.h:158: __int_as_floa
 #endif
 }
 
+// floor(x / c) for a launch constant c > 0 without a divide: q = x * r with r = RN(1 / c), one fused residual e = q * c - x
+// (exact), q - e * r.  For r correctly rounded this is the correctly rounded quotient (Markstein) wherever nothing underflows — and
+// it is not taken on trust: xs_const_div_prepare(c) runs both forms over all 2^32 operands on the device (2 ms) and the short form is
+// used for a constant only after that.  `ok` bit 1: floor(short form) == floor(x / c) for every |x| <= 2^60, denormals and zeros
+// included (the voxel-index use); bit 0: the quotients themselves are bit-identical for 2^-60 <= |x| <= 2^60 and +-0 (written this
+// way the residual keeps the sign of a zero) — recorded, but no kernel uses it: with a launch-constant divisor the compiler hoists half
+// of the IEEE sequence out of the loops and the short quotient with its domain guard measured slower (xs_raycast.hip, voxel_index).
+// Explicit fma builtins: the library is built with -ffp-contract=off.
+struct ConstDiv { float c, rc; unsigned ok; };
+__device__ __forceinline__ float div_short(float x, float c, float rc) {
+    const float q = x * rc;
+    const float e = __builtin_fmaf(q, c, -x);
+    return __builtin_fmaf(e, -rc, q);
+}
+__device__ __forceinline__ int cvt_floor(float v) {  // (int)floorf(v) in one instruction
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+template <bool SHORT> __device__ __forceinline__ int floor_div_by(float x, const ConstDiv &d) {   // (int)floorf(x / c)
+    if (!SHORT) return __float2int_rd(x / d.c);
+    // branch-free: beyond 2^60 — where the check does not reach — the plain product x * r stands in: for 2^-20 <= c <= 2^20
+    // (xs_const_div_prepare refuses others) it and the quotient both exceed 2^39 in magnitude, or are both the same infinity or
+    // both NaN, and the conversion saturates alike
+    const float q0 = x * d.rc;
+    const float e = __builtin_fmaf(q0, d.c, -x);
+    const float q1 = __builtin_fmaf(e, -d.rc, q0);
+    return cvt_floor(fabsf(x) <= 0x1p60f ? q1 : q0);
+}
+
 template <class T> __device__ __forceinline__ T *row_ptr(T *base, size_t step, int y) { return (T *)((char *)base + (size_t)y * step); }
 template <class T> __device__ __forceinline__ const T *row_ptr(const T *base, size_t step, int y) {
     return (const T *)((const char *)base + (size_t)y * step);

@@ -13,12 +13,14 @@
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
+xs::ConstDiv xs_const_div_get(float c);   // xs_constdiv.hip
 
 struct RaycastArgs {
     MatS33 Rc2v; cfloat3 tc2v; MatS33 Rv2w; cfloat3 tv2w;
     int X, Y, Z;
     float voxel_size, time_step;
-    float inv_vs_lo, inv_vs_hi;  // 1/voxel_size nudged 4 ulp down / up (march index shortcut)
+    float inv_vs_lo, inv_vs_hi;  // 1/voxel_size nudged 4 ulp down / up (march index shortcut when the constant is not prepared)
+    ConstDiv dv;                 // division by voxel_size (xs_const_div_prepare)
     int cols, rows;
     const float *value; const float *grad; size_t vstep;
     Intr intr;
@@ -43,7 +45,14 @@ __device__ __forceinline__ int cvt_flr(float v) {  // (int)floorf(v) in one inst
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
-__device__ __forceinline__ int voxel_index(float p, float vs, float r_lo, float r_hi) {
+template <bool SHORT>
+__device__ __forceinline__ int voxel_index(float p, float vs, float r_lo, float r_hi, const ConstDiv &dv) {
+    // SHORT (the march kernels, when xs_const_div_prepare has checked voxel_size over all 2^32 operands): the exact short division,
+    // six branch-free instructions; else two reciprocal products that bracket the quotient, with the divide where they disagree.
+    // (Measured, round 3: march 48-51 us against 52-53; the crossing kernel and the integrate band keep their IEEE divides — the
+    // compiler hoists the divisor's half of that sequence (v_rcp, v_div_scale, refinement) out of the loop as the divisor is a launch
+    // constant, so a divide costs ~6 instructions there, and the short form made the crossing 8-18 % SLOWER: profiles/r03_ab_const_div.txt)
+    if (SHORT) return floor_div_by<true>(p, dv);
     const int f_lo = cvt_flr(p * r_lo), f_hi = cvt_flr(p * r_hi);
     if (__builtin_expect(f_lo == f_hi, 1)) return f_lo;
     return __float2int_rd(p / vs);
@@ -167,7 +176,7 @@ struct Vol {
 // (crossing kernels: five waves per SIMD — a 640 x 480 frame is 4 800 waves on 1 024 SIMDs, all resident at once; the
 // two-samples-per-round-trip form would otherwise take 104 registers, i.e. four)
 constexpr int raycast_min_waves(int mode) { return mode == 3 || mode == 5 ? 5 : 1; }
-template <int MODE, bool OFF32>
+template <int MODE, bool OFF32, bool SHORT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycast_min_waves(MODE)))) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1 || MODE == 4 || MODE == 5;
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
@@ -305,9 +314,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                 for (int j = 0; j < NS; ++j) {
                     tc[j] = t;
                     const float tn = t + time_step;
-                    const int jx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
-                    const int jy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
-                    const int jz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const int jx = voxel_index<SHORT>(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                    const int jy = voxel_index<SHORT>(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                    const int jz = voxel_index<SHORT>(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
                     const bool inb = (unsigned)jx < (unsigned)a.X && (unsigned)jy < (unsigned)a.Y && (unsigned)jz < (unsigned)a.Z;
                     const bool st = inb && jz >= a.zs0 && jz < a.zs1;
                     term |= ((t < max_time) && inb ? 0u : 1u) << j;
@@ -356,9 +365,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
             int pgx = gx, pgy = gy, pgz = gz;
             for (; time_curr < max_time; time_curr += time_step, ++step_index) {
                 const float tn = time_curr + time_step;
-                gx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);  // floor(p / vs) without the divide
-                gy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
-                gz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                gx = voxel_index<SHORT>(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);  // floor(p / vs) without the divide
+                gy = voxel_index<SHORT>(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                gz = voxel_index<SHORT>(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
                 if (!(gx >= 0 && gy >= 0 && gz >= 0 && gx < a.X && gy < a.Y && gz < a.Z)) break;
                 const bool owned = gz >= a.z0 && gz < a.z1;
                 const int qx = pgx, qy = pgy, qz = pgz;
@@ -395,9 +404,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                 for (int j = 0; j < NS; ++j) {
                     tc[j] = t;
                     const float tn = t + time_step;
-                    const int jx = voxel_index(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
-                    const int jy = voxel_index(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
-                    const int jz = voxel_index(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi);
+                    const int jx = voxel_index<SHORT>(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                    const int jy = voxel_index<SHORT>(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                    const int jz = voxel_index<SHORT>(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
                     // (one unsigned compare per axis; a step outside reads voxel (0, 0, first plane), always resident,
                     // and its value is never looked at)
                     const bool ok = (t < max_time) && (unsigned)jx < (unsigned)a.X && (unsigned)jy < (unsigned)a.Y && (unsigned)jz < (unsigned)a.Z;
@@ -455,6 +464,7 @@ static void set_inv_vs(RaycastArgs &a) {
     float lo = 1.0f / a.voxel_size, hi = lo;
     for (int i = 0; i < 4; ++i) { lo = nextafterf(lo, 0.f); hi = nextafterf(hi, INFINITY); }
     a.inv_vs_lo = lo; a.inv_vs_hi = hi;
+    a.dv = xs_const_div_get(a.voxel_size);
 }
 static void ld_mat(const float *p, MatS33 &m) {
     for (int r = 0; r < 3; ++r) {
@@ -499,15 +509,15 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     if (workspace) {
         // march (few registers, many waves, eight gathers in flight per lane) then the crossings
         a.hits = nullptr;
-        if (off32) hipLaunchKernelGGL((k_raycast<2, true>), grid, block, 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_raycast<2, false>), grid, block, 0, (hipStream_t)stream, a);
+        if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<2, true, true> : k_raycast<2, true, false>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_raycast<2, false, false>), grid, block, 0, (hipStream_t)stream, a);
         a.hits = hits_dev;
-        if (off32) hipLaunchKernelGGL((k_raycast<3, true>), grid, block, 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_raycast<3, false>), grid, block, 0, (hipStream_t)stream, a);
+        if (off32) hipLaunchKernelGGL((k_raycast<3, true, false>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_raycast<3, false, false>), grid, block, 0, (hipStream_t)stream, a);
     } else if (off32)
-        hipLaunchKernelGGL((k_raycast<0, true>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<0, true, false>), grid, block, 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((k_raycast<0, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<0, false, false>), grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -544,11 +554,11 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
     if (fits32(a)) {
-        hipLaunchKernelGGL((k_raycast<4, true>), grid, block, 0, (hipStream_t)stream, a);
-        hipLaunchKernelGGL((k_raycast<5, true>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<4, true, true> : k_raycast<4, true, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<5, true, false>), grid, block, 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL((k_raycast<4, false>), grid, block, 0, (hipStream_t)stream, a);
-        hipLaunchKernelGGL((k_raycast<5, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<4, false, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_raycast<5, false, false>), grid, block, 0, (hipStream_t)stream, a);
     }
     XS_CHECK(hipGetLastError());
     return 0;

@@ -150,6 +150,9 @@ void KinectFusionReconstruction::AllocateBuffers() {
         }
     }
     depthRawScaled_d.create(depth_height, depth_width);
+    // the constant the raycast march divides by, checked once (all 2^32 operands, ~2 ms): it then takes floor(p / voxel_size) with the
+    // short division; a constant that fails its check keeps the bracketed reciprocals + divide, same results
+    xs_const_div_prepare(voxel_size);
     {
         const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
         integrate_ws_.create(xs_integrate_workspace_bytes(res, zs1 - zs0));
