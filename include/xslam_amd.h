@@ -178,6 +178,10 @@ int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, cons
                float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
                void *stream);
+/* Measurement hook (bench.py, SURVEY 8(d): "Raycast: report Mrays/s and steps/ray"): a device buffer of rows x cols ints that the
+ * following xs_raycast calls of this thread fill with each ray's march length — the iterations the reference's loop (RayCaster.cu:222-247)
+ * runs for it; NULL switches it off. */
+void xs_raycast_set_step_buffer(int *steps_dev);
 
 /* Slab form for a z-sharded volume (the reference is single-GPU; per-ray semantics are those of
  * RayCaster.cu:197-310).  value / grad hold planes [zs0, zs1) = owned slab + halo (6 planes);

@@ -287,6 +287,55 @@ def test_posted_pose_loop_is_bit_identical_to_launch_after_solve(dev, lookahead)
     a.close(); b.close()
 
 
+def test_posted_pose_numbers_cross_the_2_to_32_wrap(dev):
+    """The mailbox sequence number of a posted launch is the low word of its completion number, and a poller accepts any post at or
+    after its own number in the modulo-2^32 order: the numbers must stay monotone across the wrap, with 0 (the mailbox's initial word)
+    skipped.  A run whose launch numbers start 30 below 2^32 — the wrap falls inside frame 3's twelve launches — gives the same sums,
+    poses and volume as a run numbered from 0, and no launch times out."""
+    torch, pl = dev
+    prm = synth.s1_params(96)
+    a = pl.KinectFusion(dict(prm, icp_post_pose=True))
+    b = pl.KinectFusion(dict(prm, icp_post_pose=True))
+    d0 = upload(torch, synth.s1_frame(0))
+    assert a.process_frame(d0) == 1 and b.process_frame(d0) == 1
+    a.debug_set_icp_sequence((1 << 32) - 30)
+    for k in range(1, 7):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1, k
+        assert np.array_equal(a.icp_log(), b.icp_log()), k
+        assert np.array_equal(a.world2camera(), b.world2camera()), k
+    for x, y in zip(a.volume(), b.volume()):
+        assert np.array_equal(x, y)
+    times = a.icp_iteration_times()
+    assert [times[lv][1] for lv in range(3)] == [6 * 5, 6 * 4, 6 * 3] and all(0.0 < times[lv][0] / times[lv][1] < 5e4 for lv in range(3))
+    a.close(); b.close()
+
+
+def test_alignment_failure_after_the_bricks_were_classified_ahead(dev):
+    """The brick classification of the integrate call is enqueued behind the last ICP launch; if that last iteration then fails (forced
+    here: the determinant gate of iteration 11), IntegrateFrame never runs and the list must not survive into the retried frame — whose
+    map preparation clears the workspace header and rewrites the depth maximum on the auxiliary stream.  The retry and the following
+    frames give the same poses, counts and volume as a run that never failed."""
+    torch, pl = dev
+    prm = synth.s1_params(128)
+    a = pl.KinectFusion(dict(prm, integrate_classify_ahead=True))
+    b = pl.KinectFusion(dict(prm, integrate_classify_ahead=True))
+    for k in range(3):
+        d = upload(torch, synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+    for k in range(3, 7):
+        d = upload(torch, synth.s1_frame(k))
+        if k in (3, 5):
+            a.debug_fail_icp_iteration(11)
+            assert a.process_frame(d) == 0 and a.frame_id == k     # lost: the same frame is offered again
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+        assert np.array_equal(a.world2camera(), b.world2camera()), k
+        assert a.last_U() == b.last_U() and a.last_hits() == b.last_hits(), k
+    for x, y in zip(a.volume(), b.volume()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_pipeline_gt_pose_mode_s2(dev, oracle):
     """flag_use_gtPose: only surface measure + integrate + raycast run (scene S2 at a small size)."""
     torch, pl = dev

@@ -109,6 +109,7 @@ _SIGS = {
     "xs_csfd_array_op": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
     "xs_dcsfd_f1": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     "xs_complex_table": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
+    "xs_raycast_set_step_buffer": (None, [_vp]),
     "xs_const_div_prepare": (C.c_uint, [C.c_float]),
     "xs_const_div_state": (C.c_uint, [C.c_float]),
     "xs_const_div_enable": (C.c_int, [C.c_int]),
@@ -377,6 +378,11 @@ def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, gr
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
                           vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _ptr(workspace), _stream(stream)))
+
+
+def raycast_set_step_buffer(buf):
+    """Per-ray march lengths of the following raycast calls go to buf (rows x cols int32 on the device); None switches it off."""
+    _lib.xs_raycast_set_step_buffer(_ptr(buf))
 
 
 def raycast_slab(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap,

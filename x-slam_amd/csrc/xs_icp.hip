@@ -17,6 +17,12 @@
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
+// The record hand-offs below (relaxed agent-scope stores + s_waitcnt vmcnt(0) + a relaxed ticket, no release fence) are correct because
+// gfx942 / gfx950 implement an agent-scope atomic store as a write-through (sc1) store that is acknowledged from memory; that is
+// outside the HIP / LLVM memory model, so the file refuses to build for anything else rather than publish stale records there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "write-through record publish: gfx942 / gfx950 only (use a release fence + acq_rel ticket on other targets)"
+#endif
 
 struct IcpArgs {
     MatS33 Rcurr; cfloat3 tcurr;

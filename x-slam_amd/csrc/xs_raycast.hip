@@ -31,6 +31,7 @@ struct RaycastArgs {
     float *cross_t; // two-kernel path: per pixel, the march time of the step before the crossing (or < 0)
     int *keys;     // slab mode: per pixel, (step << 1 | no_hit) of the first event among owned steps, INT_MAX if none
     unsigned long long *hits;
+    int *steps;    // optional (measurement): per pixel, the march iterations the reference's loop (RayCaster.cu:222-247) runs for this ray
 };
 
 namespace {
@@ -392,6 +393,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
             float tsdf = vol.read_value(gx, gy, gz);
             float cross = -1.f;
             bool done = false;
+            int nsteps = 0;   // iterations of the reference's loop so far (only stored when a.steps is given)
             while (!done && time_curr < max_time) {
                 // eight steps at once, straight-line: positions, clamped (always valid) gathers, then one
                 // event mask — out of range / past the end, - to + (no vertex), + to - (crossing) — whose
@@ -426,18 +428,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                 const unsigned ev = oob | down | up;
                 if (ev) {
                     const int e = __ffs(ev) - 1;
-                    if (!((oob >> e) & 1u) && ((down >> e) & 1u)) {
-                        float tce = tc[0];
+                    float tce = tc[0];
 #pragma unroll
-                        for (int j = 1; j < NS; ++j) tce = (e == j) ? tc[j] : tce;
+                    for (int j = 1; j < NS; ++j) tce = (e == j) ? tc[j] : tce;
+                    if (!((oob >> e) & 1u) && ((down >> e) & 1u)) {
                         if (MODE == 2) cross = tce; else hit = crossing(tce, tce + time_step);
                     }
+                    // the reference's loop runs iteration e of this batch unless its own condition (time_curr < max_time) ends it first
+                    nsteps += e + (tce < max_time ? 1 : 0);
                     done = true;
-                }
+                } else
+                    nsteps += NS;
                 tsdf = val[NS - 1];
                 time_curr = t;
             }
             if (MODE == 2) a.cross_t[y * a.cols + x] = cross;
+            if (a.steps) a.steps[y * a.cols + x] = nsteps;
         }
         if (SLAB) a.keys[y * a.cols + x] = key;  // (MODE 5 rewrites the key it read: even where the crossing gave a vertex)
     }
@@ -454,6 +460,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
         }
     }
 }
+
+// measurement hook (bench.py): a device buffer of rows x cols ints that the single-GPU march fills with every ray's step count
+static thread_local int *g_ray_steps = nullptr;
+extern "C" void xs_raycast_set_step_buffer(int *steps_dev) { g_ray_steps = steps_dev; }
 
 // do the resident planes of one volume array span at most 4 GiB (and the 24-bit products hold)?
 static bool fits32(const RaycastArgs &a) {
@@ -501,7 +511,7 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
-    a.hits = hits_dev; a.cross_t = workspace;
+    a.hits = hits_dev; a.cross_t = workspace; a.steps = g_ray_steps;
     static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
     a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
@@ -549,7 +559,7 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
-    a.hits = nullptr; a.cross_t = nullptr;
+    a.hits = nullptr; a.cross_t = nullptr; a.steps = nullptr;
     static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
     a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);

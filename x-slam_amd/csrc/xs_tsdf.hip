@@ -23,6 +23,12 @@
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
+// The record hand-offs below (relaxed agent-scope stores + s_waitcnt vmcnt(0) + a relaxed ticket, no release fence) are correct because
+// gfx942 / gfx950 implement an agent-scope atomic store as a write-through (sc1) store that is acknowledged from memory; that is
+// outside the HIP / LLVM memory model, so the file refuses to build for anything else rather than publish stale records there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "write-through record publish: gfx942 / gfx950 only (use a release fence + acq_rel ticket on other targets)"
+#endif
 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_init_volume(float *value, int *weight, float *grad, size_t step, int X, long long rows) {
@@ -812,7 +818,12 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: the flags concern the workspace path");
     if (z0 < 0 || z1 > res[2] || z1 < z0 || (vol_step % 4) != 0 || vol_step < (size_t)res[0] * 4)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: bad slab or pitch");
-    if (z1 == z0 || res[0] == 0 || res[1] == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (z1 == z0 || res[0] == 0 || res[1] == 0) {   // nothing to launch: the caller's timing / completion events are recorded all the same
+        if (g_int_ev0) XS_CHECK(hipEventRecord(g_int_ev0, st));
+        if (g_int_ev1) XS_CHECK(hipEventRecord(g_int_ev1, st));
+        return 0;
+    }
     IntegrateArgs a;
     a.depth = depth_scaled; a.dstep = scaled_step; a.drows = rows; a.dcols = cols;
     a.value = value; a.weight = weight; a.grad = grad; a.vstep = vol_step;
@@ -830,7 +841,6 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
     a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, a.brick_z);
     a.zchunk = nz;
-    hipStream_t st = (hipStream_t)stream;
     dim3 block(64, 4);
     if (workspace && a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047) {  // packed brick ids: 10 + 10 + 11 bits
         a.brick_count = (unsigned *)workspace;
@@ -862,10 +872,11 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
         a.zchunk = div_up(nz, zsplit);
         dim3 grid(gx, gy, div_up(nz, a.zchunk));
-        if (threshold > 0.0f)
-            hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, st, a);
-        else
-            hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, st, a);
+        // (the events xs_integrate_set_timing_events handed over ride on this dispatch too: a caller that waits on the stop event — the
+        // orchestrator's auxiliary stream does — must find it recorded whichever kernel ran)
+        void (*kern)(const IntegrateArgs) = threshold > 0.0f ? k_integrate<true> : k_integrate<false>;
+        if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, grid, block, 0, st, g_int_ev0, g_int_ev1, 0, a);
+        else hipLaunchKernelGGL(kern, grid, block, 0, st, a);
     }
     XS_CHECK(hipGetLastError());
     return 0;

@@ -3,6 +3,7 @@
 // launcher shim.  One stream, no per-frame allocation, synchronisation only where the host
 // needs a result (the 6x6 normal equations of each ICP iteration).
 #include "KinectFusionReconstruction.h"
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -341,12 +342,16 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
     auto enqueue_through = [&](int last, MatS33 *R0, devComplex3 *t0) {
         for (; enqueued < total_iters && enqueued <= last; ++enqueued) {
             if (enqueued == 0) { seq_of[0] = launch_local(level_of[0], R0, t0, 0); continue; }
-            unsigned m = (unsigned)(icp_seq_ + 1);
-            if (m == 0) m = 1u << 31;  // never the mailbox's initial word
+            // the mailbox sequence number is the low word of the launch's completion number; a poller accepts any post at or after its
+            // own number in the modulo-2^32 order, so the numbers must stay monotone there: 0 (the mailbox's initial word) is skipped
+            // by spending one completion number, not replaced by an out-of-order value
+            if ((unsigned)(icp_seq_ + 1) == 0u) ++icp_seq_;
+            const unsigned m = (unsigned)(icp_seq_ + 1);
             mail_of[enqueued] = m;
             seq_of[enqueued] = launch_local(level_of[enqueued], nullptr, nullptr, m);
         }
     };
+    auto t_prev = std::chrono::steady_clock::now();
     for (int n = 0; n < total_iters; ++n) {
         {
             const int level_index = level_of[n];
@@ -378,6 +383,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                     hipSafeCall(hipStreamSynchronize(current_stream()));
                     check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
                     stage_end(ST_ICP);
+                    AbandonClassifiedList();
                     std::cout << "error::KinectFusionReconstruction, ICP launch timed out waiting for its pose" << std::endl;
                     return 0;
                 };
@@ -401,6 +407,12 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 inliers = (long long)pinned_sums_[54];
             } else
                 icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
+            if (level_index < 3) {   // this iteration's sums are in: the period since the previous iteration's were
+                const auto t_now = std::chrono::steady_clock::now();
+                icp_level_us[level_index] += std::chrono::duration<double, std::micro>(t_now - t_prev).count();
+                ++icp_level_calls[level_index];
+                t_prev = t_now;
+            }
             // The solve and the post come first: the enqueued launch is waiting for them.
             hostComplexICP sol[6];
             llt_solve6(A, b, sol);
@@ -417,7 +429,8 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
             // before the post — the enqueued launch of a singular system is told to leave (cmd 1) instead of running
             // unobserved on maps the next frame's preparation may already be rewriting
             const double det = real_determinant6(A);
-            const bool singular = fabs(det) < 1e-15 || std::isnan(det);
+            bool singular = fabs(det) < 1e-15 || std::isnan(det);
+            if (debug_fail_icp_iteration_ == n) { singular = true; debug_fail_icp_iteration_ = -1; }   // (test aid)
             if (next_enqueued) {
                 if (singular) xs_icp_post_pose(mailbox, nullptr, nullptr, last_mail_seq, 1);
                 else xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rnext).data[0].x.re, &device_cast<devComplex3>(tnext).x.re, next_mail_seq, 0);
@@ -436,6 +449,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 if (std::isnan(det)) std::cout << "qnan det" << std::endl;
                 else std::cout << "eps det: " << fabs(det) << std::endl;
                 stage_end(ST_ICP);
+                AbandonClassifiedList();
                 return 0;
             }
             tcurr = tnext;
@@ -591,6 +605,25 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
                                    tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
                                    integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
     list_ready_ = true;
+}
+
+// A frame whose alignment fails after ClassifyAhead has run never reaches IntegrateFrame: the classification kernel is still in the main
+// stream, has filled the workspace header, and reads the frame's depth maximum — while the retried frame's SurfaceMeasure clears that header
+// and rewrites the maximum on the auxiliary stream, ordered only behind the previous frame's integrate kernel.  So the failure path (rare: a
+// singular system, a launch that timed out) drains the main stream, clears the header there and forgets the list.
+void KinectFusionReconstruction::AbandonClassifiedList() {
+    if (!list_ready_) return;
+    list_ready_ = false;
+    check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), current_stream()), "integrate workspace");
+    hipSafeCall(hipStreamSynchronize(current_stream()));
+    integrate_header_clear_ = true;
+}
+void KinectFusionReconstruction::DebugSetIcpSequence(unsigned long long v) {
+    synchronize();
+    icp_seq_ = v;
+    // the mailbox holds the number of the last post: bring it up to date, or a launch numbered just above v would take the stale, smaller
+    // number for a later one after the 2^32 wrap (an abandon command nobody is waiting for)
+    if (icp_mailbox_ && (unsigned)v != 0u) xs_icp_post_pose(icp_mailbox_, nullptr, nullptr, (unsigned)v, 1);
 }
 
 int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &depth_frame_d) {

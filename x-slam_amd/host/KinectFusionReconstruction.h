@@ -216,6 +216,17 @@ private:
     void *icp_mailbox_ = nullptr;              // pose mailbox of the posted ICP launches (xs_icp_mailbox_alloc)
     int icp_mailbox_in_device_ = 0;
     unsigned long long icp_seq_ = 0;
+public:
+    // host wall clock of the ICP loop per pyramid level: from the completion of one iteration's sums to the completion of the next one's
+    // (kernel + completion word over PCIe + solve + post) — SURVEY 8(d): "ICP: report us per iteration".  Always on: two clock reads.
+    double icp_level_us[3] = {0, 0, 0};
+    long long icp_level_calls[3] = {0, 0, 0};
+    // test aids: start the launch sequence numbers at `v` (the mailbox is told); make the determinant gate fail at iteration n of the
+    // next PoseEstimate (-1: off)
+    void DebugSetIcpSequence(unsigned long long v);
+    int debug_fail_icp_iteration_ = -1;
+private:
+    void AbandonClassifiedList();
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
     hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr, scale_done_ = nullptr;
     hipEvent_t integrate_done_now_ = nullptr;   // the event that marks the last integrate call's completion (integrate_done_, or its dispatch's stop event)

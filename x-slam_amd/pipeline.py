@@ -51,6 +51,9 @@ _SIGS = {
     "xs_kf_set_profiling": (None, [_vp, C.c_int]),
     "xs_kf_stage_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_reset_stage_times": (None, [_vp]),
+    "xs_kf_icp_iteration_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
+    "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
+    "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
     "xs_kf_cumulative_counters": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
@@ -255,6 +258,19 @@ class KinectFusion:
 
     def reset_stage_times(self):
         _lib.xs_kf_reset_stage_times(self.h)
+
+    def icp_iteration_times(self):
+        """{level: (microseconds summed, iterations)} of the ICP loop's host-side iteration period since the last reset."""
+        us = np.zeros(3, np.float64)
+        calls = (C.c_longlong * 3)()
+        _lib.xs_kf_icp_iteration_times(self.h, us.ctypes.data_as(_f64p), calls)
+        return {lv: (float(us[lv]), int(calls[lv])) for lv in range(3)}
+
+    def debug_set_icp_sequence(self, v):
+        _lib.xs_kf_debug_set_icp_sequence(self.h, int(v))
+
+    def debug_fail_icp_iteration(self, n):
+        _lib.xs_kf_debug_fail_icp_iteration(self.h, int(n))
 
     def save_checkpoint(self, path):
         _lib.xs_kf_save_checkpoint(self.h, path.encode())
