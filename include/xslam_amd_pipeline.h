@@ -104,10 +104,11 @@ void xs_kf_stage_times(void *kf, double *ms6, long long *calls6);
 /* voxels written / raycast hits summed over the frames processed with profiling on */
 void xs_kf_cumulative_counters(void *kf, long long *updated, long long *hits);
 void xs_kf_reset_stage_times(void *kf);
-/* Host wall clock of the ICP loop per pyramid level (index = level, 0 = full resolution): microseconds summed over the iterations run
- * since the last xs_kf_reset_stage_times, and their count — the period from one iteration's sums arriving to the next one's (kernel,
- * completion word, 6x6 solve, pose post).  ICP.cu:395-417 is a launch + device sync + copy per iteration.  Always on. */
-void xs_kf_icp_iteration_times(void *kf, double *us3, long long *calls3);
+/* Host wall clock of the ICP loop per pyramid level (index = level, 0 = full resolution; index 3 = the first iteration of each frame,
+ * kept apart because it also waits for the stream to drain the previous frame's tail): microseconds summed over the iterations run since
+ * the last xs_kf_reset_stage_times, and their count — the period from one iteration's sums arriving to the next one's (kernel, completion
+ * word, 6x6 solve, pose post).  ICP.cu:395-417 is a launch + device sync + copy per iteration.  Always on. */
+void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4);
 /* Test aids.  Start the ICP launch sequence numbers at v (exercises the 2^32 wrap of the mailbox numbers); make the determinant gate of
  * iteration n (0-based, over all levels) of the next alignment fail as for a singular system (KinectFusionReconstruction.cpp:203-210). */
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v);

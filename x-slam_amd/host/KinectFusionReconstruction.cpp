@@ -409,8 +409,9 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 icp_normal_equations(device_Rcurr, device_tcurr, device_Rprev_inv, device_tprev, level_index, A, b, &inliers);
             if (level_index < 3) {   // this iteration's sums are in: the period since the previous iteration's were
                 const auto t_now = std::chrono::steady_clock::now();
-                icp_level_us[level_index] += std::chrono::duration<double, std::micro>(t_now - t_prev).count();
-                ++icp_level_calls[level_index];
+                const int slot = n == 0 ? 3 : level_index;   // (the frame's first iteration also waits for the previous frame's tail and the map preparation)
+                icp_level_us[slot] += std::chrono::duration<double, std::micro>(t_now - t_prev).count();
+                ++icp_level_calls[slot];
                 t_prev = t_now;
             }
             // The solve and the post come first: the enqueued launch is waiting for them.

@@ -219,8 +219,8 @@ private:
 public:
     // host wall clock of the ICP loop per pyramid level: from the completion of one iteration's sums to the completion of the next one's
     // (kernel + completion word over PCIe + solve + post) — SURVEY 8(d): "ICP: report us per iteration".  Always on: two clock reads.
-    double icp_level_us[3] = {0, 0, 0};
-    long long icp_level_calls[3] = {0, 0, 0};
+    double icp_level_us[4] = {0, 0, 0, 0};          // [3]: the frame's first iteration, which also waits for the stream to drain the previous frame's tail
+    long long icp_level_calls[4] = {0, 0, 0, 0};
     // test aids: start the launch sequence numbers at `v` (the mailbox is told); make the determinant gate fail at iteration n of the
     // next PoseEstimate (-1: off)
     void DebugSetIcpSequence(unsigned long long v);

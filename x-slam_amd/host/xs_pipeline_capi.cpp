@@ -244,11 +244,11 @@ void xs_kf_reset_stage_times(void *kf) {
     if (k->profiling) k->collect_stage_times();
     k->cum_updated = 0; k->cum_hits = 0;
     for (int i = 0; i < KF::ST_COUNT; ++i) { k->stage_ms[i] = 0; k->stage_calls[i] = 0; }
-    for (int i = 0; i < 3; ++i) { k->icp_level_us[i] = 0; k->icp_level_calls[i] = 0; }
+    for (int i = 0; i < 4; ++i) { k->icp_level_us[i] = 0; k->icp_level_calls[i] = 0; }
 }
-void xs_kf_icp_iteration_times(void *kf, double *us3, long long *calls3) {
+void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4) {
     KF *k = (KF *)kf;
-    for (int i = 0; i < 3; ++i) { if (us3) us3[i] = k->icp_level_us[i]; if (calls3) calls3[i] = k->icp_level_calls[i]; }
+    for (int i = 0; i < 4; ++i) { if (us4) us4[i] = k->icp_level_us[i]; if (calls4) calls4[i] = k->icp_level_calls[i]; }
 }
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v) { ((KF *)kf)->DebugSetIcpSequence(v); }
 void xs_kf_debug_fail_icp_iteration(void *kf, int n) { ((KF *)kf)->debug_fail_icp_iteration_ = n; }

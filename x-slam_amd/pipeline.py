@@ -260,11 +260,12 @@ class KinectFusion:
         _lib.xs_kf_reset_stage_times(self.h)
 
     def icp_iteration_times(self):
-        """{level: (microseconds summed, iterations)} of the ICP loop's host-side iteration period since the last reset."""
-        us = np.zeros(3, np.float64)
-        calls = (C.c_longlong * 3)()
+        """{slot: (microseconds summed, iterations)} of the ICP loop's host-side iteration period since the last reset; slots 0..2 = pyramid
+        level, 3 = the first iteration of each frame (which also waits for the previous frame's tail)."""
+        us = np.zeros(4, np.float64)
+        calls = (C.c_longlong * 4)()
         _lib.xs_kf_icp_iteration_times(self.h, us.ctypes.data_as(_f64p), calls)
-        return {lv: (float(us[lv]), int(calls[lv])) for lv in range(3)}
+        return {lv: (float(us[lv]), int(calls[lv])) for lv in range(4)}
 
     def debug_set_icp_sequence(self, v):
         _lib.xs_kf_debug_set_icp_sequence(self.h, int(v))
