@@ -145,6 +145,86 @@ def test_relocalize_recovers_a_perturbed_pose(dev):
     kf.close()
 
 
+def se3_exp_c64(xi):
+    """The reference's se3Exp (KinectFusionReconstruction.h:176-219) restated in numpy complex64, operation for operation: the hat matrix,
+    the small-angle branch on |omega| < 1e-6, A = sin t / t, B = (1 - cos t) / t^2, C = (t - sin t) / t^3 with t = sqrt(omega^T omega)
+    (no conjugation), R = I + A K + B K^2, V = I + B K + C K^2, translation V v."""
+    xi = np.asarray(xi, np.complex64)
+    v, om = xi[:3], xi[3:]
+    K = np.zeros((3, 3), np.complex64)
+    K[0, 1], K[0, 2], K[1, 2] = -om[2], om[1], -om[0]
+    K[1, 0], K[2, 0], K[2, 1] = om[2], -om[1], om[0]
+    I = np.eye(3, dtype=np.complex64)
+    if np.sqrt(np.sum(np.abs(om) ** 2)) < 1e-6:
+        R, V = I + K, I + K
+    else:
+        th = np.sqrt(np.complex64(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]))
+        s_, c_ = np.sin(th), np.cos(th)
+        K2 = (K @ K).astype(np.complex64)
+        A = np.complex64(s_ / th); B = np.complex64((np.complex64(1) - c_) / th ** 2); Cc = np.complex64((th - s_) / th ** 3)
+        R, V = I + A * K + B * K2, I + B * K + Cc * K2
+    T = np.zeros((4, 4), np.complex64)
+    T[:3, :3] = R; T[:3, 3] = V @ v; T[3, 3] = 1
+    return T
+
+
+def test_relocalization_loop_against_an_oracle_twin(dev, oracle):
+    """RelocalizeGaussNewton as a loop (the per-pass kernel had an oracle twin, the host's damped solve + se3Exp step
+    did not).  The twin: the oracle's six-pose kernel for the 29 sums, and around it a numpy restatement of the host step — poses
+    inverse(se3Exp(i h e_k) c2v) in complex64, sums scaled by 1 / h and 1 / h^2, the damped 6x6 system solved by Cholesky in double,
+    the update se3Exp(x) c2v in complex64 (se3Exp restated from the reference's text, above).  Five iterations at 128^3 (scene S3) from a
+    perturbed pose: every intermediate loss and the final camera2volume agree (pose entries within 1e-6)."""
+    torch, capi, pl = dev
+    n = 128
+    prm = synth.s1_params(n)
+    kf = pl.KinectFusion(prm)
+    frames = [synth.s3_frame(k) for k in range(6)]   # the box room: every degree of freedom constrained, so rounding differences are not amplified
+    dfr = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
+    for k in range(6):
+        assert kf.process_frame(dfr[k]) == 1
+    t_true = kf.camera2volume()[..., 0].astype(np.float64)
+    start = twist_matrix(np.array([0.008, -0.006, 0.005, 0.004, -0.005, 0.006])) @ t_true
+    c2v0 = np.zeros((4, 4, 2), np.float32); c2v0[..., 0] = start
+    iters, damping = 5, 1e-3
+    ok, refined, hist = kf.relocalize(dfr[5], c2v0, iterations=iters, damping=damping)
+    assert ok
+    gt = kf.volume()[0]                     # the map the GPU loop aligned to (value plane, dense)
+    kf.close()
+    ds = oracle.scale_depth(frames[5])
+    res, vs, trunc, k4 = [n, n, n], prm["tsdf_voxel_size"], tranc_dist(prm), intr_of(prm)
+    h = np.float32(1e-7)
+    c2v = (c2v0[..., 0] + 1j * c2v0[..., 1]).astype(np.complex64)
+    twin_hist = []
+    def terms(c2v):
+        Rs = np.zeros((6, 3, 3, 2), np.float32); ts = np.zeros((6, 3, 2), np.float32)
+        for k in range(6):
+            xi = np.zeros(6, np.complex64); xi[k] = 1j * h
+            v2c = np.linalg.inv((se3_exp_c64(xi) @ c2v).astype(np.complex128)).astype(np.complex64)
+            Rs[k, ..., 0], Rs[k, ..., 1] = v2c[:3, :3].real, v2c[:3, :3].imag
+            ts[k, :, 0], ts[k, :, 1] = v2c[:3, 3].real, v2c[:3, 3].imag
+        s = oracle.tsdf_gn_terms(ds, res, vs, Rs, ts, trunc, k4, gt)
+        ih = 1.0 / float(h)
+        s = s.copy(); s[:21] *= ih * ih; s[21:27] *= ih
+        return s
+    for it in range(iters):
+        s = terms(c2v)
+        twin_hist.append(s[27] / s[28])
+        A = np.zeros((6, 6)); q = 0
+        for j in range(6):
+            for k in range(j, 6):
+                A[j, k] = A[k, j] = s[q]; q += 1
+        A[np.diag_indices(6)] *= 1.0 + float(np.float32(damping))
+        L = np.linalg.cholesky(A)
+        x = np.linalg.solve(L.T, np.linalg.solve(L, -s[21:27]))
+        c2v = (se3_exp_c64(x.astype(np.float32).astype(np.complex64)) @ c2v).astype(np.complex64)
+    s = terms(c2v)
+    twin_hist.append(s[27] / s[28])
+    assert np.all(np.abs(refined[..., 0] - c2v.real) <= 1e-6), np.abs(refined[..., 0] - c2v.real).max()
+    assert np.all(refined[..., 1] == 0) and np.all(c2v.imag == 0)
+    assert np.allclose(hist, twin_hist, rtol=2e-4, atol=0), (hist, twin_hist)
+    assert hist[-1] < 0.5 * hist[0]
+
+
 def test_residual_kernels_non_cubic_volume(dev, oracle):
     """The three residual kernels (dual-complex Hessian, real loss, six-pose Gauss-Newton terms) over a 96 x 64 x 80 map —
     two columns of 64-wide tiles, the second a half one; planes that are not a multiple of the 32-plane batches — against

@@ -19,8 +19,8 @@ def side_by_side(torch, pl, oracle, scene, n, frames, seed=(0, 3), threshold=0.0
     if twin is not None:
         rec_twin = []
     render = synth.s3_frame if scene == "s3" else synth.s1_frame
-    rec = dict(dpose=[], dderiv_rel=[], deriv_scale=[], dU=[], U=[], dhits=[], hits=[], dinliers=[])
-    rec_twin = []
+    rec = dict(dpose=[], dderiv_rel=[], dderiv_abs=[], deriv_scale=[], dU=[], U=[], dhits=[], hits=[], dinliers=[])
+    rec_twin, rec_twin_deriv = [], []
     secs = dict(render=0.0, gpu=0.0, oracle=0.0, volumes=0.0)
     for k in range(frames):
         t0 = time.perf_counter()
@@ -37,12 +37,14 @@ def side_by_side(torch, pl, oracle, scene, n, frames, seed=(0, 3), threshold=0.0
                 d2[240, 320] += 1
             assert twin.process_frame(torch.from_numpy(d2.view(np.int16)).cuda()) == 1
             rec_twin.append(float(np.abs(kf.world2camera()[..., 0].astype(np.float64) - twin.world2camera()[..., 0]).max()))
+            rec_twin_deriv.append(float(np.abs(kf.world2camera()[..., 1].astype(np.float64) - twin.world2camera()[..., 1]).max() / prm["csfd_seed_h"]))
         secs["render"] += t1 - t0; secs["gpu"] += t2 - t1; secs["oracle"] += t3 - t2
         assert a == 1 and b == 1, (scene, n, k, a, b)
         g, w = kf.world2camera().astype(np.float64), ok.world2camera().astype(np.float64)
         scale = max(np.abs(w[..., 1]).max(), 1e-30)
         rec["dpose"].append(float(np.abs(g[..., 0] - w[..., 0]).max()))
         rec["dderiv_rel"].append(float(np.abs(g[..., 1] - w[..., 1]).max() / scale))
+        rec["dderiv_abs"].append(float(np.abs(g[..., 1] - w[..., 1]).max() / prm["csfd_seed_h"]))   # in units of d pose / d seed
         rec["deriv_scale"].append(float(scale / prm["csfd_seed_h"]))
         rec["dU"].append(int(abs(kf.last_U() - ok.last_U()))); rec["U"].append(int(ok.last_U()))
         rec["dhits"].append(int(abs(kf.last_hits() - ok.last_hits()))); rec["hits"].append(int(ok.last_hits()))
@@ -52,6 +54,7 @@ def side_by_side(torch, pl, oracle, scene, n, frames, seed=(0, 3), threshold=0.0
     if twin is not None:
         twin.close()
         rec["sensitivity_dpose"] = rec_twin
+        rec["sensitivity_dderiv_abs"] = rec_twin_deriv
     # the fused volumes on seeded voxels (the arrays are 0.5-1.5 GB each at 512^3: one at a time)
     t0 = time.perf_counter()
     rng = np.random.default_rng(0xC5FD + n)
