@@ -229,25 +229,49 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 // needs 80-104 registers.  PASSES: the LDS tile holds all 55 values of the eight waves at once (123 KB: one workgroup per CU —
 // launches of up to 256 workgroups: levels 1 and 2), 28 in two passes (64 KB, two per CU at four waves per SIMD, up to 512) or 19
 // in three (45 KB, three per CU at six waves per SIMD, 80 VGPRs: up to 768 — level 0's 600).
-template <int POSE_SRC, int WAVES, int PASSES>
+// BAL (round 3; WAVES = 8, PASSES = 2, a grid of exactly two workgroups per CU): a launch whose tiles outnumber the resident waves by
+// up to a quarter — level 0 of a 640 x 480 frame: 4 800 tiles for 4 096 — deals them out evenly instead of launching a third
+// workgroup on some CUs: workgroup b takes ntiles / grid tiles, the first ntiles % grid one more (9 or 10 of them: ten tile slots), and
+// its waves 0 and 1 work through a second tile.  With 600 one-tile-per-wave workgroups 88 of the 256 CUs held three of them (24 tiles on
+// the busiest against 18.75 on average) and the launch lasted as long as those; now every CU holds 18-20.  The partition is a function
+// of the launch geometry alone, so the sums keep one fixed association (slot order = tile order inside a workgroup).
+template <int POSE_SRC, int WAVES, int PASSES, bool BAL = false>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu(WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6))))
     k_icp(const IcpArgs a) {
+    static_assert(!BAL || (WAVES == 8 && PASSES == 2), "the balanced instance is the eight-wave, two-pass one");
+    constexpr int SLOTS = BAL ? 10 : WAVES;   // tiles a workgroup can take
     XS_STAMP(0);
     // one tile per wave: the tile's current-frame vertices are on their way before the pose is (a pixel outside the image reads
     // pixel (0, y0): resident, never used)
-    cfloat3 pre_v;
-    bool pre_ok = false;
-    int pre_x = 0, pre_y = a.y0;
+    cfloat3 pre_v, pre_v2;
+    bool pre_ok = false, pre_ok2 = false;
+    int pre_x = 0, pre_y = a.y0, pre_x2 = 0, pre_y2 = a.y0;
     if constexpr (WAVES == 8) {
         const int tiles_x0 = (a.cols + 63) / 64;
-        const int t0 = blockIdx.x * 8 + (threadIdx.x >> 6);
+        const int nt0 = tiles_x0 * (a.y1 - a.y0);
+        int t0 = blockIdx.x * 8 + (threadIdx.x >> 6), t1 = nt0;
+        if constexpr (BAL) {
+            const int base = nt0 / (int)gridDim.x, rem = nt0 % (int)gridDim.x;
+            const int start = (int)blockIdx.x * base + min((int)blockIdx.x, rem), cnt = base + ((int)blockIdx.x < rem ? 1 : 0);
+            const int w = threadIdx.x >> 6;
+            t0 = w < cnt ? start + w : nt0;
+            t1 = 8 + w < cnt ? start + 8 + w : nt0;
+        }
         const int y = a.y0 + t0 / tiles_x0, x = (t0 % tiles_x0) * 64 + (threadIdx.x & 63);
-        pre_ok = t0 < tiles_x0 * (a.y1 - a.y0) && x < a.cols;
+        pre_ok = t0 < nt0 && x < a.cols;
         if (pre_ok) { pre_x = x; pre_y = y; }
 #ifndef XS_ICP_NO_PREFETCH
         load_vertex(a, pre_x, pre_y, pre_v);
 #endif
+        if constexpr (BAL) {
+            if (threadIdx.x < 128) {   // waves 0 and 1: a second tile
+                const int y2 = a.y0 + t1 / tiles_x0, x2 = (t1 % tiles_x0) * 64 + (threadIdx.x & 63);
+                pre_ok2 = t1 < nt0 && x2 < a.cols;
+                if (pre_ok2) { pre_x2 = x2; pre_y2 = y2; }
+                load_vertex(a, pre_x2, pre_y2, pre_v2);
+            }
+        }
     }
     MatS33 Rcurr = a.Rcurr;
     cfloat3 tcurr = a.tcurr;
@@ -325,11 +349,11 @@ __global__ void __launch_bounds__(64 * WAVES)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_x = (a.cols + 63) / 64;
     const int ntiles = tiles_x * (a.y1 - a.y0);
-    __shared__ double smem[WAVES][NP];
+    __shared__ double smem[SLOTS][NP];
     // one LDS buffer for the fold's tile and, afterwards, the last workgroup's row-group sums
     constexpr int PV = (NS + 1 + PASSES - 1) / PASSES;   // eight-wave instance: 55, 28 or 19 values per pass
     constexpr int RS = 68;                               // ... in rows 68 floats apart
-    constexpr int TILE_BYTES = WAVES == 4 ? 4 * 28 * 65 * 8 : 8 * PV * RS * 4;
+    constexpr int TILE_BYTES = WAVES == 4 ? 4 * 28 * 65 * 8 : SLOTS * PV * RS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_tile[TILE_BYTES];
     if constexpr (WAVES == 4) {
     double acc[NS];
@@ -407,12 +431,28 @@ __global__ void __launch_bounds__(64 * WAVES)
             for (int i = 0; i < 7; ++i) row[i] = cfloat(0.0f, 0.0f);   // ICP.cu:262: a rejected pixel contributes zeros
         }
     }
+    cfloat row2[BAL ? 7 : 1];
+    float one2 = 0.0f;
+    if constexpr (BAL) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) row2[i] = cfloat(0.0f, 0.0f);
+        if (wave < 2) {   // (wave-uniform) the second tile of waves 0 and 1; a workgroup with nine tiles leaves wave 1's slot all zeros
+            cfloat3 n, d, s;
+            if (pre_ok2 && search_vertex_loaded(a, Rcurr, tcurr, pre_x2, pre_y2, pre_v2, n, d, s)) {
+                const cfloat3 cr = cross(s, n);
+                row2[0] = cr.x; row2[1] = cr.y; row2[2] = cr.z;
+                row2[3] = n.x; row2[4] = n.y; row2[5] = n.z;
+                row2[6] = dot(n, d - s);
+                one2 = 1.0f;
+            }
+        }
+    }
     XS_STAMP(2);
     // Rows of 64 floats, one per (wave, value), 68 floats apart: 16-byte aligned with an odd number of 16-byte chunks between
     // rows, so the wave's row-wise stores and the adders' 128-bit loads (eight consecutive lanes = eight consecutive rows, or
     // four rows x two halves) are both free of bank conflicts.  A row is added by two lanes, 32 entries each, when the
     // workgroup has the threads for it (two or three passes), by one otherwise.
-    constexpr int SPLIT = 16 * PV <= 512 ? 2 : 1;
+    constexpr int SPLIT = 16 * PV <= 512 ? 2 : 1;   // (the balanced instance's 280 rows: a few lanes take a second one)
     float *tile = reinterpret_cast<float *>(lds_tile);
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
@@ -427,13 +467,24 @@ __global__ void __launch_bounds__(64 * WAVES)
                     const cfloat p = row[i] * row[j];
                     if (kre / PV == pass) tile[(wave * PV + kre % PV) * RS + lane] = p.re;
                     if (kim / PV == pass) tile[(wave * PV + kim % PV) * RS + lane] = p.im;
+                    if constexpr (BAL) {
+                        if (wave < 2) {
+                            const cfloat p2 = row2[i] * row2[j];
+                            if (kre / PV == pass) tile[((8 + wave) * PV + kre % PV) * RS + lane] = p2.re;
+                            if (kim / PV == pass) tile[((8 + wave) * PV + kim % PV) * RS + lane] = p2.im;
+                        }
+                    }
                 }
                 ++shift;
             }
-        if (pass == NS / PV) tile[(wave * PV + NS % PV) * RS + lane] = one;
+        if (pass == NS / PV) {
+            tile[(wave * PV + NS % PV) * RS + lane] = one;
+            if constexpr (BAL) { if (wave < 2) tile[((8 + wave) * PV + NS % PV) * RS + lane] = one2; }
+        }
         __syncthreads();
-        const int r = threadIdx.x / SPLIT, h = threadIdx.x % SPLIT;
-        if (r < 8 * PV) {
+        const int h = threadIdx.x % SPLIT;
+#pragma unroll
+        for (int r = threadIdx.x / SPLIT; r < SLOTS * PV; r += (64 * WAVES) / SPLIT) {
             // four interleaved partial sums (entries i, i + 4, ... each) per lane; with two lanes per row the halves are added
             // partial by partial, then ((s0 + s1) + (s2 + s3)): the same fixed association every launch.  The second lane
             // walks its eight chunks starting from the fifth, which keeps the pair on different banks.
@@ -477,8 +528,8 @@ __global__ void __launch_bounds__(64 * WAVES)
             if (threadIdx.x < NP / 2) {
                 const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
                 d2 v;
-                v.x = wave_order_sum<WAVES>(smem, k0);
-                v.y = k1 <= NS ? wave_order_sum<WAVES>(smem, k1) : 0.0;
+                v.x = wave_order_sum<SLOTS>(smem, k0);
+                v.y = k1 <= NS ? wave_order_sum<SLOTS>(smem, k1) : 0.0;
                 if (k1 <= NS) reinterpret_cast<d2 *>(a.host_records)[(size_t)blockIdx.x * (NP / 2) + threadIdx.x] = v;
                 else a.host_records[(size_t)blockIdx.x * NP + k0] = v.x;      // the count; the pad word is the sequence slot
             }
@@ -496,8 +547,8 @@ __global__ void __launch_bounds__(64 * WAVES)
         // six hundred do).
         const int k0 = 2 * threadIdx.x, k1 = k0 + 1;
         double *rec = a.partials + (size_t)blockIdx.x * NP;
-        __hip_atomic_store(rec + k0, wave_order_sum<WAVES>(smem, k0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rec + k1, k1 <= NS ? wave_order_sum<WAVES>(smem, k1) : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + k0, wave_order_sum<SLOTS>(smem, k0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + k1, k1 <= NS ? wave_order_sum<SLOTS>(smem, k1) : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // publish: the storing wave waits until its write-through stores are acknowledged, then its first lane takes a ticket
     // (same wave, program order: no barrier in between); the atomic is performed at agent scope after the records are in memory
@@ -693,6 +744,13 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
 // level of a 640 x 480 frame), else four waves striding over the tiles with the sums in registers (any size)
 static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
     const int tiles = div_up(cols, 64) * (y1 - y0);
+    // more tiles than the 4 096 waves of two eight-wave workgroups per CU, by up to a quarter: 512 workgroups of nine or ten tiles
+    // (k_icp<., 8, 2, true>; `waves` 9 marks it).  XS_ICP_BALANCED=0: the one-tile-per-wave launch (measurement aid).
+    static const bool balanced = !(getenv("XS_ICP_BALANCED") && atoi(getenv("XS_ICP_BALANCED")) == 0);
+    if (balanced && tiles > 8 * 512 && tiles <= 10 * 512) {
+        if (waves) *waves = 9;
+        return 512;
+    }
     int w = 8, blocks = div_up(tiles, 8);
     if (blocks > XS_ICP_MAX_BLOCKS) {
         w = 4;
@@ -704,7 +762,8 @@ static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
 }
 template <int POSE_SRC>
 static void icp_dispatch(int waves, int blocks, hipStream_t st, const IcpArgs &a) {
-    if (waves == 8 && blocks <= 256) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 1>), dim3(blocks), dim3(512), 0, st, a);
+    if (waves == 9) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2, true>), dim3(blocks), dim3(512), 0, st, a);
+    else if (waves == 8 && blocks <= 256) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 1>), dim3(blocks), dim3(512), 0, st, a);
     else if (waves == 8 && blocks <= 512) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2>), dim3(blocks), dim3(512), 0, st, a);
     else if (waves == 8) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 3>), dim3(blocks), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((k_icp<POSE_SRC, 4, 2>), dim3(blocks), dim3(256), 0, st, a);
