@@ -365,8 +365,11 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Vo
 // z in [zb, ze) of column (x, y).  The voxel's current state (coalesced 256 B rows) is requested
 // before the projection arithmetic so its HBM latency runs under it.  (Two planes per trip with
 // six reads in flight was measured slower: 102 VGPRs halve the resident waves.)
-template <bool BILINEAR>
-__device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x, int y, int zb, int ze) {
+// OFF32 (the brick kernel): the three arrays are addressed as a wave-uniform base (the brick's first voxel: scalar registers) + one 32-bit
+// byte offset per lane that advances by a plane per trip — one VALU instruction per trip for the addresses instead of the six of three
+// 64-bit pointers.  ubase: byte offset of the brick's voxel (0, 0, zb0) in each array; zb0: the brick's first plane.
+template <bool BILINEAR, bool OFF32 = false>
+__device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x, int y, int zb, int ze, size_t ubase = 0, int zb0 = 0, unsigned lane_off = 0) {
     unsigned n_upd = 0;
     const float vgx = (x + 0.5f) * a.voxel_size;
     const float vgy = (y + 0.5f) * a.voxel_size;
@@ -385,6 +388,26 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
     float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
     const size_t zstride = (size_t)a.Y * (a.vstep / 4);
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    if constexpr (OFF32) {
+        char *bv = reinterpret_cast<char *>(a.value) + ubase, *bw = reinterpret_cast<char *>(a.weight) + ubase, *bg = reinterpret_cast<char *>(a.grad) + ubase;
+        const unsigned plane = (unsigned)a.Y * (unsigned)a.vstep;
+        unsigned off = lane_off + (unsigned)(zb - zb0) * plane;
+        for (int z = zb; z < ze; ++z, off += plane) {
+            float *pos = reinterpret_cast<float *>(bv + off), *gpos = reinterpret_cast<float *>(bg + off);
+            int *wpos = reinterpret_cast<int *>(bw + off);
+            const float v0 = *pos, g0 = *gpos;
+            const int w0 = *wpos;
+            float ov, og; int ow;
+            if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) {
+                if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
+                if ((unsigned)(ow ^ w0) | always) *wpos = ow;
+                if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
+                ++n_upd;
+            }
+            else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
+        }
+        return n_upd;
+    }
     // (Requesting the state of voxel z+1 one trip ahead, in front of or behind the depth gather, was
     // measured slower: loads return in issue order and the extra live registers cost a wave.)
     for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
@@ -497,7 +520,7 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     }
 }
 
-template <bool BILINEAR>
+template <bool BILINEAR, bool OFF32 = false>
 __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs a) {
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
@@ -510,14 +533,24 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
         reinterpret_cast<float *>(&s_cp)[threadIdx.x] = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
     __syncthreads();
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
-        const int b = a.brick_list[e];
+        // (OFF32: the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
+        // or every address derived from it would be a 64-bit vector quantity)
+        const int b = OFF32 ? __builtin_amdgcn_readfirstlane(a.brick_list[e]) : a.brick_list[e];
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
-        const int x = bx * BRICK_X + t256 % BRICK_X, y = by * BRICK_Y + t256 / BRICK_X;
+        const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
+        const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
         if (x < a.X && y < a.Y) {
-            int zb = a.z0 + bz * a.brick_z, ze = min(zb + a.brick_z, a.z1);
+            const int zb0 = a.z0 + bz * a.brick_z;
+            int zb = zb0, ze = min(zb + a.brick_z, a.z1);
             clip_column(s_cp, far, x, y, zb, ze);
-            if (zb < ze) n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
+            if (zb < ze) {
+                if constexpr (OFF32) {
+                    const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
+                    n_upd += integrate_span<BILINEAR, true>(a, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
+                } else
+                    n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
+            }
         }
     }
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
@@ -859,8 +892,12 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // the kernel's own begin / end timestamps), so it adds no marker packets to the stream and times what
         // rocprofv3 times
         // (either event may be null: a completion event alone lets another stream wait for this kernel without a marker packet)
-        void (*kern)(const IntegrateArgs) = threshold > 0.0f ? k_integrate_bricks<true> : k_integrate_bricks<false>;
-        static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel
+        // 32-bit lane offsets from the brick's first voxel whenever a brick spans less than 4 GiB of an array (always, short of absurd
+        // pitches): no spills, the state loads take a scalar base (S1 launch 40.5 -> 39.2 us for the whole call, S2 unchanged)
+        static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel; "off64" = 64-bit pointers per lane
+        const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
+        void (*kern)(const IntegrateArgs) = threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true> : k_integrate_bricks<true, false>)
+                                                              : (off32 ? k_integrate_bricks<false, true> : k_integrate_bricks<false, false>);
         if (env_k && !strcmp(env_k, "ring") && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
             kern = k_integrate_bricks_ring<false>;
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
