@@ -86,6 +86,7 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
 #define XS_INTEGRATE_HEADER_IS_CLEAR 1u
 #define XS_INTEGRATE_NO_FOLD 2u
 #define XS_INTEGRATE_ALWAYS_STORE 8u    /* store all three words of every updated voxel, also where their bits do not change (the default stores only words that change: same volume, fewer bytes) */
+#define XS_INTEGRATE_POSE_POSTED 16u     /* the kernel takes its pose from a mailbox (xs_integrate_set_pose_mailbox / xs_integrate_post_pose): see below */
 #define XS_INTEGRATE_LIST_IS_READY 4u   /* xs_integrate_classify has produced the brick list on this stream (see there) */
 int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
@@ -101,6 +102,17 @@ int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, v
  * image size, else clear the header again (xs_integrate_workspace_clear) and call it without.  flags of xs_integrate_classify:
  * XS_INTEGRATE_HEADER_IS_CLEAR as above.  Results are those of the plain call, bit for bit (the list is a superset; every voxel
  * still takes the exact tests with the final pose). */
+/* The integrate kernel enqueued before its pose exists (flag XS_INTEGRATE_POSE_POSTED, with XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR):
+ * xs_integrate_set_pose_mailbox(mailbox, seq, slack_scale, pose_dev) names — for the NEXT xs_integrate_scaled_ex call of this thread — the mailbox
+ * (xs_icp_mailbox_alloc: one of its own, not the ICP loop's) that a one-wave gate kernel in front of the integrate kernel polls, the sequence number
+ * it waits for, the factor the call widens the frustum planes by, and 128 bytes of device memory (pose_dev) through which the gate hands the pose on; that call is given the pose the brick list was classified with (xs_integrate_classify) and uses it for the planes only.
+ * When the final pose is known: if xs_integrate_pose_covered(..., list pose, slack_scale, final pose) post it with
+ * xs_icp_post_pose(mailbox, Rv2c18, tv2c6, seq, 0) — the kernel then integrates with exactly that pose, same volume as a plain call — else post
+ * xs_icp_post_pose(mailbox, NULL, NULL, seq, 1): the launch leaves without touching the volume, and a plain call follows.  Every posted launch must
+ * be answered by exactly one post (it gives up after ~1 s otherwise).  Sequence numbers: non-zero, increasing per mailbox. */
+void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mailbox_seq, float slack_scale, void *pose_dev);
+int xs_integrate_pose_covered(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18_list,
+                              const float *tv2c6_list, float slack_scale, const float *Rv2c18, const float *tv2c6);
 int xs_integrate_classify(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
                           float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale, unsigned flags,
                           void *stream);

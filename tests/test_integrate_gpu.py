@@ -176,6 +176,71 @@ def test_integrate_with_the_brick_list_classified_ahead(dev):
         assert not capi.integrate_list_covers(Hh, Ww, k4, res, vs, Rl, far_t, 2.0, T["Rv2c"], T["tv2c"])
 
 
+def test_integrate_with_the_pose_posted_to_an_enqueued_launch(dev):
+    """XS_INTEGRATE_POSE_POSTED: the integrate kernel is enqueued before its pose exists — behind a classification made for a nearby
+    pose — and takes the final pose from a mailbox.  Posted the final pose, it writes the volume and count of a plain call, bit for
+    bit (bilinear branch too); posted an abandon command, it leaves the volume untouched; and xs_integrate_pose_covered refuses a pose
+    whose frustum leaves the widened planes."""
+    torch, capi = dev
+    n = 128
+    res = [n, n, n]
+    Wd, Hd = synth.WIDTH, synth.HEIGHT
+    for threshold in (0.0, 0.02):
+        prm = synth.s1_params(n, threshold=threshold)
+        k4, vs, trunc = intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm)
+        # classified for a pose a twentieth of a frame step away from the one integrated with (in the pipeline the two differ by the last level-0
+        # ICP update); a whole frame step away is refused
+        T_list, T_fin = s1_transforms(4.95, prm), s1_transforms(5, prm)
+        assert capi.integrate_pose_covered(Hd, Wd, k4, res, vs, T_list["Rv2c"], T_list["tv2c"], 2.0, T_fin["Rv2c"], T_fin["tv2c"])
+        assert not capi.integrate_pose_covered(Hd, Wd, k4, res, vs, T_list["Rv2c"], T_list["tv2c"], 2.0, s1_transforms(8, prm)["Rv2c"], s1_transforms(8, prm)["tv2c"])
+        depth = torch.from_numpy(synth.s1_frame(5).astype(np.int16)).cuda()
+        scaled = torch.empty((Hd, Wd), dtype=torch.float32, device="cuda")
+        dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+        capi.scale_depth_max(depth, Wd * 2, Hd, Wd, scaled, Wd * 4, dmax)
+        mailbox, in_dev = capi.icp_mailbox_alloc()
+        pose_dev = torch.zeros(32, dtype=torch.int32, device="cuda")
+        try:
+            vols = []
+            for mode in ("plain", "posted", "abandoned"):
+                value = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+                weight = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
+                grad = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+                ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+                counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+                # two frames first, so that the running mean, the weight and the store elision all have something to do
+                for kf in (3, 4):
+                    Tk = s1_transforms(kf, prm)
+                    capi.integrate_tsdf_volume(torch.from_numpy(synth.s1_frame(kf).astype(np.int16)).cuda(), Wd * 2, Hd, Wd, k4, 100, res, vs, Tk["Rv2c"],
+                                               Tk["tv2c"], trunc, value, weight, grad, n * 4, torch.empty((Hd, Wd), dtype=torch.float32, device="cuda"), Wd * 4,
+                                               threshold=threshold)
+                before = [t.clone() for t in (value, weight, grad)]
+                args = (scaled, Wd * 4, Hd, Wd, k4, 100, res, vs)
+                tail = (trunc, value, weight, grad, n * 4)
+                if mode == "plain":
+                    capi.integrate_scaled_ex(*args, T_fin["Rv2c"], T_fin["tv2c"], *tail, 0, threshold=threshold, updated=counter, depth_max=dmax, workspace=ws)
+                else:
+                    seq = 7 if mode == "posted" else 9
+                    capi.integrate_classify(Hd, Wd, k4, res, vs, T_list["Rv2c"], T_list["tv2c"], trunc, ws, slack_scale=2.0, depth_max=dmax)
+                    capi.integrate_set_pose_mailbox(mailbox, seq, 2.0, pose_dev)
+                    capi.integrate_scaled_ex(*args, T_list["Rv2c"], T_list["tv2c"], *tail, 16 | 4 | 1, threshold=threshold, updated=counter, depth_max=dmax,
+                                             workspace=ws)
+                    if mode == "posted":
+                        capi.icp_post_pose(mailbox, T_fin["Rv2c"], T_fin["tv2c"], seq, 0)
+                    else:
+                        capi.icp_post_pose(mailbox, None, None, seq, 1)
+                torch.cuda.synchronize()
+                vols.append(([t.cpu().numpy() for t in (value, weight, grad)], int(counter.item()), [t.cpu().numpy() for t in before]))
+            (pv, pc, _), (qv, qc, _), (av, ac, ab) = vols
+            for x, y in zip(pv, qv):
+                assert np.array_equal(x.view(np.int32), y.view(np.int32))
+            assert pc == qc > 1000
+            for x, y in zip(av, ab):
+                assert np.array_equal(x.view(np.int32), y.view(np.int32))
+            assert ac == 0
+        finally:
+            capi.icp_mailbox_free(mailbox, in_dev)
+
+
 def test_integrate_rotated_and_inside_out_views(dev, oracle):
     """Column clipping under strong rotations (every sign of the half-space slopes), a camera
     outside the volume and a view from the far side."""

@@ -210,17 +210,21 @@ def test_pipeline_fewer_pyramid_levels_against_live_oracle(dev, oracle, levels):
 
 def test_brick_list_classified_ahead_changes_nothing(dev):
     """integrate_classify_ahead (the integrate call's brick list built behind the last ICP launch, from the pose that launch
-    starts from) against the plain order, and against a list slack of 1 — with which no final pose is ever covered, so every
-    frame takes the fall-back (header cleared again, classification repeated): the same poses, counts and volume, bit for bit."""
+    starts from) against the plain order and against a list slack of 1 — with which no final pose is ever covered, so every frame
+    takes the fall-back (header cleared again, classification repeated); and integrate_post_pose (the integrate kernel itself
+    enqueued behind the classification and handed the final pose through its mailbox), covered and — slack 1 — never covered (the
+    posted launch told to leave every frame): the same poses, counts and volume, bit for bit."""
     torch, pl = dev
     prm = synth.s1_params(128)
     runs = [pl.KinectFusion(dict(prm, integrate_classify_ahead=False)), pl.KinectFusion(dict(prm, integrate_classify_ahead=True)),
-            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_slack=1.0))]
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_slack=1.0)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_post_pose=True)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_post_pose=True, integrate_classify_slack=1.0))]
     blank = upload(torch, np.zeros_like(synth.s1_frame(0)))
     for k in list(range(6)) + ["blank", 6, 7]:
         d = blank if k == "blank" else upload(torch, synth.s1_frame(k))
         rcs = [r.process_frame(d) for r in runs]
-        assert rcs[0] == rcs[1] == rcs[2] == (0 if k == "blank" else 1)
+        assert all(rc == (0 if k == "blank" else 1) for rc in rcs)
         for r in runs[1:]:
             assert np.array_equal(r.world2camera(), runs[0].world2camera())
             assert r.last_U() == runs[0].last_U() and r.last_hits() == runs[0].last_hits()
@@ -318,7 +322,7 @@ def test_alignment_failure_after_the_bricks_were_classified_ahead(dev):
     frames give the same poses, counts and volume as a run that never failed."""
     torch, pl = dev
     prm = synth.s1_params(128)
-    a = pl.KinectFusion(dict(prm, integrate_classify_ahead=True))
+    a = pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_post_pose=True))   # (the failure path of the posted launch too)
     b = pl.KinectFusion(dict(prm, integrate_classify_ahead=True))
     for k in range(3):
         d = upload(torch, synth.s1_frame(k))

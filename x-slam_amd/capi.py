@@ -110,6 +110,8 @@ _SIGS = {
     "xs_dcsfd_f1": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     "xs_complex_table": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
     "xs_raycast_set_step_buffer": (None, [_vp]),
+    "xs_integrate_set_pose_mailbox": (None, [_vp, C.c_uint, C.c_float, _vp]),
+    "xs_integrate_pose_covered": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_const_div_prepare": (C.c_uint, [C.c_float]),
     "xs_const_div_state": (C.c_uint, [C.c_float]),
     "xs_const_div_enable": (C.c_int, [C.c_int]),
@@ -251,6 +253,20 @@ def integrate_list_covers(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_lis
     a, b, c, d = _fa(Rv2c_list, 18), _fa(tv2c_list, 6), _fa(Rv2c, 18), _fa(tv2c, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
     return bool(_lib.xs_integrate_list_covers(rows, cols, P(k), r.ctypes.data_as(_i32p), voxel_size, P(a), P(b), slack_scale, P(c), P(d)))
+
+
+def integrate_set_pose_mailbox(mailbox, mailbox_seq, slack_scale=2.0, pose_dev=None):
+    """Names the mailbox / sequence number / plane widening / 128-byte device hand-over buffer of the next integrate_scaled_ex call with
+    flag 16 (XS_INTEGRATE_POSE_POSTED)."""
+    _lib.xs_integrate_set_pose_mailbox(_ptr(mailbox), mailbox_seq, slack_scale, _ptr(pose_dev))
+
+
+def integrate_pose_covered(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_list, slack_scale, Rv2c, tv2c):
+    r = _ia(res, 3)
+    k = _fa(intr, 4)
+    a, b, c, d = _fa(Rv2c_list, 18), _fa(tv2c_list, 6), _fa(Rv2c, 18), _fa(tv2c, 6)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    return bool(_lib.xs_integrate_pose_covered(rows, cols, P(k), r.ctypes.data_as(_i32p), voxel_size, P(a), P(b), slack_scale, P(c), P(d)))
 
 
 def integrate_workspace_clear(workspace, stream=None):

@@ -13,6 +13,7 @@
 // second launch.  How each phase was measured: profiles/tools/trace_icp.sh, profiles/r02_icp_phases.txt.
 #include <string.h>
 #include "xs_device.h"
+#include "xs_mailbox.h"
 #include "xs_icp_solve.h"
 #include "../../include/xslam_amd.h"
 
@@ -211,7 +212,6 @@ __device__ __forceinline__ double wave_order_sum(const double (*smem)[NP], int k
 // with f = the 18 floats of Rcurr followed by the 6 of tcurr; cmd 0 = run, 1 = abandon the launch.  The poller takes
 // the payload from a second load issued after it has seen both sequence words (see there).
 enum { POSE_ARGS = 0, POSE_DEVICE = 1, POSE_POSTED = 2 };
-enum { MAILBOX_WORDS = 32, MAILBOX_MAX_POLLS = 400000 };  // ~2 us per poll: gives up after about a second
 constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 
 // POSE_ARGS: Rcurr / tcurr are kernel arguments (xs_icp_accumulate, first iteration of xs_icp_iterate).
@@ -298,33 +298,7 @@ __global__ void __launch_bounds__(64 * WAVES)
         // both lines carry this launch's sequence number, then hands the 32 words to the others through
         // LDS.  Bounded: after MAILBOX_MAX_POLLS the launch gives up and says so in the completion word.
         __shared__ unsigned s_mail[MAILBOX_WORDS];
-        if (threadIdx.x < 64) {
-            unsigned v = 0, cmd_override = 0;
-            for (int polls = 0;; ++polls) {
-                v = __hip_atomic_load(a.mailbox + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
-                // this launch's number — or a later one: the host has moved past this launch (an abandon command releases
-                // every launch in the queue with one post: see below)
-                if (s0 == s1 && (int)(s0 - a.mailbox_seq) >= 0) break;
-                if (polls >= MAILBOX_MAX_POLLS) { cmd_override = 2; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            // The load that saw both sequence words is not taken as the payload: sixteen lanes reading one line are
-            // one request in practice, but nothing promises that its sectors are read at one instant, and a line caught
-            // between the host's payload stores and its sequence store would hand over a mixed pose without any error.
-            // The host orders payload -> store fence -> sequence words -> store fence (xs_icp_post_pose), so a load
-            // ISSUED after the sequence words were seen returns the complete payload: read the 32 words once more
-            // (the exit test above consumed v, i.e. the first load has returned before this one is issued; both are
-            // system-scope and bypass the caches).  The sequence words are checked again on the way.
-            if (!cmd_override) {
-                v = __hip_atomic_load(a.mailbox + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 1);
-                if (s0 == a.mailbox_seq && s1 == a.mailbox_seq) { /* this launch's post: pose or command as posted */ }
-                else if (s0 == s1 && (int)(s0 - a.mailbox_seq) > 0 && c == 1) cmd_override = 1;   // abandon, addressed to a later launch: leave too
-                else cmd_override = 2;   // the host broke the one-post-per-launch contract
-            }
-            if (threadIdx.x < MAILBOX_WORDS) s_mail[threadIdx.x] = threadIdx.x == 1 && cmd_override ? cmd_override : v;
-        }
+        if (threadIdx.x < 64) mailbox_wait(a.mailbox, a.mailbox_seq, s_mail, (int)threadIdx.x);   // (xs_mailbox.h)
         __syncthreads();
         const unsigned cmd = s_mail[1];
         if (cmd != 0) {

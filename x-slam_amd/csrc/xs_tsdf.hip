@@ -17,7 +17,9 @@
 // takes the exact path.  Only voxels that pass the reference's predicate touch memory.
 #include <hip/hip_ext.h>
 #include <string.h>
+#include <stdio.h>
 #include "xs_device.h"
+#include "xs_mailbox.h"
 #include <algorithm>
 #include <stdlib.h>
 #include "../../include/xslam_amd.h"
@@ -154,6 +156,8 @@ struct IntegrateArgs {
     int *brick_list; unsigned *brick_count;  // work list of the two-phase path
     int bricks_x, bricks_y, bricks_z, brick_z;  // brick_z: planes per brick (runtime; BRICK_Z by default)
     unsigned kflags;              // KF_*
+    const unsigned *mailbox; unsigned mailbox_seq;   // posted pose: what k_pose_gate polls ...
+    unsigned *pose_dev;                              // ... and where it leaves {cmd, 24 floats} for k_integrate_bricks<., ., true>
 };
 enum { KF_ALWAYS_STORE = 1u };    // write every updated voxel's three words even where the bits do not change (measurement aid)
 
@@ -207,6 +211,7 @@ __device__ __forceinline__ bool box_may_pass(const Frustum &f, int x0, int x1, i
 // The reference's per-voxel body (TsdfFusion.cu:110-168) for one voxel whose current state
 // (value, grad, weight) has already been loaded.  Returns true and the new state if the voxel is
 // written.
+struct PoseRT { MatS33 R; cfloat3 t; };   // volume-to-camera pose: the kernel argument's, or the one a posted launch took from its mailbox
 struct VoxelCtx {
     cfloat base[3];
     float fx, fy, cx, cy, ulo, uhi, vlo, vhi;
@@ -237,11 +242,11 @@ struct DepthBuffer {
 enum { BUFFER_RSRC_FLAGS = 0x00020000 };   // gfx9 raw buffer, dword 3: 32-bit data format
 // phase 1 (TsdfFusion.cu:110-143): project the voxel, fetch its depth.  false = not written.
 template <bool BILINEAR, class Depth>
-__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, VoxelProj &o, const Depth &dimg) {
+__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, int z, VoxelProj &o, const Depth &dimg) {
     const float vgz = (z + 0.5f) * a.voxel_size;
-    o.v_c.x = (k.base[0] + a.R.data[0].z * vgz) + a.t.x;
-    o.v_c.y = (k.base[1] + a.R.data[1].z * vgz) + a.t.y;
-    o.v_c.z = (k.base[2] + a.R.data[2].z * vgz) + a.t.z;
+    o.v_c.x = (k.base[0] + ps.R.data[0].z * vgz) + ps.t.x;
+    o.v_c.y = (k.base[1] + ps.R.data[1].z * vgz) + ps.t.y;
+    o.v_c.z = (k.base[2] + ps.R.data[2].z * vgz) + ps.t.z;
     const float c = o.v_c.z.re;
     o.c = c;
     if (c < 0) return false;  // Re(1/v_c.z) < 0
@@ -355,10 +360,10 @@ __device__ __forceinline__ void running_mean(const IntegrateArgs &a, cfloat tsdf
     out_w = min(pre_w + 1, a.max_weight);
 }
 template <bool BILINEAR>
-__device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
+__device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
                                                 float &out_v, float &out_g, int &out_w) {
     VoxelProj p;
-    if (!project_voxel<BILINEAR>(a, k, z, p, DepthGlobal{a.depth, a.dstep})) return false;
+    if (!project_voxel<BILINEAR>(a, ps, k, z, p, DepthGlobal{a.depth, a.dstep})) return false;
     return update_voxel(a, k, p, pre_v, pre_g, pre_w, out_v, out_g, out_w);
 }
 
@@ -369,7 +374,7 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Vo
 // byte offset per lane that advances by a plane per trip — one VALU instruction per trip for the addresses instead of the six of three
 // 64-bit pointers.  ubase: byte offset of the brick's voxel (0, 0, zb0) in each array; zb0: the brick's first plane.
 template <bool BILINEAR, bool OFF32 = false>
-__device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x, int y, int zb, int ze, size_t ubase = 0, int zb0 = 0, unsigned lane_off = 0) {
+__device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const PoseRT &ps, int x, int y, int zb, int ze, size_t ubase = 0, int zb0 = 0, unsigned lane_off = 0) {
     unsigned n_upd = 0;
     const float vgx = (x + 0.5f) * a.voxel_size;
     const float vgy = (y + 0.5f) * a.voxel_size;
@@ -377,7 +382,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
     // z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy); v_g has zero imaginary
     // part, so each complex product is (re*vg, im*vg)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) k.base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
+    for (int r = 0; r < 3; ++r) k.base[r] = ps.R.data[r].x * vgx + ps.R.data[r].y * vgy;
     k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
     // conservative image window in un-divided form (one pixel of slack on each side)
     k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
@@ -398,7 +403,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
             const float v0 = *pos, g0 = *gpos;
             const int w0 = *wpos;
             float ov, og; int ow;
-            if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) {
+            if (integrate_voxel<BILINEAR>(a, ps, k, z, v0, g0, w0, ov, og, ow)) {
                 if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
                 if ((unsigned)(ow ^ w0) | always) *wpos = ow;
                 if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
@@ -415,12 +420,12 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, int x
         float v0 = 1.0f, g0 = 0.0f; int w0 = 5;
         asm volatile("" : "+v"(v0), "+v"(g0), "+v"(w0));
         float ov, og; int ow;
-        if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) { asm volatile("" ::"v"(ov), "v"(og), "v"(ow)); ++n_upd; }
+        if (integrate_voxel<BILINEAR>(a, ps, k, z, v0, g0, w0, ov, og, ow)) { asm volatile("" ::"v"(ov), "v"(og), "v"(ow)); ++n_upd; }
 #else
         const float v0 = *pos, g0 = *gpos;
         const int w0 = *wpos;
         float ov, og; int ow;
-        if (integrate_voxel<BILINEAR>(a, k, z, v0, g0, w0, ov, og, ow)) {
+        if (integrate_voxel<BILINEAR>(a, ps, k, z, v0, g0, w0, ov, og, ow)) {
             // only the words whose bits change are stored (same volume, fewer bytes: in free space in front of a surface the running
             // mean of (1, 0) with (1, 0) is (1, 0) again, and a saturated weight stays)
 #if defined(XS_PROBE_NT_STORES)   // measurement only: non-temporal stores (profiles/tools/probe_integrate_nt.sh)
@@ -486,7 +491,7 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
         int zb = a.z0 + blockIdx.z * a.zchunk;
         int ze = min(zb + a.zchunk, a.z1);
         clip_column(a.cp, far_limit(a), x, y, zb, ze);
-        if (zb < ze) n_upd = integrate_span<BILINEAR>(a, x, y, zb, ze);
+        if (zb < ze) n_upd = integrate_span<BILINEAR>(a, PoseRT{a.R, a.t}, x, y, zb, ze);
     }
     if (a.updated) block_count_add(n_upd, a.updated, 1);
 }
@@ -520,8 +525,39 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     }
 }
 
-template <bool BILINEAR, bool OFF32 = false>
+// One wave waits at the mailbox for the pose of a posted integrate launch and leaves it in device memory for the launch behind it on the
+// stream: a single poller (two thousand workgroups polling one line themselves serialise at the memory side: measured, 87 us instead of 27).
+__global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsigned seq, unsigned *pose_dev) {
+    __shared__ unsigned s_mail[MAILBOX_WORDS];
+    mailbox_wait(mailbox, seq, s_mail, (int)threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) pose_dev[0] = s_mail[1];
+    if (threadIdx.x < 24) pose_dev[1 + threadIdx.x] = s_mail[threadIdx.x < 14 ? 2 + threadIdx.x : 18 + (threadIdx.x - 14)];
+}
+
+// POSTED: the launch is enqueued before its pose exists — behind the classification, which already runs behind the last ICP launch — and
+// takes R / t from what k_pose_gate, one wave in front of it on the stream, read out of a mailbox the host posts the final pose to
+// (xs_mailbox.h; xs_icp_post_pose): what is left between the last ICP
+// reduction and the first integrated voxel is the host's solve + one posted write + one poll instead of those plus a kernel launch
+// (~16 us -> ~4).  The frustum planes (brick test, column clip) stay those of the pose the list was classified with, widened: they
+// only bound the voxels that take the exact tests, and the host posts only after checking that the final pose's planes lie inside
+// them (xs_integrate_pose_covered); otherwise it posts an abandon command and the launch leaves without touching the volume.
+template <bool BILINEAR, bool OFF32 = false, bool POSTED = false>
 __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs a) {
+    PoseRT ps{a.R, a.t};
+    if constexpr (POSTED) {
+        // the pose k_pose_gate (the launch in front of this one) took from the mailbox: word 0 = command (0: run), words 1..24 = R, t
+        const unsigned *pd = a.pose_dev;
+        if (__builtin_amdgcn_readfirstlane((int)pd[0]) != 0) return;   // abandoned (or the gate gave up): nothing is written, nothing is counted
+        auto f = [&](int i) { return __int_as_float(__builtin_amdgcn_readfirstlane((int)pd[1 + i])); };
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            ps.R.data[r].x = cfloat(f(6 * r + 0), f(6 * r + 1));
+            ps.R.data[r].y = cfloat(f(6 * r + 2), f(6 * r + 3));
+            ps.R.data[r].z = cfloat(f(6 * r + 4), f(6 * r + 5));
+        }
+        ps.t.x = cfloat(f(18), f(19)); ps.t.y = cfloat(f(20), f(21)); ps.t.z = cfloat(f(22), f(23));
+    }
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
     const float far = far_limit(a);
@@ -547,9 +583,9 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
             if (zb < ze) {
                 if constexpr (OFF32) {
                     const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-                    n_upd += integrate_span<BILINEAR, true>(a, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
+                    n_upd += integrate_span<BILINEAR, true>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
                 } else
-                    n_upd += integrate_span<BILINEAR>(a, x, y, zb, ze);
+                    n_upd += integrate_span<BILINEAR>(a, ps, x, y, zb, ze);
             }
         }
     }
@@ -661,7 +697,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks_ring(const Integrat
             if (in) {
                 VoxelProj p;
                 p.Dp = cfloat(-1.0f, 0.0f);
-                const bool vis = project_voxel<BILINEAR>(a, k, z, p, dimg);
+                const bool vis = project_voxel<BILINEAR>(a, PoseRT{a.R, a.t}, k, z, p, dimg);
                 gathered = p.Dp.re >= 0.0f;   // (the fetch ran: a depth is never negative)
                 wr = vis && voxel_tsdf(a, k, p, tsdf);
             }
@@ -704,7 +740,7 @@ static void set_plane(Frustum &f, int P, const float T[3], const float M[3][3], 
     f.bz[P] = cxk * M[0][2] + cyk * M[1][2] + czk * M[2][2];
     f.slack[P] = sl;
 }
-static void host_frustum(IntegrateArgs &a) {
+static void host_frustum(IntegrateArgs &a, float slack_scale = 1.0f) {
     Frustum &f = a.fr;
     const float vs = a.voxel_size, fx = a.intr.fx, fy = a.intr.fy;
     const float ul = (1.5f - a.intr.cx) - 2.f, uh = ((a.dcols - 0.5f) - a.intr.cx + 1.0f) + 2.f;
@@ -718,7 +754,7 @@ static void host_frustum(IntegrateArgs &a) {
     const float mag0 = fabsf(T[0]) + (fabsf(M[0][0]) + fabsf(M[0][1]) + fabsf(M[0][2])) * ext;
     const float mag1 = fabsf(T[1]) + (fabsf(M[1][0]) + fabsf(M[1][1]) + fabsf(M[1][2])) * ext;
     const float mag2 = fabsf(T[2]) + (fabsf(M[2][0]) + fabsf(M[2][1]) + fabsf(M[2][2])) * ext;
-    const float rel = 2e-3f;
+    const float rel = 2e-3f * slack_scale;
     set_plane(f, 0, T, M, 0.f, 0.f, 1.f, rel * mag2);                                      // c >= 0
     set_plane(f, 1, T, M, fx, 0.f, -ul, rel * (fabsf(fx) * mag0 + fabsf(ul) * mag2));      // fx*X >= ul*c
     set_plane(f, 2, T, M, -fx, 0.f, uh, rel * (fabsf(fx) * mag0 + fabsf(uh) * mag2));      // fx*X <= uh*c
@@ -750,6 +786,16 @@ static void host_frustum(IntegrateArgs &a) {
 static thread_local hipEvent_t g_int_ev0 = nullptr, g_int_ev1 = nullptr;
 extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) {
     g_int_ev0 = (hipEvent_t)start_event; g_int_ev1 = (hipEvent_t)stop_event;
+}
+
+// posted-pose hook (see k_integrate_bricks<., ., true>): the mailbox the next XS_INTEGRATE_POSE_POSTED call's kernel polls, its number, and the
+// factor by which that call widens the frustum planes of the pose it is given (the list's pose)
+static thread_local const unsigned *g_post_mailbox = nullptr;
+static thread_local unsigned g_post_seq = 0;
+static thread_local float g_post_slack = 2.0f;
+static thread_local unsigned *g_post_pose_dev = nullptr;
+extern "C" void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mailbox_seq, float slack_scale, void *pose_dev) {
+    g_post_mailbox = (const unsigned *)mailbox; g_post_seq = mailbox_seq; g_post_slack = slack_scale; g_post_pose_dev = (unsigned *)pose_dev;
 }
 
 /* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
@@ -834,6 +880,23 @@ extern "C" int xs_integrate_list_covers(int rows, int cols, const float *intr4, 
     }
     return 1;
 }
+/* Host only: the stricter cover test a POSTED integrate launch needs — it keeps the list pose's widened planes for its column clip too, where
+ * a voxel is kept when alpha + b . index >= -slack (the brick test of xs_integrate_list_covers allows 1.5 slack): 1 if every half-space of
+ * (Rv2c18, tv2c6), anywhere in the volume, lies inside that of (Rv2c18_list, tv2c6_list) widened by slack_scale.  Implies xs_integrate_list_covers. */
+extern "C" int xs_integrate_pose_covered(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18_list,
+                                         const float *tv2c6_list, float slack_scale, const float *Rv2c18, const float *tv2c6) {
+    if (!intr4 || !res || !Rv2c18_list || !tv2c6_list || !Rv2c18 || !tv2c6) return 0;
+    IntegrateArgs l, f;
+    classify_args(l, rows, cols, intr4, res, voxel_size, Rv2c18_list, tv2c6_list, 1.0f, 0, res[2], nullptr);
+    classify_args(f, rows, cols, intr4, res, voxel_size, Rv2c18, tv2c6, 1.0f, 0, res[2], nullptr);
+    for (int p = 0; p < 6; ++p) {
+        const double d = fabs((double)l.fr.alpha[p] - f.fr.alpha[p]) + fabs((double)l.fr.bx[p] - f.fr.bx[p]) * res[0] +
+                         fabs((double)l.fr.by[p] - f.fr.by[p]) * res[1] + fabs((double)l.fr.bz[p] - f.fr.bz[p]) * res[2];
+        const double room = (double)slack_scale * l.fr.slack[p] - f.fr.slack[p];
+        if (!(d <= 0.8 * room)) return 0;   // (a fifth of the room left for the float evaluation of the forms and of the roots the clip solves them for)
+    }
+    return 1;
+}
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                                    float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
@@ -868,7 +931,14 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     a.brick_list = nullptr; a.brick_count = nullptr; a.kflags = 0;
     static const bool env_always = getenv("XS_INTEGRATE_ALWAYS_STORE") != nullptr;   // measurement aid, as the flag
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
-    host_frustum(a);
+    const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
+    a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
+    if (posted) {
+        if (!workspace || !(flags & XS_INTEGRATE_LIST_IS_READY) || !g_post_mailbox || !g_post_pose_dev)
+            return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: a posted launch needs the classified list and a mailbox (xs_integrate_set_pose_mailbox)");
+        a.mailbox = g_post_mailbox; a.mailbox_seq = g_post_seq; a.pose_dev = g_post_pose_dev;
+    }
+    host_frustum(a, posted ? g_post_slack : 1.0f);
     const int nz = z1 - z0;
     static const int env_bz = getenv("XS_BRICK_Z") ? atoi(getenv("XS_BRICK_Z")) : 0;  // tuning aid
     a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
@@ -898,6 +968,11 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
         void (*kern)(const IntegrateArgs) = threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true> : k_integrate_bricks<true, false>)
                                                               : (off32 ? k_integrate_bricks<false, true> : k_integrate_bricks<false, false>);
+        if (posted) {
+            if (!off32) return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: posted launch on a volume whose bricks span 4 GiB");
+            kern = threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>;
+            hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
+        }
         if (env_k && !strcmp(env_k, "ring") && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
             kern = k_integrate_bricks_ring<false>;
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
@@ -905,6 +980,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
             hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
     } else {
+        if (posted) return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: posted launch without a brick list");
         int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
         while ((long long)gx * gy * zsplit < 4096 && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
         a.zchunk = div_up(nz, zsplit);

@@ -40,6 +40,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
     if (pinned_records_) (void)hipHostFree(pinned_records_);
     if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
+    if (integrate_mailbox_) (void)xs_icp_mailbox_free(integrate_mailbox_, integrate_mailbox_in_device_);
     for (int i = 0; i < 2; ++i) {
         if (ingest_pinned_[i]) { (void)hipEventSynchronize(ingest_done_[i]); (void)hipHostFree(ingest_pinned_[i]); (void)hipEventDestroy(ingest_done_[i]); }
     }
@@ -114,6 +115,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_real_current_maps = config.as<bool>("icp_real_current_maps", true);
     integrate_classify_ahead = config.as<bool>("integrate_classify_ahead", true);
     integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
+    integrate_post_pose = config.as<bool>("integrate_post_pose", false);
     icp_lookahead = config.as<int>("icp_lookahead", 1);
     icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
@@ -160,6 +162,8 @@ void KinectFusionReconstruction::AllocateBuffers() {
         icp_ws_.create(xs_icp_workspace_bytes());
         check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
         if (!icp_mailbox_) check_rc(xs_icp_mailbox_alloc(&icp_mailbox_, &icp_mailbox_in_device_), "icp mailbox");
+        if (!integrate_mailbox_) check_rc(xs_icp_mailbox_alloc(&integrate_mailbox_, &integrate_mailbox_in_device_), "integrate mailbox");
+        posted_pose_.create(32);
         icp_sums_.create(64);
         icp_pose_.create(xs_icp_pose_state_bytes());
         ray_ws_.create((size_t)depth_width * depth_height);
@@ -370,7 +374,10 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 enqueue_through(n + std::max(1, icp_lookahead), &device_Rcurr, &device_tcurr);
                 // the last launch is in the queue: the integrate call's brick classification goes in behind it, for the pose that
                 // launch starts from — the final one differs by the last level-0 update, which IntegrateFrame checks is covered
-                if (n == total_iters - 1 && integrate_classify_ahead && integrate_split()) ClassifyAhead(Rcurr, tcurr);
+                // (with integrate_post_pose the integrate kernel follows the classification into the queue, and both go in as soon as the last
+                // ICP launch has — one iteration earlier — so that the host's share of three launches is over before the last reduction is)
+                if ((integrate_post_pose ? enqueued == total_iters : n == total_iters - 1) && !list_ready_ && integrate_classify_ahead && integrate_split())
+                    ClassifyAhead(Rcurr, tcurr);
                 const unsigned long long seq = seq_of[n];
                 if (n + 1 < total_iters) {
                     next_mail_seq = mail_of[n + 1];
@@ -606,6 +613,51 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
                                    tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
                                    integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
     list_ready_ = true;
+    EnqueuePostedIntegrate();
+}
+
+// this frame's counter slot; entering a half of the ring clears that half (its frames were folded or abandoned at least COUNTER_RING / 2
+// frames ago) — once per frame, whichever of the two integrate paths comes first
+unsigned long long *KinectFusionReconstruction::PrepareFrameCounters(hipStream_t st) {
+    if (counters_prepared_for_ != counter_frame_) {
+        counters_prepared_for_ = counter_frame_;
+        if (counter_frame_ % (COUNTER_RING / 2) == 0 && counter_frame_ > 0)
+            hipSafeCall(hipMemsetAsync(frame_counters(), 0, (COUNTER_RING / 2) * 2 * sizeof(unsigned long long), st));
+    }
+    return frame_counters();
+}
+
+// Behind the classification: the integrate kernel itself, to take the final pose from its mailbox (k_integrate_bricks<., ., true>).  Everything
+// IntegrateFrame does around its launch happens here; IntegrateFrame then only checks that the final pose is covered and posts it.
+void KinectFusionReconstruction::EnqueuePostedIntegrate() {
+    if (!integrate_post_pose || !integrate_split() || !integrate_mailbox_ || !integrate_mailbox_in_device_ || !list_ready_) return;
+    if (zs0 != zo0 || zs1 != zo1) return;   // (halo bands: several calls per frame)
+    hipStream_t st = current_stream();
+    unsigned long long *counters = PrepareFrameCounters(st);
+    const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
+    DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
+    DeviceArray2D<int> weight = tsdf_volume_d_ptr->weight();
+    hipEvent_t integrate_stop = integrate_done_;
+    if (profiling) {
+        integrate_stop = prof_ring_[prof_pending_].ev[ST_INTEGRATE][1];
+        xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], integrate_stop);
+        prof_ring_[prof_pending_].used[ST_INTEGRATE] = true;
+    } else
+        xs_integrate_set_timing_events(nullptr, integrate_stop);
+    if (++integrate_mail_seq_ == 0u) ++integrate_mail_seq_;
+    posted_seq_ = integrate_mail_seq_;
+    xs_integrate_set_pose_mailbox(integrate_mailbox_, posted_seq_, integrate_classify_slack, posted_pose_.ptr());
+    const bool split = integrate_header_clear_;   // header cleared and count folded on the auxiliary stream (SurfaceMeasure)
+    check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_height, depth_width, &kinect_intrinsic.fx, max_integration_weight,
+                                    res, voxel_size, list_Rv2c_, list_tv2c_, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), weight.ptr(0), grad.ptr(0),
+                                    value.step(), biInterpolate_threshold, zo0, zo1, counters, depth_max_.ptr(), integrate_ws_.ptr(),
+                                    XS_INTEGRATE_POSE_POSTED | XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR | (split ? XS_INTEGRATE_NO_FOLD : 0u), st),
+             "integrateTsdfVolume (posted)");
+    xs_integrate_set_timing_events(nullptr, nullptr);
+    xs_integrate_set_pose_mailbox(nullptr, 0, 1.0f, nullptr);
+    posted_pending_ = true;
+    posted_stop_ = integrate_stop;
+    posted_split_ = split;
 }
 
 // A frame whose alignment fails after ClassifyAhead has run never reaches IntegrateFrame: the classification kernel is still in the main
@@ -615,6 +667,10 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
 void KinectFusionReconstruction::AbandonClassifiedList() {
     if (!list_ready_) return;
     list_ready_ = false;
+    if (posted_pending_) {   // the integrate launch waiting for this frame's pose leaves without touching the volume
+        xs_icp_post_pose(integrate_mailbox_, nullptr, nullptr, posted_seq_, 1);
+        posted_pending_ = false;
+    }
     check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), current_stream()), "integrate workspace");
     hipSafeCall(hipStreamSynchronize(current_stream()));
     integrate_header_clear_ = true;
@@ -649,11 +705,25 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     hipStream_t st = current_stream();
-    // this frame's counter slot; entering a half of the ring clears that half (its frames were folded or
-    // abandoned at least COUNTER_RING / 2 frames ago)
-    if (counter_frame_ % (COUNTER_RING / 2) == 0 && counter_frame_ > 0)
-        hipSafeCall(hipMemsetAsync(frame_counters(), 0, (COUNTER_RING / 2) * 2 * sizeof(unsigned long long), st));
-    unsigned long long *counters = frame_counters();
+    unsigned long long *counters = PrepareFrameCounters(st);
+    // A posted integrate launch is waiting in the stream for this pose (EnqueuePostedIntegrate): if the pose's frustum lies inside the planes
+    // that launch was given, post it — the launch is the frame's integrate call; else tell it to leave and take the plain path below.
+    bool integrated_by_post = false;
+    if (posted_pending_) {
+        posted_pending_ = false;
+        const int res_[3] = {volume_res.x, volume_res.y, volume_res.z};
+        if (xs_integrate_pose_covered(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res_, voxel_size, list_Rv2c_, list_tv2c_,
+                                      integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re)) {
+            xs_icp_post_pose(integrate_mailbox_, &device_Rv2c.data[0].x.re, &device_tv2c.x.re, posted_seq_, 0);
+            integrated_by_post = true;
+            list_ready_ = false;
+            if (posted_split_) { integrate_header_clear_ = false; pending_fold_ = counters; }
+        } else {   // (never seen: the last ICP update moved the frustum further than the widened planes allow for)
+            xs_icp_post_pose(integrate_mailbox_, nullptr, nullptr, posted_seq_, 1);
+            list_ready_ = false;
+            check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
+        }
+    }
     // the depth scaling ran on the auxiliary stream behind the map preparation
     // (a wait is a packet the next kernel queues behind: none is enqueued for an event that has already completed — the
     // scaling finished under the ICP loop long ago)
@@ -670,13 +740,14 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     // (its stop event — the profiling pair's when profiling) instead of a marker packet behind it, which the raycast
     // launch would queue behind (~5 us of every frame).
     hipEvent_t integrate_stop = integrate_done_;
-    if (profiling) {
+    if (integrated_by_post) integrate_stop = posted_stop_;
+    else if (profiling) {
         integrate_stop = prof_ring_[prof_pending_].ev[ST_INTEGRATE][1];
         xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], integrate_stop);
         prof_ring_[prof_pending_].used[ST_INTEGRATE] = true;
     } else if (integrate_split())
         xs_integrate_set_timing_events(nullptr, integrate_stop);
-    {
+    if (!integrated_by_post) {
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
         const int zr[3][2] = {{zo0, zo1}, {zs0, zo0}, {zo1, zs1}};

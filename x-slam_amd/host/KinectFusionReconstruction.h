@@ -57,6 +57,12 @@ public:
     // the integrate call's brick classification enqueued behind the last ICP launch, with the pose that launch starts from (YAML
     // integrate_classify_ahead, default true; single GPU with the posted ICP loop): IntegrateFrame then finds the list ready
     bool integrate_classify_ahead = true;
+    // the integrate kernel itself enqueued behind that classification, handed the final pose through a mailbox of its own and a one-wave gate
+    // kernel (YAML integrate_post_pose, default FALSE; needs integrate_classify_ahead and a mailbox in device memory).  Built and measured in
+    // round 3: the gap between the last ICP reduction and the integrate kernel falls from 16 to 10 us, but 16 % of the frames are not covered by
+    // the planes of a pose two updates old at slack 2 (they fall back), and at slack 4 the wider list costs the kernel what the gap saved:
+    // +0.7 % frames/s, inside the noise — off by default (profiles/r03_ab_integrate_post.txt).
+    bool integrate_post_pose = false;
     float integrate_classify_slack = 2.0f;   // YAML integrate_classify_slack: how much wider than its own the list's frustum slack is (1 = every frame falls back)
     bool list_ready_ = false;
     float list_Rv2c_[18]{}, list_tv2c_[6]{};
@@ -214,6 +220,17 @@ private:
     unsigned long long *pending_fold_ = nullptr;
     double *pinned_records_ = nullptr;   // xs_icp_records_bytes() of host-coherent pinned memory (icp_host_fold)
     void *icp_mailbox_ = nullptr;              // pose mailbox of the posted ICP launches (xs_icp_mailbox_alloc)
+    void *integrate_mailbox_ = nullptr;        // ... and the posted integrate launch's own (never rewritten while its kernel may still poll)
+    int integrate_mailbox_in_device_ = 0;
+    unsigned integrate_mail_seq_ = 0;
+    DeviceArray<unsigned> posted_pose_;        // {command, 24 floats}: the gate kernel's hand-over to the posted integrate launch
+    bool posted_pending_ = false;              // a posted integrate launch is in the stream, waiting for its pose
+    unsigned posted_seq_ = 0;
+    hipEvent_t posted_stop_ = nullptr;         // its completion event
+    bool posted_split_ = false;
+    void EnqueuePostedIntegrate();
+    long long counters_prepared_for_ = -1;     // the frame whose counter slot has been prepared (ring half cleared)
+    unsigned long long *PrepareFrameCounters(hipStream_t st);
     int icp_mailbox_in_device_ = 0;
     unsigned long long icp_seq_ = 0;
 public:
