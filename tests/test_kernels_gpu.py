@@ -643,7 +643,7 @@ def test_icp_records_folded_on_the_host(dev, oracle, level):
     """xs_icp_accumulate_records + xs_icp_sum_records (every workgroup's record written straight to pinned host memory, the
     host adds them in index order) against xs_icp_accumulate (last workgroup adds them on the device): the same records,
     so the same inlier count and sums equal up to the association of the double additions; twice the same bits; a posted
-    launch (pose through the mailbox) gives the same bits as one given its pose; a record count per level of 45 / 150 / 512."""
+    launch (pose through the mailbox) gives the same bits as one given its pose; a record count per level of 45 / 150 / 256."""
     import ctypes as C
     torch, capi = dev
     prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
@@ -665,8 +665,8 @@ def test_icp_records_folded_on_the_host(dev, oracle, level):
     torch.cuda.synchronize()
     ref = ref.cpu().numpy()
     count = capi.icp_records_count(cols, 0, rows)
-    # eight tiles (one per wave) per workgroup at levels 1 / 2; level 0's 4 800 tiles as 512 workgroups of nine or ten (two per CU)
-    assert count == {0: 512, 1: 150, 2: 45}[level] and capi.icp_records_bytes() == 768 * 56 * 8
+    # eight tiles (one per wave) per workgroup at levels 1 / 2; level 0's 4 800 tiles as 256 sixteen-wave workgroups of 18 or 19 (one per CU)
+    assert count == {0: 256, 1: 150, 2: 45}[level] and capi.icp_records_bytes() == 768 * 56 * 8
     rec, free = _coherent_host_bytes(capi.icp_records_bytes())
     mailbox, in_dev = capi.icp_mailbox_alloc()
     try:

@@ -158,6 +158,39 @@ __device__ __forceinline__ bool search_vertex_loaded(const IcpArgs &a, const Mat
     n = nprev_g; d = vprev_g; s = vcurr_g;
     return true;
 }
+// search_vertex_loaded in two stages, for a wave that works through two tiles (the balanced level-0 instance): stage 1 asks for the
+// pixel's normal, projects it and asks for the six model-map values — of pixel (0, 0) where the projection leaves the image: resident,
+// never used — without a branch, so that the requests of the second tile go out before the first tile's answers are looked at (two tiles
+// one after the other were two dependent chains of memory round trips: the pixel phase of those waves took 6.2 us against 4.4); stage 2
+// applies the rejection tests in the order of ICP.cu:202-241.  Same outcome for every pixel as search_vertex_loaded.
+struct SearchStage { cfloat3 ncurr, vcurr_g, nprev_g, vprev_g; bool inb; };
+__device__ __forceinline__ void search_issue(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, const cfloat3 &vcurr, SearchStage &st) {
+    load_normal(a, x, y, st.ncurr);
+    st.vcurr_g = Rcurr * vcurr + tcurr;
+    const cfloat3 vcp = a.Rprev_inv * (st.vcurr_g - a.tprev);
+    const float cpx = vcp.x.re, cpy = vcp.y.re, cpz = vcp.z.re;
+    const float fu = cpx * a.intr.fx / cpz + a.intr.cx, fv = cpy * a.intr.fy / cpz + a.intr.cy;
+    int ux = fu == fu ? __float2int_rn(fu) : 0;
+    int uy = fv == fv ? __float2int_rn(fv) : 0;
+    st.inb = !(ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || cpz < 0);
+    ux = st.inb ? ux : 0; uy = st.inb ? uy : 0;
+    st.nprev_g.x = row_ptr(a.nmap_g_prev, a.mstep, uy)[ux];
+    st.nprev_g.y = row_ptr(a.nmap_g_prev, a.mstep, uy + a.rows)[ux];
+    st.nprev_g.z = row_ptr(a.nmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+    st.vprev_g.x = row_ptr(a.vmap_g_prev, a.mstep, uy)[ux];
+    st.vprev_g.y = row_ptr(a.vmap_g_prev, a.mstep, uy + a.rows)[ux];
+    st.vprev_g.z = row_ptr(a.vmap_g_prev, a.mstep, uy + 2 * a.rows)[ux];
+}
+__device__ __forceinline__ bool search_finish(const IcpArgs &a, const MatS33 &Rcurr, const SearchStage &st, cfloat3 &n, cfloat3 &d, cfloat3 &s) {
+    if (!st.inb) return false;
+    if (isnan(st.ncurr.x.re)) return false;      // ICP.cu:202-204
+    if (isnan(st.nprev_g.x.re)) return false;
+    if (re_sqrt_exceeds(squarednorm(st.vprev_g - st.vcurr_g), a.distThres, false)) return false;   // norm(...).re > distThres
+    const cfloat3 ncurr_g = Rcurr * st.ncurr;
+    if (re_sqrt_exceeds(squarednorm(cross(ncurr_g, st.nprev_g)), a.angleThres, true)) return false;   // norm(...).re >= angleThres
+    n = st.nprev_g; d = st.vprev_g; s = st.vcurr_g;
+    return true;
+}
 __device__ __forceinline__ bool search(const IcpArgs &a, const MatS33 &Rcurr, const cfloat3 &tcurr, int x, int y, cfloat3 &n, cfloat3 &d,
                                        cfloat3 &s) {
     cfloat3 ncurr, vcurr;
@@ -229,34 +262,37 @@ constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 // needs 80-104 registers.  PASSES: the LDS tile holds all 55 values of the eight waves at once (123 KB: one workgroup per CU —
 // launches of up to 256 workgroups: levels 1 and 2), 28 in two passes (64 KB, two per CU at four waves per SIMD, up to 512) or 19
 // in three (45 KB, three per CU at six waves per SIMD, 80 VGPRs: up to 768 — level 0's 600).
-// BAL (round 3; WAVES = 8, PASSES = 2, a grid of exactly two workgroups per CU): a launch whose tiles outnumber the resident waves by
-// up to a quarter — level 0 of a 640 x 480 frame: 4 800 tiles for 4 096 — deals them out evenly instead of launching a third
-// workgroup on some CUs: workgroup b takes ntiles / grid tiles, the first ntiles % grid one more (9 or 10 of them: ten tile slots), and
-// its waves 0 and 1 work through a second tile.  With 600 one-tile-per-wave workgroups 88 of the 256 CUs held three of them (24 tiles on
-// the busiest against 18.75 on average) and the launch lasted as long as those; now every CU holds 18-20.  The partition is a function
-// of the launch geometry alone, so the sums keep one fixed association (slot order = tile order inside a workgroup).
+// BAL (round 3; PASSES = 2): a launch whose tiles outnumber the resident waves by up to a quarter — level 0 of a 640 x 480 frame: 4 800 tiles
+// for 4 096 — deals them out evenly instead of launching a third workgroup on some CUs: workgroup b takes ntiles / grid tiles, the first
+// ntiles % grid one more, and its first WAVES / 4 waves work through a second tile (in lock step: search_issue / search_finish).  With 600
+// one-tile-per-wave workgroups 88 of the 256 CUs held three of them (24 tiles on the busiest against 18.75 on average) and the launch lasted
+// as long as those.  WAVES = 8: 512 workgroups (two per CU) of nine or ten tiles — 22.3 -> 20.4 us per launch inside the loop; WAVES = 16
+// (the default): 256 workgroups (one per CU, 158 KB of LDS) of 18 or 19 — half the records for the last workgroup to add and half the
+// tickets: 18.9 us (profiles/r03_ab_icp_balanced_fps.txt).  The partition is a function of the launch geometry alone, so the sums keep one
+// fixed association (slot order = tile order inside a workgroup).
 template <int POSE_SRC, int WAVES, int PASSES, bool BAL = false>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu(WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6), WAVES == 4 || PASSES == 1 ? 2 : (PASSES == 2 ? 4 : 6))))
     k_icp(const IcpArgs a) {
-    static_assert(!BAL || (WAVES == 8 && PASSES == 2), "the balanced instance is the eight-wave, two-pass one");
-    constexpr int SLOTS = BAL ? 10 : WAVES;   // tiles a workgroup can take
+    static_assert(!BAL || ((WAVES == 8 || WAVES == 16) && PASSES == 2), "the balanced instances are the eight- and sixteen-wave, two-pass ones");
+    constexpr int EXTRA = BAL ? WAVES / 4 : 0;   // waves that work through a second tile
+    constexpr int SLOTS = WAVES + EXTRA;         // tiles a workgroup can take
     XS_STAMP(0);
     // one tile per wave: the tile's current-frame vertices are on their way before the pose is (a pixel outside the image reads
     // pixel (0, y0): resident, never used)
     cfloat3 pre_v, pre_v2;
     bool pre_ok = false, pre_ok2 = false;
     int pre_x = 0, pre_y = a.y0, pre_x2 = 0, pre_y2 = a.y0;
-    if constexpr (WAVES == 8) {
+    if constexpr (WAVES >= 8) {
         const int tiles_x0 = (a.cols + 63) / 64;
         const int nt0 = tiles_x0 * (a.y1 - a.y0);
-        int t0 = blockIdx.x * 8 + (threadIdx.x >> 6), t1 = nt0;
+        int t0 = blockIdx.x * WAVES + (threadIdx.x >> 6), t1 = nt0;
         if constexpr (BAL) {
             const int base = nt0 / (int)gridDim.x, rem = nt0 % (int)gridDim.x;
             const int start = (int)blockIdx.x * base + min((int)blockIdx.x, rem), cnt = base + ((int)blockIdx.x < rem ? 1 : 0);
             const int w = threadIdx.x >> 6;
             t0 = w < cnt ? start + w : nt0;
-            t1 = 8 + w < cnt ? start + 8 + w : nt0;
+            t1 = WAVES + w < cnt ? start + WAVES + w : nt0;
         }
         const int y = a.y0 + t0 / tiles_x0, x = (t0 % tiles_x0) * 64 + (threadIdx.x & 63);
         pre_ok = t0 < nt0 && x < a.cols;
@@ -265,7 +301,7 @@ __global__ void __launch_bounds__(64 * WAVES)
         load_vertex(a, pre_x, pre_y, pre_v);
 #endif
         if constexpr (BAL) {
-            if (threadIdx.x < 128) {   // waves 0 and 1: a second tile
+            if (threadIdx.x < 64 * EXTRA) {   // the first waves: a second tile
                 const int y2 = a.y0 + t1 / tiles_x0, x2 = (t1 % tiles_x0) * 64 + (threadIdx.x & 63);
                 pre_ok2 = t1 < nt0 && x2 < a.cols;
                 if (pre_ok2) { pre_x2 = x2; pre_y2 = y2; }
@@ -387,7 +423,26 @@ __global__ void __launch_bounds__(64 * WAVES)
     // floats, one row per (wave, value), in one, two or three passes — and are added in double, lane order then wave order, as above
     cfloat row[7];
     float one = 0.0f;
-    {
+    cfloat row2[BAL ? 7 : 1];
+    float one2 = 0.0f;
+    auto fill_row = [](cfloat (&r)[7], const cfloat3 &n, const cfloat3 &d, const cfloat3 &s) {
+        const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
+        r[0] = cr.x; r[1] = cr.y; r[2] = cr.z;
+        r[3] = n.x; r[4] = n.y; r[5] = n.z;
+        r[6] = dot(n, d - s);
+    };
+    if constexpr (BAL) {
+        // both tiles of waves 0 and 1 in lock step (search_issue / search_finish above); the other waves' single tile the same way
+        SearchStage sa, sb;
+        search_issue(a, Rcurr, tcurr, pre_x, pre_y, pre_v, sa);
+        const bool two = wave < EXTRA;   // (wave-uniform)
+        if (two) search_issue(a, Rcurr, tcurr, pre_x2, pre_y2, pre_v2, sb);
+        cfloat3 n, d, s;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { row[i] = cfloat(0.0f, 0.0f); row2[i] = cfloat(0.0f, 0.0f); }   // ICP.cu:262: a rejected pixel contributes zeros
+        if (pre_ok && search_finish(a, Rcurr, sa, n, d, s)) { fill_row(row, n, d, s); one = 1.0f; }
+        if (two && pre_ok2 && search_finish(a, Rcurr, sb, n, d, s)) { fill_row(row2, n, d, s); one2 = 1.0f; }   // a workgroup with nine tiles leaves wave 1's second slot all zeros
+    } else {
         bool ok = false;
         cfloat3 n, d, s;
 #ifdef XS_ICP_NO_PREFETCH
@@ -395,30 +450,11 @@ __global__ void __launch_bounds__(64 * WAVES)
 #endif
         if (pre_ok) ok = search_vertex_loaded(a, Rcurr, tcurr, pre_x, pre_y, pre_v, n, d, s);
         if (ok) {
-            const cfloat3 cr = cross(s, n);  // ICP.cu:257-259
-            row[0] = cr.x; row[1] = cr.y; row[2] = cr.z;
-            row[3] = n.x; row[4] = n.y; row[5] = n.z;
-            row[6] = dot(n, d - s);
+            fill_row(row, n, d, s);
             one = 1.0f;
         } else {
 #pragma unroll
             for (int i = 0; i < 7; ++i) row[i] = cfloat(0.0f, 0.0f);   // ICP.cu:262: a rejected pixel contributes zeros
-        }
-    }
-    cfloat row2[BAL ? 7 : 1];
-    float one2 = 0.0f;
-    if constexpr (BAL) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) row2[i] = cfloat(0.0f, 0.0f);
-        if (wave < 2) {   // (wave-uniform) the second tile of waves 0 and 1; a workgroup with nine tiles leaves wave 1's slot all zeros
-            cfloat3 n, d, s;
-            if (pre_ok2 && search_vertex_loaded(a, Rcurr, tcurr, pre_x2, pre_y2, pre_v2, n, d, s)) {
-                const cfloat3 cr = cross(s, n);
-                row2[0] = cr.x; row2[1] = cr.y; row2[2] = cr.z;
-                row2[3] = n.x; row2[4] = n.y; row2[5] = n.z;
-                row2[6] = dot(n, d - s);
-                one2 = 1.0f;
-            }
         }
     }
     XS_STAMP(2);
@@ -442,10 +478,10 @@ __global__ void __launch_bounds__(64 * WAVES)
                     if (kre / PV == pass) tile[(wave * PV + kre % PV) * RS + lane] = p.re;
                     if (kim / PV == pass) tile[(wave * PV + kim % PV) * RS + lane] = p.im;
                     if constexpr (BAL) {
-                        if (wave < 2) {
+                        if (wave < EXTRA) {
                             const cfloat p2 = row2[i] * row2[j];
-                            if (kre / PV == pass) tile[((8 + wave) * PV + kre % PV) * RS + lane] = p2.re;
-                            if (kim / PV == pass) tile[((8 + wave) * PV + kim % PV) * RS + lane] = p2.im;
+                            if (kre / PV == pass) tile[((WAVES + wave) * PV + kre % PV) * RS + lane] = p2.re;
+                            if (kim / PV == pass) tile[((WAVES + wave) * PV + kim % PV) * RS + lane] = p2.im;
                         }
                     }
                 }
@@ -453,7 +489,7 @@ __global__ void __launch_bounds__(64 * WAVES)
             }
         if (pass == NS / PV) {
             tile[(wave * PV + NS % PV) * RS + lane] = one;
-            if constexpr (BAL) { if (wave < 2) tile[((8 + wave) * PV + NS % PV) * RS + lane] = one2; }
+            if constexpr (BAL) { if (wave < EXTRA) tile[((WAVES + wave) * PV + NS % PV) * RS + lane] = one2; }
         }
         __syncthreads();
         const int h = threadIdx.x % SPLIT;
@@ -555,7 +591,7 @@ __global__ void __launch_bounds__(64 * WAVES)
         struct alignas(16) d2 { double x, y; };
         // (eight waves: twice the threads, so eighteen row groups with sixteen loads each in flight — the same bytes in
         // flight per workgroup at half the registers per lane, which is what lets this instance run at four waves per SIMD)
-        constexpr int G = WAVES == 8 ? 18 : 9, DEPTH = WAVES == 8 ? 16 : 32;
+        constexpr int G = WAVES == 16 ? 36 : (WAVES == 8 ? 18 : 9), DEPTH = WAVES == 16 ? 8 : (WAVES == 8 ? 16 : 32);
         static_assert(TILE_BYTES >= G * 28 * 16, "row-group sums live in the fold's tile");
         d2 (*s_red)[28] = reinterpret_cast<d2 (*)[28]>(lds_tile);   // every wave is past the fold (barriers above)
         const int q = threadIdx.x % 28, g = threadIdx.x / 28;
@@ -718,12 +754,14 @@ extern "C" int xs_icp_workspace_init(void *workspace, void *stream) {
 // level of a 640 x 480 frame), else four waves striding over the tiles with the sums in registers (any size)
 static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
     const int tiles = div_up(cols, 64) * (y1 - y0);
-    // more tiles than the 4 096 waves of two eight-wave workgroups per CU, by up to a quarter: 512 workgroups of nine or ten tiles
-    // (k_icp<., 8, 2, true>; `waves` 9 marks it).  XS_ICP_BALANCED=0: the one-tile-per-wave launch (measurement aid).
-    static const bool balanced = !(getenv("XS_ICP_BALANCED") && atoi(getenv("XS_ICP_BALANCED")) == 0);
-    if (balanced && tiles > 8 * 512 && tiles <= 10 * 512) {
-        if (waves) *waves = 9;
-        return 512;
+    // more tiles than the 4 096 waves a launch can keep resident at this kernel's register / LDS budget, by up to a quarter (level 0 of a
+    // 640 x 480 frame: 4 800): one sixteen-wave workgroup per CU, 18 or 19 tiles each (k_icp<., 16, 2, true>; `waves` 17 marks it) —
+    // 256 records for the last workgroup to add instead of 512 or 600.  XS_ICP_BALANCED (measurement aid): 1 = 512 eight-wave workgroups
+    // of nine or ten tiles (`waves` 9), 0 = the one-tile-per-wave launch.
+    static const int mode = getenv("XS_ICP_BALANCED") ? atoi(getenv("XS_ICP_BALANCED")) : 2;
+    if (mode != 0 && tiles > 8 * 512 && tiles <= 10 * 512) {
+        if (waves) *waves = mode == 1 ? 9 : 17;
+        return mode == 1 ? 512 : 256;
     }
     int w = 8, blocks = div_up(tiles, 8);
     if (blocks > XS_ICP_MAX_BLOCKS) {
@@ -737,6 +775,7 @@ static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
 template <int POSE_SRC>
 static void icp_dispatch(int waves, int blocks, hipStream_t st, const IcpArgs &a) {
     if (waves == 9) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2, true>), dim3(blocks), dim3(512), 0, st, a);
+    else if (waves == 17) hipLaunchKernelGGL((k_icp<POSE_SRC, 16, 2, true>), dim3(blocks), dim3(1024), 0, st, a);
     else if (waves == 8 && blocks <= 256) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 1>), dim3(blocks), dim3(512), 0, st, a);
     else if (waves == 8 && blocks <= 512) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 2>), dim3(blocks), dim3(512), 0, st, a);
     else if (waves == 8) hipLaunchKernelGGL((k_icp<POSE_SRC, 8, 3>), dim3(blocks), dim3(512), 0, st, a);
