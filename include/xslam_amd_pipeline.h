@@ -113,6 +113,9 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4);
  * iteration n (0-based, over all levels) of the next alignment fail as for a singular system (KinectFusionReconstruction.cpp:203-210). */
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v);
 void xs_kf_debug_fail_icp_iteration(void *kf, int n);
+/* Rebuilds the sign map of the ray march (xslam_amd.h) from the volume: to be called by whoever writes the value array through
+ * xs_kf_volume_ptr (loadCheckpoint does it itself).  No-op in shard mode or with raycast_sign_map: false. */
+void xs_kf_rebuild_sign_map(void *kf);
 
 /* volume checkpoint (value + grad + weight + poses)   cf. saveTSDFVolume, .cpp:438-447 */
 int xs_kf_save_checkpoint(void *kf, const char *path);

@@ -236,6 +236,60 @@ def test_brick_list_classified_ahead_changes_nothing(dev):
         r.close()
 
 
+@pytest.mark.parametrize("n,scene", [(128, "s1"), (512, "s1"), (256, "s3")])
+def test_ray_march_from_the_sign_map_changes_nothing(dev, tmp_path, n, scene):
+    """raycast_sign_map (the integrate kernel marks the bricks it writes negative values into, the march starts each ray at the first
+    step that can end it: csrc/xs_signmap.h) against the march of every step, with bricks of 8^3 and of 16^3 voxels: the same poses,
+    counts, model maps and volume, bit for bit, over 12 frames — a blank frame among them — and after a checkpoint is loaded into a
+    fresh pipeline (whose map is rebuilt from the restored volume)."""
+    torch, pl = dev
+    prm = synth.s1_params(n)    # (S3 — the box room — shares S1's placement and camera path)
+    frame = synth.s1_frame if scene == "s1" else synth.s3_frame
+    runs = [pl.KinectFusion(dict(prm, raycast_sign_map=False)), pl.KinectFusion(dict(prm, raycast_sign_map=True)),
+            pl.KinectFusion(dict(prm, raycast_sign_map=True, raycast_sign_map_shift=4))]
+    blank = upload(torch, np.zeros_like(frame(0)))
+
+    def maps_same(r):
+        # every ray that hit, all three planes (the y and z planes of a ray that missed are not written: they keep what the buffer held)
+        H_ = synth.HEIGHT
+        for which in ("vmaps_g_prev", "nmaps_g_prev"):
+            a_, b_ = r.map(which, 0), runs[0].map(which, 0)
+            valid = np.isfinite(b_[:H_, :, 0])
+            assert np.array_equal(valid, np.isfinite(a_[:H_, :, 0]))
+            for p_ in range(3):
+                assert np.array_equal(a_[p_ * H_:(p_ + 1) * H_][valid].view(np.int32), b_[p_ * H_:(p_ + 1) * H_][valid].view(np.int32))
+
+    def same(r):
+        assert np.array_equal(r.world2camera(), runs[0].world2camera())
+        assert r.last_U() == runs[0].last_U() and r.last_hits() == runs[0].last_hits()
+        maps_same(r)
+
+    for k in list(range(5)) + ["blank"] + list(range(5, 11)):
+        d = blank if k == "blank" else upload(torch, frame(k))
+        rcs = [r.process_frame(d) for r in runs]
+        assert all(rc == (0 if k == "blank" else 1) for rc in rcs), (k, rcs)
+        for r in runs[1:]:
+            same(r)
+    assert runs[0].last_hits() > 0.5 * synth.HEIGHT * synth.WIDTH
+    path = str(tmp_path / "vol.ckpt")
+    runs[0].save_checkpoint(path)
+    fresh = pl.KinectFusion(dict(prm, raycast_sign_map=True))
+    assert fresh.load_checkpoint(path)
+    runs.append(fresh)
+    maps_same(fresh)   # the maps the load regenerated from the restored volume
+    for k in (11, 12):
+        d = upload(torch, frame(k))
+        assert all(r.process_frame(d) == 1 for r in runs)
+        for r in runs[1:]:
+            same(r)
+    v0, w0, g0 = runs[0].volume()
+    for r in runs[1:]:
+        v, w, g = r.volume()
+        assert np.array_equal(w, w0) and np.array_equal(v, v0) and np.array_equal(g, g0)
+    for r in runs:
+        r.close()
+
+
 def test_device_pose_solve_matches_host_solve(dev):
     """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
     the reference's one host solve per iteration — on the same frames: identical first-iteration sums,

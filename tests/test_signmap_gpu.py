@@ -1,0 +1,197 @@
+"""GPU: the sign map (include/xslam_amd.h, csrc/xs_signmap.h) — the ray march started at the first step that can end it.
+The reference has no such thing (RayCaster.cu:222-247 walks every step from t = 0.2 m); what is asserted here is therefore equality
+with OUR OWN full march, which the oracle tests pin to the reference: the same crossing times, march lengths, vertices, normals and
+hit counts, bit for bit, on fused scenes and on adversarial volumes, and that the map is a superset of the bricks holding negatives."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import intr_of, s1_transforms, synth, tranc_dist
+
+pytestmark = pytest.mark.gpu
+H, W = synth.HEIGHT, synth.WIDTH
+HEAD = 64 + 320 * 4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch, importlib.import_module("x-slam_amd.capi")
+
+
+def fuse(torch, capi, prm, res, frames, signmap=None, shift=3, bricks=True, depth_fn=None, threshold=0.0):
+    X, Y, Z = res
+    value = torch.zeros((Y * Z, X), dtype=torch.float32, device="cuda")
+    weight = torch.zeros((Y * Z, X), dtype=torch.int32, device="cuda")
+    grad = torch.zeros((Y * Z, X), dtype=torch.float32, device="cuda")
+    scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(capi.integrate_workspace_bytes(res, Z), dtype=torch.uint8, device="cuda") if bricks else None
+    if signmap is not None:
+        capi.signmap_reset(signmap, res, shift, tranc_dist(prm))
+    capi.integrate_set_signmap(signmap)
+    try:
+        for k in frames:
+            d = depth_fn(k) if depth_fn else synth.s1_frame(k)
+            depth = torch.from_numpy(d.astype(np.int16)).cuda()
+            T = s1_transforms(k, prm)
+            capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+            capi.integrate_scaled_ex(scaled, W * 4, H, W, intr_of(prm), prm["max_integration_weight"], res, prm["tsdf_voxel_size"],
+                                     T["Rv2c"], T["tv2c"], tranc_dist(prm), value, weight, grad, X * 4, 0, threshold=threshold,
+                                     depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+    finally:
+        capi.integrate_set_signmap(None)
+    return value, weight, grad
+
+
+def cast(torch, capi, prm, res, value, grad, T, signmap=None, shift=3, tranc=None):
+    X = res[0]
+    vm = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    nm = torch.full((3 * H, W, 2), 5.0, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(H * W, dtype=torch.float32, device="cuda")
+    steps = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+    hits = torch.zeros(1, dtype=torch.int64, device="cuda")
+    capi.raycast_set_step_buffer(steps)
+    capi.raycast_set_signmap(signmap, shift, tranc_dist(prm) if tranc is None else tranc)
+    try:
+        capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], value, grad,
+                     X * 4, vm, nm, W * 8, H, W, hits=hits, workspace=ws)
+        torch.cuda.synchronize()
+    finally:
+        capi.raycast_set_step_buffer(None)
+        capi.raycast_set_signmap(None)
+    return [t.cpu().numpy() for t in (vm, nm, ws, steps, hits)]
+
+
+def same_bits(a, b):
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.int32) if x.dtype != np.int64 else x, y.view(np.int32) if y.dtype != np.int64 else y)
+
+
+def bricks_of(torch, signmap, res, shift):
+    e = 1 << shift
+    nx, ny, nz = [(r + e - 1) >> shift for r in res]
+    nb = nx * ny * nz
+    pad = (nb + 255) & ~255
+    raw = signmap[HEAD:HEAD + nb].view(nz, ny, nx)
+    dil = signmap[HEAD + pad:HEAD + pad + nb].view(nz, ny, nx)
+    return raw, dil
+
+
+def negatives_by_brick(torch, value, res, shift):
+    X, Y, Z = res
+    e = 1 << shift
+    neg = (value.view(Z, Y, X) < 0).to(torch.float32)[None, None]
+    return torch.nn.functional.max_pool3d(neg, e, ceil_mode=True)[0, 0] > 0
+
+
+@pytest.mark.parametrize("n,shift", [(128, 3), (256, 3), (256, 4), (512, 3), (512, 4)])
+def test_march_from_the_sign_map_gives_the_same_bits(dev, n, shift):
+    torch, capi = dev
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    sm = torch.zeros(capi.signmap_bytes(res, shift), dtype=torch.uint8, device="cuda")
+    value, weight, grad = fuse(torch, capi, prm, res, [0, 1, 2], signmap=sm, shift=shift)
+    plain = fuse(torch, capi, prm, res, [0, 1, 2])                # marking the map leaves the volume alone
+    assert torch.equal(value, plain[0]) and torch.equal(weight, plain[1]) and torch.equal(grad, plain[2])
+    raw, dil = bricks_of(torch, sm, res, shift)
+    neg = negatives_by_brick(torch, value, res, shift)
+    assert int(neg.sum()) > 50 and bool((raw[neg] == 1).all())    # a superset of the bricks that hold a negative voxel
+    grown = torch.nn.functional.max_pool3d(raw.to(torch.float32)[None, None], 3, stride=1, padding=1)[0, 0] > 0
+    assert bool((dil[grown] == 1).all())                          # ... grown by one brick
+    assert bool((dil[0] == 1).all()) and bool((dil[:, :, -1] == 1).all())   # ... and the boundary shell
+    for k in (2, 3, 9):
+        T = s1_transforms(k, prm)
+        full = cast(torch, capi, prm, res, value, grad, T)
+        fast = cast(torch, capi, prm, res, value, grad, T, signmap=sm, shift=shift)
+        same_bits(full, fast)
+        assert int(full[4][0]) > 0.5 * H * W
+    # the map rebuilt from the volume alone (a checkpoint was loaded): again the same bits, and no brick more than the marked ones
+    sm2 = torch.zeros_like(sm)
+    capi.signmap_rebuild(sm2, res, shift, tranc_dist(prm), value, n * 4)
+    torch.cuda.synchronize()
+    raw2, _ = bricks_of(torch, sm2, res, shift)
+    assert bool(((raw2 == 1) == neg).all()) and bool((raw >= raw2).all())
+    T = s1_transforms(3, prm)
+    same_bits(cast(torch, capi, prm, res, value, grad, T), cast(torch, capi, prm, res, value, grad, T, signmap=sm2, shift=shift))
+
+
+def test_sign_map_on_adversarial_volumes(dev):
+    """Volumes no fusion would produce: isolated negative voxels in free space (a ray must stop at each), negative voxels at brick corners,
+    a wholly negative volume, a camera outside the volume, a ragged size (the last brick overhangs)."""
+    torch, capi = dev
+    n = 96
+    prm = synth.s1_params(n)
+    rng = np.random.default_rng(11)
+    cases = []
+    for res in ([96, 96, 96], [90, 70, 83]):
+        X, Y, Z = res
+        v = np.where(rng.random((Z, Y, X)) < 2e-4, -0.5, rng.random((Z, Y, X))).astype(np.float32)
+        cases.append((res, v, "isolated negatives"))
+        v = np.full((Z, Y, X), 0.3, np.float32)
+        v[7::8, 7::8, 7::8] = -0.2
+        v[8::16, 8::16, 8::16] = -0.2
+        cases.append((res, v, "brick corners"))
+        cases.append((res, np.full((Z, Y, X), -0.4, np.float32), "all negative"))
+        cases.append((res, np.zeros((Z, Y, X), np.float32), "never observed"))
+    for res, v, name in cases:
+        value = torch.from_numpy(v.reshape(res[1] * res[2], res[0])).cuda()
+        grad = torch.zeros_like(value)
+        for shift in (2, 3, 4):
+            sm = torch.zeros(capi.signmap_bytes(res, shift), dtype=torch.uint8, device="cuda")
+            capi.signmap_rebuild(sm, res, shift, tranc_dist(prm), value, res[0] * 4)
+            for k in (0, 5):
+                T = s1_transforms(k, prm)
+                for out in (0.0, 4.0):     # 4.0: the camera 4 m further back, outside the volume
+                    T2 = dict(T)
+                    T2["tc2v"] = T["tc2v"].copy()
+                    T2["tc2v"][2, 0] -= out   # Re z of the camera position in the volume frame
+                    full = cast(torch, capi, prm, res, value, grad, T2)
+                    fast = cast(torch, capi, prm, res, value, grad, T2, signmap=sm, shift=shift)
+                    for x, y in zip(full, fast):
+                        assert np.array_equal(x.view(np.int32) if x.dtype != np.int64 else x, y.view(np.int32) if y.dtype != np.int64 else y), (name, res, shift, k, out)
+
+
+def test_sign_map_of_the_column_walk_and_the_bilinear_branch(dev):
+    """The integrate paths other than the brick list mark the map too: the column walk (no workspace) and the bilinear depth lookup."""
+    torch, capi = dev
+    n = 128
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    for bricks, threshold in ((False, 0.0), (True, 0.05), (False, 0.05)):
+        sm = torch.zeros(capi.signmap_bytes(res, 3), dtype=torch.uint8, device="cuda")
+        value, weight, grad = fuse(torch, capi, prm, res, [0, 1], signmap=sm, bricks=bricks, threshold=threshold)
+        raw, dil = bricks_of(torch, sm, res, 3)
+        neg = negatives_by_brick(torch, value, res, 3)
+        assert int(neg.sum()) > 50 and bool((raw[neg] == 1).all())
+        T = s1_transforms(2, prm)
+        same_bits(cast(torch, capi, prm, res, value, grad, T), cast(torch, capi, prm, res, value, grad, T, signmap=sm))
+
+
+def test_sign_map_misuse_is_refused(dev):
+    torch, capi = dev
+    n = 64
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    assert capi.signmap_bytes(res, 1) == 0 and capi.signmap_bytes(res, 7) == 0 and capi.signmap_bytes([0, 4, 4], 3) == 0
+    sm = torch.zeros(capi.signmap_bytes(res, 3), dtype=torch.uint8, device="cuda")
+    capi.signmap_reset(sm, res, 3, tranc_dist(prm))
+    value = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+    T = s1_transforms(0, prm)
+    with pytest.raises(RuntimeError, match="truncation"):      # the time table belongs to another truncation distance
+        cast(torch, capi, prm, res, value, value, T, signmap=sm, tranc=2 * tranc_dist(prm))
+    with pytest.raises(RuntimeError, match="time table"):      # more march steps than the table holds
+        capi.signmap_reset(sm, res, 3, 1e-4)
+    # a slab launch cannot mark a whole-volume map
+    weight = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
+    scaled = torch.ones((H, W), dtype=torch.float32, device="cuda")
+    capi.integrate_set_signmap(sm)
+    try:
+        with pytest.raises(RuntimeError, match="slab"):
+            capi.integrate_scaled(scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm),
+                                  value, weight, value.clone(), n * 4, z0=0, z1=n // 2)
+    finally:
+        capi.integrate_set_signmap(None)

@@ -113,6 +113,12 @@ _SIGS = {
     "xs_integrate_set_pose_mailbox": (None, [_vp, C.c_uint, C.c_float, _vp]),
     "xs_integrate_pose_covered": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_const_div_prepare": (C.c_uint, [C.c_float]),
+    "xs_raycast_signmap_shift": (C.c_int, [_f32p, C.c_float, C.c_float]),
+    "xs_signmap_bytes": (C.c_size_t, [_i32p, C.c_int]),
+    "xs_signmap_reset": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp]),
+    "xs_signmap_rebuild": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp, C.c_size_t, _vp]),
+    "xs_integrate_set_signmap": (None, [_vp]),
+    "xs_raycast_set_signmap": (None, [_vp, C.c_int, C.c_float]),
     "xs_const_div_state": (C.c_uint, [C.c_float]),
     "xs_const_div_enable": (C.c_int, [C.c_int]),
 }
@@ -399,6 +405,34 @@ def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, gr
 def raycast_set_step_buffer(buf):
     """Per-ray march lengths of the following raycast calls go to buf (rows x cols int32 on the device); None switches it off."""
     _lib.xs_raycast_set_step_buffer(_ptr(buf))
+
+
+def raycast_signmap_shift(intr, voxel_size, tranc_dist):
+    """xs_raycast_signmap_shift: the finest sign map the march can use for this configuration (log2 of the brick edge in voxels), 0 if none."""
+    return int(_lib.xs_raycast_signmap_shift(_fa(intr, 4).ctypes.data_as(_f32p), voxel_size, tranc_dist))
+
+
+def signmap_bytes(res, shift=3):
+    """xs_signmap_bytes: device bytes of a sign map (one byte per brick of 2^shift voxels a side, twice, + the march's time table)."""
+    return int(_lib.xs_signmap_bytes(_ia(res, 3).ctypes.data_as(_i32p), shift))
+
+
+def signmap_reset(signmap, res, shift, tranc_dist, stream=None):
+    check(_lib.xs_signmap_reset(_ptr(signmap), _ia(res, 3).ctypes.data_as(_i32p), shift, tranc_dist, _stream(stream)))
+
+
+def signmap_rebuild(signmap, res, shift, tranc_dist, value, vol_step, stream=None):
+    check(_lib.xs_signmap_rebuild(_ptr(signmap), _ia(res, 3).ctypes.data_as(_i32p), shift, tranc_dist, _ptr(value), vol_step, _stream(stream)))
+
+
+def integrate_set_signmap(signmap):
+    """The sign map the following integrate calls mark (None: none)."""
+    _lib.xs_integrate_set_signmap(_ptr(signmap))
+
+
+def raycast_set_signmap(signmap, shift=3, tranc_dist=0.0):
+    """The sign map the following raycast calls (with a workspace) start their rays from (None: every ray from t = 0.2)."""
+    _lib.xs_raycast_set_signmap(_ptr(signmap), shift, tranc_dist)
 
 
 def raycast_slab(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap,

@@ -10,6 +10,8 @@
 // real(ray_start + ray_dir * t) performs; the gradient volume is read only at the crossing,
 // where the 2 + 6 trilinear samples run in complex arithmetic.
 #include "xs_device.h"
+#include "xs_signmap.h"
+#include <type_traits>
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
@@ -32,6 +34,8 @@ struct RaycastArgs {
     int *keys;     // slab mode: per pixel, (step << 1 | no_hit) of the first event among owned steps, INT_MAX if none
     unsigned long long *hits;
     int *steps;    // optional (measurement): per pixel, the march iterations the reference's loop (RayCaster.cu:222-247) runs for this ray
+    SignMap sm;    // sm.dil != null (single-GPU march only): start each ray at the first step that can end it (xs_signmap.h)
+    float sm_dt; int sm_rounds;   // sign map: spacing of the per-wave samples along the tile's centre ray; 64 * sm_rounds of them
 };
 
 namespace {
@@ -177,7 +181,7 @@ struct Vol {
 // (crossing kernels: five waves per SIMD — a 640 x 480 frame is 4 800 waves on 1 024 SIMDs, all resident at once; the
 // two-samples-per-round-trip form would otherwise take 104 registers, i.e. four)
 constexpr int raycast_min_waves(int mode) { return mode == 3 || mode == 5 ? 5 : 1; }
-template <int MODE, bool OFF32, bool SHORT>
+template <int MODE, bool OFF32, bool SHORT, bool MAP = false>   // MAP (MODE 2 only): start every ray from the sign map (a.sm)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycast_min_waves(MODE)))) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1 || MODE == 4 || MODE == 5;
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
@@ -193,6 +197,68 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
     const int x = (tile % tiles_x) * 2 * wx + (wave & 1) * wx + (lane & (wx - 1));
     const int y = (tile / tiles_x) * 2 * wy + (wave >> 1) * wy + (lane >> a.wshift);
     unsigned hit = 0;
+    // MAP: which iterations of the reference's loop this wave's rays have to evaluate, as a wave-uniform bit mask (bit k = iteration k)
+    constexpr int UW = SIGNMAP_MAX_STEPS / 64;
+    unsigned long long unsafe[UW];
+#pragma unroll
+    for (int w = 0; w < UW; ++w) unsafe[w] = 0ull;
+    if (MAP && tile_ok) {
+        // Sign map, one pass per WAVE.  The 64 lanes sample the ray through the centre of the wave's pixel tile at t_i = 0.2 + i * dt — every
+        // sample of the ray in one or two byte gathers from a table the L2 holds.  Every ray of the tile stays within t * delta of the
+        // centre ray (delta: the tile's half diagonal in normalised image coordinates — normalising vectors of length >= 1 does not
+        // stretch their difference), and the host chose dt with dt + (5.2 + dt) * delta <= 0.9 brick edges: every point any of the tile's
+        // rays reaches at a parameter in [t_i, t_i + dt] lies in sample i's brick or one of its 26 neighbours, so a clear byte (xs_signmap.h)
+        // says that no iteration whose sample falls into that stretch can see an event, on any of these rays.
+        const int x0 = (tile % tiles_x) * 2 * wx + (wave & 1) * wx, y0 = (tile / tiles_x) * 2 * wy + (wave >> 1) * wy;
+        cfloat3 rc;
+        rc.x = cfloat(((float)x0 + 0.5f * (float)(wx - 1) - a.intr.cx) / a.intr.fx);
+        rc.y = cfloat(((float)y0 + 0.5f * (float)(wy - 1) - a.intr.cy) / a.intr.fy);
+        rc.z = cfloat(1.f);
+        const cfloat3 dc = normalized((a.Rc2v * rc + a.tc2v) - a.tc2v);
+        const float inv_edge = 1.0f / (a.voxel_size * (float)(1 << a.sm.shift));
+        unsigned long long flagged[2] = {~0ull, ~0ull};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h < a.sm_rounds) {
+                const float tt = 0.2f + a.sm_dt * (float)(lane + 64 * h);
+                const int qx = cvt_flr((a.tc2v.x.re + dc.x.re * tt) * inv_edge), qy = cvt_flr((a.tc2v.y.re + dc.y.re * tt) * inv_edge),
+                          qz = cvt_flr((a.tc2v.z.re + dc.z.re * tt) * inv_edge);
+                const bool in = (unsigned)qx < (unsigned)a.sm.nx && (unsigned)qy < (unsigned)a.sm.ny && (unsigned)qz < (unsigned)a.sm.nz;
+                const unsigned char f = a.sm.dil[in ? (qz * a.sm.ny + qy) * a.sm.nx + qx : 0];
+                flagged[h] = __builtin_amdgcn_ballot_w64(!in || f);
+            }
+        }
+        // Iteration k (lane k % 64 of word k / 64) samples the volume at parameter t[k + 1] — the table holds the reference's running
+        // float sum t[0] = 0.2, t[j + 1] = t[j] + time_step.  It may be left out if that parameter lies in the stretch of a clear sample
+        // (within 2 % of a stretch's end, of the neighbouring one as well: the float error of the position is ~1e-6 of it).
+        const float inv_dt = 1.0f / a.sm_dt;
+        auto is_set = [&](int i) -> bool {   // sample i flagged (or none such: beyond the samples taken)
+            return (unsigned)i >= (unsigned)(64 * a.sm_rounds) || (((i < 64 ? flagged[0] : flagged[1]) >> (i & 63)) & 1ull) != 0ull;
+        };
+#pragma unroll
+        for (int w = 0; w < UW; ++w) {
+            const int k = 64 * w + lane;
+            if (64 * w <= a.sm.nt - 2) {   // (wave-uniform)
+                const bool runs = k <= a.sm.nt - 2;   // iteration k runs while t[k] < max_time, i.e. k <= nt - 2
+                const float tau = a.sm.t[runs ? k + 1 : 0];
+                const float xq = (tau - 0.2f) * inv_dt;
+                const int i = cvt_flr(xq);
+                const float fr = xq - (float)i;
+                const bool uns = is_set(i) || (fr < 0.02f && is_set(i - 1)) || (fr > 0.98f && is_set(i + 1));
+                unsafe[w] = __builtin_amdgcn_ballot_w64(runs && uns);
+            }
+        }
+    }
+    // first iteration >= k that has to be evaluated, or -1 (wave-uniform)
+    auto next_unsafe = [&](int k) -> int {
+        int r = -1;
+#pragma unroll
+        for (int w = UW - 1; w >= 0; --w) {
+            const unsigned long long m = (k >> 6) < w ? unsafe[w] : ((k >> 6) == w ? unsafe[w] & (~0ull << (k & 63)) : 0ull);
+            r = m ? 64 * w + (int)__builtin_ctzll(m) : r;
+        }
+        return r;
+    };
     if (tile_ok && x < a.cols && y < a.rows) {
         int key = 0x7fffffff, step_index = 0;
         if (MODE == 1 || MODE == 4) {
@@ -390,10 +456,64 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
             // time (four gathers in flight per lane instead of one dependent chain) and then tested
             // in order; whatever lies behind the first event is discarded.  The times are the same
             // float running sum the one-step loop forms.
-            float tsdf = vol.read_value(gx, gy, gz);
             float cross = -1.f;
             bool done = false;
             int nsteps = 0;   // iterations of the reference's loop so far (only stored when a.steps is given)
+            if (MAP) {
+                // The march over the iterations the wave has to evaluate, eight at a time; stretches in between are jumped over.  An iteration
+                // that is left out has its sample in a brick without negative voxels, so the value the reference carries out of it is positive:
+                // the first iteration behind a jump starts from "positive" (its magnitude never matters), iteration 0 from the clamped start
+                // voxel as in the reference.  Within a batch the times are the reference's own running sum from t[k].
+                constexpr int NS = 8;
+                int k = next_unsafe(0);
+                float prev = 1.0f;
+                if (k == 0) prev = vol.read_value(gx, gy, gz);
+                bool finished = false;
+                nsteps = a.sm.nt - 1;   // (no event: the loop runs until its own condition ends it)
+                while (k >= 0) {
+                    float val[NS];
+                    unsigned oob = 0;
+                    const float tb = a.sm.t[k];
+                    if (!finished) {
+                        float t = tb;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const float tn = t + time_step;
+                            const int jx = voxel_index<SHORT>(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                            const int jy = voxel_index<SHORT>(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                            const int jz = voxel_index<SHORT>(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                            const bool ok = (t < max_time) && (unsigned)jx < (unsigned)a.X && (unsigned)jy < (unsigned)a.Y && (unsigned)jz < (unsigned)a.Z;
+                            oob |= (ok ? 0u : 1u) << i;
+                            if (OFF32) val[i] = vol.value_at(ok ? vol.offset32(jx, jy, jz) : 0u) + 1e-5f;
+                            else val[i] = vol.read_value(ok ? jx : 0, ok ? jy : 0, ok ? jz : a.zs0);
+                            t += time_step;
+                        }
+                        unsigned down = 0, up = 0;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            down |= ((prev > 0.f && val[i] < 0.f) ? 1u : 0u) << i;
+                            up |= ((prev < 0.f && val[i] > 0.f) ? 1u : 0u) << i;
+                            prev = val[i];
+                        }
+                        const unsigned ev = oob | down | up;
+                        if (ev) {
+                            const int e = __ffs(ev) - 1;
+                            float tce = tb;   // time_curr of iteration k + e: the same e additions once more (once per ray)
+                            for (int i = 0; i < e; ++i) tce += time_step;
+                            if (!((oob >> e) & 1u) && ((down >> e) & 1u)) cross = tce;
+                            nsteps = k + e + (tce < max_time ? 1 : 0);   // the reference's loop runs iteration k + e unless its own condition ends it first
+                            finished = true;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) break;
+                    const int kn = next_unsafe(k + NS);
+                    if (kn != k + NS) prev = 1.0f;
+                    k = kn;
+                }
+                done = true;
+                time_curr = max_time;
+            }
+            float tsdf = vol.read_value(gx, gy, gz);
             while (!done && time_curr < max_time) {
                 // eight steps at once, straight-line: positions, clamped (always valid) gathers, then one
                 // event mask — out of range / past the end, - to + (no vertex), + to - (crossing) — whose
@@ -465,6 +585,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
 static thread_local int *g_ray_steps = nullptr;
 extern "C" void xs_raycast_set_step_buffer(int *steps_dev) { g_ray_steps = steps_dev; }
 
+static int ray_wshift() {
+    static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
+    return (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
+}
+// spacing of the per-wave sign-map samples (k_raycast, MAP): dt + (5.2 + dt) * delta <= 0.9 brick edges, delta = the pixel tile's half
+// diagonal in normalised image coordinates (+ 1 %); at most two samples per lane must reach from t = 0.2 past max_time = 5
+static bool sign_map_spacing(float fx, float fy, int wshift, float voxel_size, int shift, float &dt_out, int &rounds_out) {
+    const float hx = 0.5f * (float)((1 << wshift) - 1) / fabsf(fx), hy = 0.5f * (float)((64 >> wshift) - 1) / fabsf(fy);
+    const float delta = 1.01f * sqrtf(hx * hx + hy * hy) + 1e-6f, edge = voxel_size * (float)(1 << shift);
+    const float dt = (0.9f * edge - 5.2f * delta) / (1.0f + delta);
+    const int need = dt > 0.0f ? (int)ceilf(4.9f / dt) + 1 : 1 << 30;
+    if (!(need <= 128)) return false;
+    dt_out = dt; rounds_out = need <= 64 ? 1 : 2;
+    return true;
+}
+extern "C" int xs_raycast_signmap_shift(const float *intr4, float voxel_size, float tranc_dist) {
+    if (!intr4 || !(voxel_size > 0.0f) || signmap_steps(tranc_dist * 0.8f) == 0) return 0;
+    float dt; int rounds;
+    for (int shift = 2; shift <= 6; ++shift)
+        if (sign_map_spacing(intr4[0], intr4[1], ray_wshift(), voxel_size, shift, dt, rounds)) return shift;
+    return 0;
+}
+
+// the sign map (xs_signmap.h) the following single-GPU launches of this thread start their rays from; null = every ray from t = 0.2
+static thread_local void *g_ray_signmap = nullptr;
+static thread_local int g_ray_signmap_shift = 0;
+static thread_local float g_ray_signmap_tranc = 0.0f;
+extern "C" void xs_raycast_set_signmap(const void *signmap, int shift, float tranc_dist) {
+    g_ray_signmap = const_cast<void *>(signmap); g_ray_signmap_shift = shift; g_ray_signmap_tranc = tranc_dist;
+}
+
 // do the resident planes of one volume array span at most 4 GiB (and the 24-bit products hold)?
 static bool fits32(const RaycastArgs &a) {
     const unsigned long long rows = (unsigned long long)(a.zs1 - a.zs0) * (unsigned long long)a.Y;
@@ -512,14 +663,30 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
     a.hits = hits_dev; a.cross_t = workspace; a.steps = g_ray_steps;
-    static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
-    a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
+    a.sm = SignMap{};
+    if (g_ray_signmap && workspace) {
+        // the map's time table was written for one truncation distance (xs_signmap_reset): any other would resume at wrong times
+        if (g_ray_signmap_tranc * 0.8f != a.time_step || g_ray_signmap_shift < 2 || g_ray_signmap_shift > 6)
+            return xs_set_error(hipErrorInvalidValue, "xs_raycast: the sign map was prepared for another truncation distance");
+        static thread_local float nt_for = 0.0f;
+        static thread_local int nt = 0;
+        if (nt_for != a.time_step) { nt = signmap_steps(a.time_step); nt_for = a.time_step; }
+        if (nt == 0) return xs_set_error(hipErrorInvalidValue, "xs_raycast: the march has more steps than the sign map's time table holds");
+        a.sm = signmap_view(g_ray_signmap, res, g_ray_signmap_shift, nt);
+    }
+    a.wshift = ray_wshift();
+    a.sm_dt = 0.0f; a.sm_rounds = 0;
+    if (a.sm.dil && !sign_map_spacing(a.intr.fx, a.intr.fy, a.wshift, voxel_size, a.sm.shift, a.sm_dt, a.sm_rounds))
+        return xs_set_error(hipErrorInvalidValue, "xs_raycast: the sign map's bricks are too small for a wave's pixel tile (xs_raycast_signmap_shift gives a usable shift)");
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
     const bool off32 = fits32(a);
     if (workspace) {
         // march (few registers, many waves, eight gathers in flight per lane) then the crossings
         a.hits = nullptr;
-        if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<2, true, true> : k_raycast<2, true, false>), grid, block, 0, (hipStream_t)stream, a);
+        if (a.sm.dil) {
+            if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<2, true, true, true> : k_raycast<2, true, false, true>), grid, block, 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_raycast<2, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+        } else if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<2, true, true> : k_raycast<2, true, false>), grid, block, 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((k_raycast<2, false, false>), grid, block, 0, (hipStream_t)stream, a);
         a.hits = hits_dev;
         if (off32) hipLaunchKernelGGL((k_raycast<3, true, false>), grid, block, 0, (hipStream_t)stream, a);
@@ -560,6 +727,7 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
     a.hits = nullptr; a.cross_t = nullptr; a.steps = nullptr;
+    a.sm = SignMap{};   // (a slab sees only its own planes: every rank marches every step it owns)
     static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
     a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);

@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include "xs_device.h"
 #include "xs_mailbox.h"
+#include "xs_signmap.h"
 #include <algorithm>
 #include <stdlib.h>
 #include "../../include/xslam_amd.h"
@@ -158,6 +159,7 @@ struct IntegrateArgs {
     unsigned kflags;              // KF_*
     const unsigned *mailbox; unsigned mailbox_seq;   // posted pose: what k_pose_gate polls ...
     unsigned *pose_dev;                              // ... and where it leaves {cmd, 24 floats} for k_integrate_bricks<., ., true>
+    unsigned char *signmap;       // xs_signmap.h buffer (whole-volume launches) or null: bricks that receive a negative value are marked
 };
 enum { KF_ALWAYS_STORE = 1u };    // write every updated voxel's three words even where the bits do not change (measurement aid)
 
@@ -393,6 +395,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
     float *gpos = row_ptr(a.grad, a.vstep, 0) + row * (a.vstep / 4) + x;
     const size_t zstride = (size_t)a.Y * (a.vstep / 4);
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    float vmin = 0.0f;   // smallest value written by this span (sign map: one v_min per written voxel, one test per span)
     if constexpr (OFF32) {
         char *bv = reinterpret_cast<char *>(a.value) + ubase, *bw = reinterpret_cast<char *>(a.weight) + ubase, *bg = reinterpret_cast<char *>(a.grad) + ubase;
         const unsigned plane = (unsigned)a.Y * (unsigned)a.vstep;
@@ -407,10 +410,12 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
                 if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
                 if ((unsigned)(ow ^ w0) | always) *wpos = ow;
                 if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
+                vmin = fminf(vmin, ov);
                 ++n_upd;
             }
             else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
         }
+        if (vmin < 0.0f && a.signmap) signmap_mark_span(a.signmap, x, y, zb, ze);
         return n_upd;
     }
     // (Requesting the state of voxel z+1 one trip ahead, in front of or behind the depth gather, was
@@ -437,6 +442,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
             if ((unsigned)(ow ^ w0) | always) *wpos = ow;
             if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
 #endif
+            vmin = fminf(vmin, ov);
             ++n_upd;
         }
         else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
@@ -445,6 +451,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
         // still in flight at the loop head, and the wait the compiler puts there to protect their
         // registers also waits for the previous trip's stores to be acknowledged)
     }
+    if (vmin < 0.0f && a.signmap) signmap_mark_span(a.signmap, x, y, zb, ze);
     return n_upd;
 }
 
@@ -799,6 +806,9 @@ extern "C" void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mail
 }
 
 /* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
+// the sign map (xs_signmap.h) the following launches of this thread mark; null = none
+static thread_local unsigned char *g_signmap = nullptr;
+extern "C" void xs_integrate_set_signmap(void *signmap) { g_signmap = static_cast<unsigned char *>(signmap); }
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
     const size_t nb = (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2);  // room for 2-plane bricks
@@ -933,6 +943,9 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
+    a.signmap = g_signmap;
+    if (a.signmap && (z0 != 0 || z1 != res[2]))
+        return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: a sign map covers the whole volume, this launch a slab of it");
     if (posted) {
         if (!workspace || !(flags & XS_INTEGRATE_LIST_IS_READY) || !g_post_mailbox || !g_post_pose_dev)
             return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: a posted launch needs the classified list and a mailbox (xs_integrate_set_pose_mailbox)");
@@ -973,7 +986,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
             kern = threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>;
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
-        if (env_k && !strcmp(env_k, "ring") && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
+        if (env_k && !strcmp(env_k, "ring") && !a.signmap && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
             kern = k_integrate_bricks_ring<false>;
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, 0, st, a);

@@ -116,11 +116,22 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     integrate_classify_ahead = config.as<bool>("integrate_classify_ahead", true);
     integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
     integrate_post_pose = config.as<bool>("integrate_post_pose", false);
+    raycast_sign_map = config.as<bool>("raycast_sign_map", true);
+    raycast_sign_map_shift = std::min(6, std::max(0, config.as<int>("raycast_sign_map_shift", 0)));   // 0: the finest usable one
     icp_lookahead = config.as<int>("icp_lookahead", 1);
     icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
+    if (sign_map_on()) {
+        // the sign map of the ray march (include/xslam_amd.h), with the finest bricks the march can use for this camera and volume — or none
+        const int finest = xs_raycast_signmap_shift(&kinect_intrinsic.fx, voxel_size, tsdf_volume_d_ptr->getTsdfTruncDist());
+        raycast_sign_map_shift = finest ? std::max(raycast_sign_map_shift, finest) : 0;   // (a finer one than the march can use is coarsened)
+        const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
+        const size_t bytes = raycast_sign_map_shift ? xs_signmap_bytes(res, raycast_sign_map_shift) : 0;
+        if (bytes) { sign_map_.create(bytes); RebuildSignMap(); }   // (from the volume as it is: empty)
+        else raycast_sign_map = false;
+    }
 
     use_gtPose = config.as<bool>("flag_use_gtPose", false);
     gt_poses.resize(0);
@@ -647,6 +658,7 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     if (++integrate_mail_seq_ == 0u) ++integrate_mail_seq_;
     posted_seq_ = integrate_mail_seq_;
     xs_integrate_set_pose_mailbox(integrate_mailbox_, posted_seq_, integrate_classify_slack, posted_pose_.ptr());
+    xs_integrate_set_signmap(sign_map_ptr());
     const bool split = integrate_header_clear_;   // header cleared and count folded on the auxiliary stream (SurfaceMeasure)
     check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_height, depth_width, &kinect_intrinsic.fx, max_integration_weight,
                                     res, voxel_size, list_Rv2c_, list_tv2c_, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), weight.ptr(0), grad.ptr(0),
@@ -655,6 +667,7 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
              "integrateTsdfVolume (posted)");
     xs_integrate_set_timing_events(nullptr, nullptr);
     xs_integrate_set_pose_mailbox(nullptr, 0, 1.0f, nullptr);
+    xs_integrate_set_signmap(nullptr);
     posted_pending_ = true;
     posted_stop_ = integrate_stop;
     posted_split_ = split;
@@ -748,6 +761,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     } else if (integrate_split())
         xs_integrate_set_timing_events(nullptr, integrate_stop);
     if (!integrated_by_post) {
+        xs_integrate_set_signmap(sign_map_ptr());   // (single GPU only: one whole-volume call)
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
         const int zr[3][2] = {{zo0, zo1}, {zs0, zo0}, {zo1, zs1}};
@@ -777,6 +791,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             if (split) { integrate_header_clear_ = false; pending_fold_ = counters; }
             if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);
         }
+        xs_integrate_set_signmap(nullptr);
     }
 
     if (integrate_split()) integrate_done_now_ = integrate_stop;          // attached to the dispatch above
@@ -919,8 +934,10 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     if (shard_count == 1 && !force_shard_composite) {
+        xs_raycast_set_signmap(sign_map_ptr(), raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist());
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
                 voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, hits_counter_, ray_ws_.ptr());
+        xs_raycast_set_signmap(nullptr, 0, 0.0f);
         return 0;
     }
     // sharded: march this rank's planes, agree on the first event of every ray, add the winners
@@ -1118,6 +1135,15 @@ void KinectFusionReconstruction::saveCheckpoint(const std::string &filename) {
 // Nothing of *this is touched until the whole file has been read and validated: magic, volume geometry (resolution,
 // voxel size, truncation distance), the planes it holds against the planes this instance stores, a sane pose count and
 // the exact file length.  Returns false (state unchanged) on any mismatch.
+// The sign map from the volume alone (allocation, checkpoint, anything that wrote the value array without the integrate kernels).
+void KinectFusionReconstruction::RebuildSignMap() {
+    if (!sign_map_on() || !sign_map_.ptr() || !tsdf_volume_d_ptr) return;
+    const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
+    DeviceArray2D<float> value = tsdf_volume_d_ptr->value();
+    check_rc(xs_signmap_rebuild(sign_map_.ptr(), res, raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), value.step(),
+                                current_stream()), "sign map");
+}
+
 bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
     std::ifstream f(filename, std::ios::binary);
     if (!f || !tsdf_volume_d_ptr) return false;
@@ -1152,6 +1178,7 @@ bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {
     restore_rows(dv, v, X, rows);
     restore_rows(dg, g, X, rows);
     restore_rows(dw, w, X, rows);
+    RebuildSignMap();    // the volume was written behind the integrate kernels' back
     world2camera_record.swap(poses);
     world2camera = world2camera_record.back();
     frame_id = h.frame_id;

@@ -64,6 +64,13 @@ public:
     // +0.7 % frames/s, inside the noise — off by default (profiles/r03_ab_integrate_post.txt).
     bool integrate_post_pose = false;
     float integrate_classify_slack = 2.0f;   // YAML integrate_classify_slack: how much wider than its own the list's frustum slack is (1 = every frame falls back)
+    // The sign map of the ray march (include/xslam_amd.h, csrc/xs_signmap.h; YAML raycast_sign_map, default true; raycast_sign_map_shift, default 0 =
+    // the finest bricks the march can use: 8^3 voxels at 512^3): the integrate kernel marks the bricks it writes negative values into, the march starts every ray at the first
+    // step that can end it — the same maps bit for bit (tests/test_signmap_gpu.py), about a fifth of the volume reads.  Single GPU only:
+    // a slab's march owns steps anywhere along the ray.
+    bool raycast_sign_map = true;
+    int raycast_sign_map_shift = 0;
+    void RebuildSignMap();   // call after writing the value array through xs_kf_volume_ptr
     bool list_ready_ = false;
     float list_Rv2c_[18]{}, list_tv2c_[6]{};
     void ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr);
@@ -208,6 +215,9 @@ private:
     int ingest_seq_ = 0;
     DeviceArray<unsigned char> maps_prev0_block_;  // level-0 model vertex + normal maps, one allocation
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
+    DeviceArray<unsigned char> sign_map_;      // raycast: bricks that may hold a negative voxel (single GPU)
+    bool sign_map_on() const { return raycast_sign_map && shard_count == 1; }   // (marked whenever it exists: the composite path of a one-rank test run just does not read it)
+    unsigned char *sign_map_ptr() { return sign_map_on() ? sign_map_.ptr() : nullptr; }
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
     // host-coherent: [0..54] sums + count, [56] completion sequence word, [64..80) pose state of the
     // device-side loop, [128 + 64*n ..) the 55 values of its iteration n

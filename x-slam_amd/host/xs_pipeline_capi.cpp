@@ -252,6 +252,7 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4) {
 }
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v) { ((KF *)kf)->DebugSetIcpSequence(v); }
 void xs_kf_debug_fail_icp_iteration(void *kf, int n) { ((KF *)kf)->debug_fail_icp_iteration_ = n; }
+void xs_kf_rebuild_sign_map(void *kf) { ((KF *)kf)->RebuildSignMap(); }
 
 int xs_kf_save_checkpoint(void *kf, const char *path) { ((KF *)kf)->saveCheckpoint(path); return 0; }
 int xs_kf_load_checkpoint(void *kf, const char *path) { return ((KF *)kf)->loadCheckpoint(path) ? 0 : -1; }

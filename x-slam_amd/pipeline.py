@@ -54,6 +54,7 @@ _SIGS = {
     "xs_kf_icp_iteration_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
+    "xs_kf_rebuild_sign_map": (None, [_vp]),
     "xs_kf_cumulative_counters": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
@@ -272,6 +273,10 @@ class KinectFusion:
 
     def debug_fail_icp_iteration(self, n):
         _lib.xs_kf_debug_fail_icp_iteration(self.h, int(n))
+
+    def rebuild_sign_map(self):
+        """After writing the value array through volume_ptr: the ray march's sign map is rebuilt from the volume."""
+        _lib.xs_kf_rebuild_sign_map(self.h)
 
     def save_checkpoint(self, path):
         _lib.xs_kf_save_checkpoint(self.h, path.encode())
