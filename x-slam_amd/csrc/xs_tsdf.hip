@@ -375,7 +375,7 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Po
 // OFF32 (the brick kernel): the three arrays are addressed as a wave-uniform base (the brick's first voxel: scalar registers) + one 32-bit
 // byte offset per lane that advances by a plane per trip — one VALU instruction per trip for the addresses instead of the six of three
 // 64-bit pointers.  ubase: byte offset of the brick's voxel (0, 0, zb0) in each array; zb0: the brick's first plane.
-template <bool BILINEAR, bool OFF32 = false>
+template <bool BILINEAR, bool OFF32 = false, bool SIGN = false>   // SIGN: a.signmap is marked (a template parameter: the walk is bound by instruction issue)
 __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const PoseRT &ps, int x, int y, int zb, int ze, size_t ubase = 0, int zb0 = 0, unsigned lane_off = 0) {
     unsigned n_upd = 0;
     const float vgx = (x + 0.5f) * a.voxel_size;
@@ -410,12 +410,12 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
                 if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
                 if ((unsigned)(ow ^ w0) | always) *wpos = ow;
                 if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
-                vmin = fminf(vmin, ov);
+                if (SIGN) vmin = fminf(vmin, ov);
                 ++n_upd;
             }
             else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
         }
-        if (vmin < 0.0f && a.signmap) signmap_mark_span(a.signmap, x, y, zb, ze);
+        if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
         return n_upd;
     }
     // (Requesting the state of voxel z+1 one trip ahead, in front of or behind the depth gather, was
@@ -442,7 +442,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
             if ((unsigned)(ow ^ w0) | always) *wpos = ow;
             if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
 #endif
-            vmin = fminf(vmin, ov);
+            if (SIGN) vmin = fminf(vmin, ov);
             ++n_upd;
         }
         else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
@@ -451,7 +451,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
         // still in flight at the loop head, and the wait the compiler puts there to protect their
         // registers also waits for the previous trip's stores to be acknowledged)
     }
-    if (vmin < 0.0f && a.signmap) signmap_mark_span(a.signmap, x, y, zb, ze);
+    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
     return n_upd;
 }
 
@@ -489,7 +489,7 @@ __global__ void k_fold_count(unsigned long long *slots, unsigned long long *upda
 }
 
 // ---- path 1: column walk (no workspace): thread (x, y) walks its clipped z interval ---------
-template <bool BILINEAR>
+template <bool BILINEAR, bool SIGN = false>
 __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
     const int x = threadIdx.x + blockIdx.x * 64;
     const int y = threadIdx.y + blockIdx.y * 4;
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
         int zb = a.z0 + blockIdx.z * a.zchunk;
         int ze = min(zb + a.zchunk, a.z1);
         clip_column(a.cp, far_limit(a), x, y, zb, ze);
-        if (zb < ze) n_upd = integrate_span<BILINEAR>(a, PoseRT{a.R, a.t}, x, y, zb, ze);
+        if (zb < ze) n_upd = integrate_span<BILINEAR, false, SIGN>(a, PoseRT{a.R, a.t}, x, y, zb, ze);
     }
     if (a.updated) block_count_add(n_upd, a.updated, 1);
 }
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
 // (~16 us -> ~4).  The frustum planes (brick test, column clip) stay those of the pose the list was classified with, widened: they
 // only bound the voxels that take the exact tests, and the host posts only after checking that the final pose's planes lie inside
 // them (xs_integrate_pose_covered); otherwise it posts an abandon command and the launch leaves without touching the volume.
-template <bool BILINEAR, bool OFF32 = false, bool POSTED = false>
+template <bool BILINEAR, bool OFF32 = false, bool POSTED = false, bool SIGN = false>
 __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs a) {
     PoseRT ps{a.R, a.t};
     if constexpr (POSTED) {
@@ -590,9 +590,9 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
             if (zb < ze) {
                 if constexpr (OFF32) {
                     const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-                    n_upd += integrate_span<BILINEAR, true>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
+                    n_upd += integrate_span<BILINEAR, true, SIGN>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
                 } else
-                    n_upd += integrate_span<BILINEAR>(a, ps, x, y, zb, ze);
+                    n_upd += integrate_span<BILINEAR, false, SIGN>(a, ps, x, y, zb, ze);
             }
         }
     }
@@ -979,11 +979,16 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // pitches): no spills, the state loads take a scalar base (S1 launch 40.5 -> 39.2 us for the whole call, S2 unchanged)
         static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel; "off64" = 64-bit pointers per lane
         const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
-        void (*kern)(const IntegrateArgs) = threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true> : k_integrate_bricks<true, false>)
-                                                              : (off32 ? k_integrate_bricks<false, true> : k_integrate_bricks<false, false>);
+        const bool sign = a.signmap != nullptr;
+        void (*kern)(const IntegrateArgs) =
+            sign ? (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true, false, true> : k_integrate_bricks<true, false, false, true>)
+                                     : (off32 ? k_integrate_bricks<false, true, false, true> : k_integrate_bricks<false, false, false, true>))
+                 : (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true> : k_integrate_bricks<true, false>)
+                                     : (off32 ? k_integrate_bricks<false, true> : k_integrate_bricks<false, false>));
         if (posted) {
             if (!off32) return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: posted launch on a volume whose bricks span 4 GiB");
-            kern = threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>;
+            kern = sign ? (threshold > 0.0f ? k_integrate_bricks<true, true, true, true> : k_integrate_bricks<false, true, true, true>)
+                        : (threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>);
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
         if (env_k && !strcmp(env_k, "ring") && !a.signmap && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
@@ -1000,7 +1005,8 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         dim3 grid(gx, gy, div_up(nz, a.zchunk));
         // (the events xs_integrate_set_timing_events handed over ride on this dispatch too: a caller that waits on the stop event — the
         // orchestrator's auxiliary stream does — must find it recorded whichever kernel ran)
-        void (*kern)(const IntegrateArgs) = threshold > 0.0f ? k_integrate<true> : k_integrate<false>;
+        void (*kern)(const IntegrateArgs) = a.signmap ? (threshold > 0.0f ? k_integrate<true, true> : k_integrate<false, true>)
+                                                      : (threshold > 0.0f ? k_integrate<true> : k_integrate<false>);
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, grid, block, 0, st, g_int_ev0, g_int_ev1, 0, a);
         else hipLaunchKernelGGL(kern, grid, block, 0, st, a);
     }
