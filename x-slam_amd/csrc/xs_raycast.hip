@@ -180,10 +180,11 @@ struct Vol {
 // eight gathers in flight, like MODE 2).
 // (crossing kernels: five waves per SIMD — a 640 x 480 frame is 4 800 waves on 1 024 SIMDs, all resident at once; the
 // two-samples-per-round-trip form would otherwise take 104 registers, i.e. four)
-constexpr int raycast_min_waves(int mode) { return mode == 3 || mode == 5 ? 5 : 1; }
-template <int MODE, bool OFF32, bool SHORT, bool MAP = false>   // MAP (MODE 2 only): start every ray from the sign map (a.sm)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycast_min_waves(MODE)))) k_raycast(const RaycastArgs a) {
+constexpr int raycast_min_waves(int mode, bool map) { return mode == 3 || mode == 5 || (mode == 0 && map) ? 5 : 1; }
+template <int MODE, bool OFF32, bool SHORT, bool MAP = false>   // MAP (MODE 2 or 0): the march evaluates only the iterations the sign map (a.sm) leaves
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycast_min_waves(MODE, MAP)))) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1 || MODE == 4 || MODE == 5;
+    constexpr bool PAIRS = MODE == 3 || MODE == 5 || (MODE == 0 && MAP);   // the crossing takes its eight samples two at a time (interp2)
     // lane -> pixel inside an 8x8 tile; 4 waves -> 16x16 tile per workgroup.  Workgroups are dealt
     // round-robin over the 8 XCDs (each with its own 4 MB L2): the linear id is remapped so that
     // XCD k marches one contiguous band of image tiles — an eighth of the frustum, which fits its
@@ -296,7 +297,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
         // zero crossing between time_curr and tn (RayCaster.cu:247-306): returns 1 if a vertex was written
         auto crossing = [&](float tc, float tn) -> int {
             cfloat Ftdt, Ft;
-            if (MODE == 3 || MODE == 5) {   // the crossing kernels: both samples in one round trip
+            if (PAIRS) {   // the crossing kernels: both samples in one round trip
                 vol.interp2(ray_start + ray_dir * tn, ray_start + ray_dir * tc, Ftdt, Ft);
                 if (isnan(Ftdt.re) || isnan(Ft.re)) return 0;
             } else {
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
             if (vx > 1 && vy > 1 && vz > 1 && vx < a.X - 2 && vy < a.Y - 2 && vz < a.Z - 2) {
                 cfloat3 t, n;
                 const float half = vs * 0.5f;
-                if (MODE == 3 || MODE == 5) {
+                if (PAIRS) {
                     cfloat3 u;
                     cfloat F1, F2;
                     // (one pair at a time: left to itself the scheduler issues all 48 loads of the six samples at once and
@@ -510,6 +511,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                     if (kn != k + NS) prev = 1.0f;
                     k = kn;
                 }
+                if (MODE == 0 && cross >= 0.f) hit = crossing(cross, cross + time_step);   // (behind the loop: the wave's hit lanes together)
                 done = true;
                 time_curr = max_time;
             }
@@ -562,7 +564,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                 tsdf = val[NS - 1];
                 time_curr = t;
             }
-            if (MODE == 2) a.cross_t[y * a.cols + x] = cross;
+            if (MODE == 2 || (MAP && a.cross_t)) a.cross_t[y * a.cols + x] = cross;   // (the fused launch fills the workspace too: same contract)
             if (a.steps) a.steps[y * a.cols + x] = nsteps;
         }
         if (SLAB) a.keys[y * a.cols + x] = key;  // (MODE 5 rewrites the key it read: even where the crossing gave a vertex)
@@ -683,6 +685,16 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     if (workspace) {
         // march (few registers, many waves, eight gathers in flight per lane) then the crossings
         a.hits = nullptr;
+        static const bool env_pair = getenv("XS_RAY_MAP_TWO_KERNELS") != nullptr;   // measurement: the mapped march and the crossing as two launches
+        if (a.sm.dil && !env_pair) {
+            // with the sign map the march is a few batches long: it and the crossing are one launch (five waves per SIMD hold the
+            // frame's 4 800 waves either way) — no second dispatch, no crossing-time plane written and read back
+            a.hits = hits_dev;
+            if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<0, true, true, true> : k_raycast<0, true, false, true>), grid, block, 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_raycast<0, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+            XS_CHECK(hipGetLastError());
+            return 0;
+        }
         if (a.sm.dil) {
             if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<2, true, true, true> : k_raycast<2, true, false, true>), grid, block, 0, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((k_raycast<2, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
