@@ -625,7 +625,15 @@ __global__ void __launch_bounds__(64 * WAVES)
         if (threadIdx.x < 28) {
             d2 t = s_red[0][threadIdx.x];
 #pragma unroll
-            for (int gg = 1; gg < G; ++gg) { t.x += s_red[gg][threadIdx.x].x; t.y += s_red[gg][threadIdx.x].y; }
+            for (int gg = 1; gg < G; ++gg) {
+                t.x += s_red[gg][threadIdx.x].x; t.y += s_red[gg][threadIdx.x].y;
+                // (both chains advance together: left alone the compiler sinks the y chain into the guarded store below, keeps all G
+                // y values live across the x chain — 36 x 4 registers at sixteen waves — and spills them: five dependent scratch reloads,
+                // 2-3.5 us at the very end of every level-0 launch, profiles/r03_icp_phases.txt)
+#ifndef XS_ICP_TAIL_BASELINE
+                asm volatile("" : "+v"(t.x), "+v"(t.y));
+#endif
+            }
             a.out[2 * threadIdx.x] = t.x;
             if (2 * threadIdx.x + 1 < NS + 1) a.out[2 * threadIdx.x + 1] = t.y;
         }
