@@ -290,6 +290,22 @@ def test_ray_march_from_the_sign_map_changes_nothing(dev, tmp_path, n, scene):
         r.close()
 
 
+def test_sign_map_over_a_long_trajectory(dev):
+    """Sixty frames of the box room at 256^3 — the camera sweeps, surfaces enter and leave the view, bricks marked early stay marked —
+    with and without the sign map: every pose, count and the final volume identical, bit for bit."""
+    torch, pl = dev
+    prm = synth.s1_params(256)
+    a, b = pl.KinectFusion(dict(prm, raycast_sign_map=False)), pl.KinectFusion(dict(prm, raycast_sign_map=True))
+    for k in range(60):
+        d = upload(torch, synth.s3_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1, k
+        assert np.array_equal(a.world2camera(), b.world2camera()), k
+        assert a.last_U() == b.last_U() and a.last_hits() == b.last_hits(), k
+    for x, y in zip(a.volume(), b.volume()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_device_pose_solve_matches_host_solve(dev):
     """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
     the reference's one host solve per iteration — on the same frames: identical first-iteration sums,
