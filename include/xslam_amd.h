@@ -178,6 +178,9 @@ int xs_resize_nmap(const float *in, size_t in_step, int src_rows, int src_cols, 
  * separate calls.  rows0 / cols0: one plane of the level-0 maps. */
 int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
                       size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *stream);
+/* Thread-local: an event that rides on the following xs_resize_pyramid dispatches (recorded when the kernel completes, with no marker packet
+ * behind it in the stream); NULL = none. */
+void xs_resize_pyramid_set_completion_event(void *event);
 
 /* ---- Raycast ------------------------------------------------------------------------------ */
 /* raycast(const Intr&, const MatS33& Rc2v, const devComplex3& tc2v, const MatS33& Rv2w,

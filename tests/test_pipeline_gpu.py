@@ -306,6 +306,44 @@ def test_sign_map_over_a_long_trajectory(dev):
     a.close(); b.close()
 
 
+def test_announcing_the_next_frame_changes_nothing(dev):
+    """hint_next_frame (the next frame's bilateral filter and depth pyramid built during this frame's ICP loop) against the plain order: the
+    same poses, counts, current-frame maps and volume, bit for bit — also when the announced frame is not the one that comes (the pipeline
+    then prepares its own maps), when a frame is announced twice, when tracking fails in between (a blank frame), and for the frame after
+    the last announcement."""
+    torch, pl = dev
+    prm = synth.s1_params(128)
+    a, b = pl.KinectFusion(prm), pl.KinectFusion(prm)
+    frames = [upload(torch, synth.s1_frame(k)) for k in range(12)]
+    blank = upload(torch, np.zeros_like(synth.s1_frame(0)))
+    order = [0, 1, 2, 3, "blank", 4, 5, 6, 7, 8, 9, 10, 11]
+    tens = lambda k: blank if k == "blank" else frames[k]
+    for n, k in enumerate(order):
+        nxt = order[n + 1] if n + 1 < len(order) else None
+        if k == 5:
+            b.hint_next_frame(frames[9])            # a wrong announcement: frame 6 comes
+        elif k == 8:
+            b.hint_next_frame(tens(nxt)); b.hint_next_frame(tens(nxt))
+        elif nxt is not None and k != 10:           # (nothing announced while frame 10 is processed: frame 11 prepares itself)
+            b.hint_next_frame(tens(nxt))
+        ra, rb = a.process_frame(tens(k)), b.process_frame(tens(k))
+        assert ra == rb == (0 if k == "blank" else 1), (k, ra, rb)
+        assert np.array_equal(a.world2camera(), b.world2camera()), k
+        assert a.last_U() == b.last_U() and a.last_hits() == b.last_hits(), k
+        for level in range(3):
+            assert np.array_equal(a.map("depths_curr", level).view(np.int32), b.map("depths_curr", level).view(np.int32)), (k, level)
+            for which in ("vmaps_curr", "nmaps_curr"):   # (an invalid pixel has NaN in its x plane; its y and z planes are not written)
+                ma, mb = a.map(which, level), b.map(which, level)
+                rows = ma.shape[0] // 3
+                valid = np.isfinite(ma[:rows, :, 0])
+                assert np.array_equal(valid, np.isfinite(mb[:rows, :, 0])), (k, which, level)
+                for p_ in range(3):
+                    assert np.array_equal(ma[p_ * rows:(p_ + 1) * rows][valid].view(np.int32), mb[p_ * rows:(p_ + 1) * rows][valid].view(np.int32)), (k, which, level)
+    for x, y in zip(a.volume(), b.volume()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_device_pose_solve_matches_host_solve(dev):
     """The two shapes of the ICP loop — pose update on the device, one host wait per frame (default) and
     the reference's one host solve per iteration — on the same frames: identical first-iteration sums,

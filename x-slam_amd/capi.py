@@ -110,6 +110,7 @@ _SIGS = {
     "xs_dcsfd_f1": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     "xs_complex_table": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
     "xs_raycast_set_step_buffer": (None, [_vp]),
+    "xs_resize_pyramid_set_completion_event": (None, [_vp]),
     "xs_integrate_set_pose_mailbox": (None, [_vp, C.c_uint, C.c_float, _vp]),
     "xs_integrate_pose_covered": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_const_div_prepare": (C.c_uint, [C.c_float]),

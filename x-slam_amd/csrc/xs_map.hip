@@ -7,6 +7,7 @@
 // rows x cols (x rows, then y, then z).  Invalid pixels carry the NaN sentinel in the x plane
 // only (Map.cu:27,42,69,126).  All kernels put 64 consecutive columns on a wave so every row
 // access is one coalesced segment (512 B of complex per wave-row).
+#include <hip/hip_ext.h>
 #include "xs_device.h"
 #include "../../include/xslam_amd.h"
 
@@ -422,6 +423,11 @@ __global__ void __launch_bounds__(256) k_resize_pyramid(const PyramidArgs a) {
     if (blockIdx.z == 0) resize_two_levels<false>(a, 0, x2, y2);
     else resize_two_levels<true>(a, 1, x2, y2);
 }
+// an event that rides on the next xs_resize_pyramid dispatch of this thread (its completion: hipExtLaunchKernelGGL's stop event) — another
+// stream can then wait for the end of a frame's raycast + pyramid without a marker packet in this one; NULL = none
+static thread_local hipEvent_t g_pyramid_done = nullptr;
+extern "C" void xs_resize_pyramid_set_completion_event(void *event) { g_pyramid_done = (hipEvent_t)event; }
+
 /* The orchestrator's model-map pyramid in one launch: level 1 and level 2 of the vertex map (as
  * resizeVMap twice) and of the normal map (as resizeNMap twice), Map.h:46-54.  rows0 / cols0: one plane
  * of the level-0 maps; all level-0 maps share in_step, level-1 mid_step, level-2 out_step. */
@@ -436,7 +442,8 @@ extern "C" int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t 
     a.out[0] = (cfloat *)vmap2; a.out[1] = (cfloat *)nmap2;
     a.istep = in_step; a.mstep = mid_step; a.ostep = out_step; a.rows0 = rows0; a.cols0 = cols0;
     dim3 block(64, 4), grid(div_up(div_up(cols1, 2), 64), div_up(div_up(rows1, 2), 4), 2);
-    hipLaunchKernelGGL(k_resize_pyramid, grid, block, 0, (hipStream_t)stream, a);
+    if (g_pyramid_done) hipExtLaunchKernelGGL(k_resize_pyramid, grid, block, 0, (hipStream_t)stream, nullptr, g_pyramid_done, 0, a);
+    else hipLaunchKernelGGL(k_resize_pyramid, grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;
 }

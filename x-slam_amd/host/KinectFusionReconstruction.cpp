@@ -20,6 +20,7 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipEventCreateWithFlags(&surface_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&scale_done_, hipEventDisableTiming));
+    hipSafeCall(hipEventCreateWithFlags(&tail_done_, hipEventDisableTiming));
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, COUNTER_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, PINNED_DOUBLES * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < PINNED_DOUBLES; ++i) pinned_sums_[i] = 0.0;
@@ -35,6 +36,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (surface_done_) (void)hipEventDestroy(surface_done_);
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
+    if (tail_done_) (void)hipEventDestroy(tail_done_);
     if (scale_done_) (void)hipEventDestroy(scale_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
@@ -820,10 +822,14 @@ void KinectFusionReconstruction::ModelMapPyramid() {
         }
         if (vmaps_g_prev_d[0].step() == nmaps_g_prev_d[0].step() && vmaps_g_prev_d[1].step() == nmaps_g_prev_d[1].step() &&
             vmaps_g_prev_d[2].step() == nmaps_g_prev_d[2].step()) {
+            // (its completion = the end of the frame's tail: what the announced next frame's map preparation waits for, HintNextFrame)
+            xs_resize_pyramid_set_completion_event(tail_done_);
             check_rc(xs_resize_pyramid(&vmaps_g_prev_d[0].ptr()->re, &nmaps_g_prev_d[0].ptr()->re, vmaps_g_prev_d[0].step(), rows0, cols0,
                                        &vmaps_g_prev_d[1].ptr()->re, &nmaps_g_prev_d[1].ptr()->re, vmaps_g_prev_d[1].step(),
                                        &vmaps_g_prev_d[2].ptr()->re, &nmaps_g_prev_d[2].ptr()->re, vmaps_g_prev_d[2].step(), current_stream()),
                      "resizeMap");
+            xs_resize_pyramid_set_completion_event(nullptr);
+            tail_recorded_ = true;
             return;
         }
     }
@@ -846,8 +852,16 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     hipStream_t main_stream = current_stream();
     current_stream() = aux_stream_;
     stage_begin(ST_SURFACE);
-    SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
-    for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
+    if (next_ready_ && next_ready_ptr_ == (const void *)depth_frame_d.ptr() && next_ready_step_ == depth_frame_d.step() &&
+        depths_next_d.size() == depths_curr_d.size()) {
+        // this frame was announced while the previous one was being tracked (HintNextFrame): its filtered depth and pyramid were built
+        // then, on this same stream — the kernels below are ordered behind them without an event
+        std::swap(depths_curr_d, depths_next_d);
+    } else {
+        SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
+        for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
+    }
+    next_ready_ = false;
     {   // createVMap + createNMap per level (camera frame, +z forward), all levels in one launch
         Intr ks[3];
         const float *dp[3]; size_t ds[3], ms[3];
@@ -910,6 +924,23 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     stage_end(ST_SCALE);
     hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
     scale_recorded_ = true;
+    if (next_hint_ptr_) {
+        // The NEXT frame's bilateral filter and depth pyramid (two thirds of a frame's map preparation) go into the queue now: they depend
+        // on that depth image alone and run while this frame's ICP launches — 45 to 256 workgroups each, waiting on one another — leave
+        // most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP launch waits for.
+        if (depths_next_d.size() != depths_curr_d.size()) depths_next_d.resize(depths_curr_d.size());
+        for (size_t i = 0; i < depths_curr_d.size(); ++i)
+            if (depths_next_d[i].rows() != depths_curr_d[i].rows() || depths_next_d[i].cols() != depths_curr_d[i].cols())
+                depths_next_d[i].create(depths_curr_d[i].rows(), depths_curr_d[i].cols());
+        const DeviceArray2D<ushort> next(depth_height, depth_width, const_cast<void *>(next_hint_ptr_), next_hint_step_);   // borrowed
+        // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
+        // on that pyramid's dispatch, the wait is a packet of this stream only
+        if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
+        SmoothDepthFrame(depths_next_d[0], next);
+        for (int i = 1; i < num_levels; ++i) pyrDown(depths_next_d[i - 1], depths_next_d[i]);
+        next_ready_ptr_ = next_hint_ptr_; next_ready_step_ = next_hint_step_; next_ready_ = true;
+        next_hint_ptr_ = nullptr;
+    }
     current_stream() = main_stream;
     // the main stream picks the maps up — without a wait packet when they are already there (the usual case once the
     // previous frame's tail is the longer of the two)

@@ -71,6 +71,11 @@ public:
     bool raycast_sign_map = true;
     int raycast_sign_map_shift = 0;
     void RebuildSignMap();   // call after writing the value array through xs_kf_volume_ptr
+    // Look-ahead of the map preparation (no counterpart in the reference, whose main.cpp:50-58 reads, uploads and processes one frame at a
+    // time): the caller names the depth image it will pass to the NEXT ProcessFrame call — device memory, unchanged until then — and that
+    // frame's bilateral filter and depth pyramid are built during this frame's ICP loop.  A ProcessFrame call with any other image simply
+    // prepares its own maps as always.  Same results bit for bit (tests/test_pipeline_gpu.py).
+    void HintNextFrame(const ushort *depth_dev, size_t step_bytes) { next_hint_ptr_ = depth_dev; next_hint_step_ = step_bytes; }
     bool list_ready_ = false;
     float list_Rv2c_[18]{}, list_tv2c_[6]{};
     void ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr);
@@ -215,6 +220,12 @@ private:
     int ingest_seq_ = 0;
     DeviceArray<unsigned char> maps_prev0_block_;  // level-0 model vertex + normal maps, one allocation
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
+    hipEvent_t tail_done_ = nullptr;           // completion of a frame's model-map pyramid (rides on its dispatch)
+    bool tail_recorded_ = false;
+    std::vector<MapArr> depths_next_d;         // the announced next frame's filtered depth pyramid (HintNextFrame)
+    const void *next_hint_ptr_ = nullptr, *next_ready_ptr_ = nullptr;
+    size_t next_hint_step_ = 0, next_ready_step_ = 0;
+    bool next_ready_ = false;
     DeviceArray<unsigned char> sign_map_;      // raycast: bricks that may hold a negative voxel (single GPU)
     bool sign_map_on() const { return raycast_sign_map && shard_count == 1; }   // (marked whenever it exists: the composite path of a one-rank test run just does not read it)
     unsigned char *sign_map_ptr() { return sign_map_on() ? sign_map_.ptr() : nullptr; }

@@ -142,6 +142,7 @@ int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) 
     DeviceArray2D<ushort> view(k->depth_height, k->depth_width, (void *)depth_dev, step_bytes);  // borrowed, not counted
     return k->ProcessFrame(view);
 }
+void xs_kf_hint_next_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes) { ((KF *)kf)->HintNextFrame(depth_dev, step_bytes); }
 int xs_kf_process_frame_host(void *kf, const uint16_t *depth_host) { return ((KF *)kf)->ProcessFrameHost(depth_host); }
 uint16_t *xs_kf_ingest_buffer(void *kf) { return ((KF *)kf)->IngestBuffer(); }
 void xs_kf_get_camera2volume(void *kf, float *out32) {

@@ -55,6 +55,7 @@ _SIGS = {
     "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
     "xs_kf_rebuild_sign_map": (None, [_vp]),
+    "xs_kf_hint_next_frame": (None, [_vp, _vp, _sz]),
     "xs_kf_cumulative_counters": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
@@ -148,6 +149,11 @@ class KinectFusion:
         ptr = depth_dev if isinstance(depth_dev, int) else depth_dev.data_ptr()
         step = step_bytes if step_bytes is not None else self.width * 2
         return _lib.xs_kf_process_frame(self.h, ptr, step)
+
+    def hint_next_frame(self, depth_dev, step_bytes=None):
+        """The device depth image the NEXT process_frame call will be given (unchanged until then): its bilateral filter and pyramid are built
+        during this frame's ICP loop.  Call before process_frame of the current frame."""
+        _lib.xs_kf_hint_next_frame(self.h, depth_dev.data_ptr(), step_bytes or self.width * 2)
 
     def process_frame_host(self, depth_u16):
         """Host frame [H, W] u16: staged through pinned memory and copied asynchronously on the second stream
