@@ -278,6 +278,11 @@ __global__ void __launch_bounds__(64 * WAVES)
     constexpr int EXTRA = BAL ? WAVES / 4 : 0;   // waves that work through a second tile
     constexpr int SLOTS = WAVES + EXTRA;         // tiles a workgroup can take
     XS_STAMP(0);
+#ifndef XS_ICP_NO_PRIO
+    // an ICP launch is a chain of dependent steps on few waves; the announced next frame's bilateral filter (HintNextFrame) shares its
+    // SIMDs with them and is throughput work: these waves go first at the issue arbiter
+    __builtin_amdgcn_s_setprio(3);
+#endif
     // one tile per wave: the tile's current-frame vertices are on their way before the pose is (a pixel outside the image reads
     // pixel (0, y0): resident, never used)
     cfloat3 pre_v, pre_v2;
