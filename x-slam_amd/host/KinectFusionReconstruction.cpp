@@ -283,6 +283,7 @@ int KinectFusionReconstruction::ProcessFrameHost(const ushort *depth_host) {
 // reference :161-175
 int KinectFusionReconstruction::AlignDepthToReconstruction(const DeviceArray2D<ushort> &depth_frame_d, bool /*use_LM*/) {
     SurfaceMeasure(depth_frame_d);
+    struct AtExit { KinectFusionReconstruction *k; ~AtExit() { k->EnqueueAnnouncedFrame(); } } announced_at_exit{this};   // (whatever path is taken below)
     if (use_gtPose) return 1;
     Matrix4cf c2w_prev = inverse(world2camera_record.back());
     Matrix3frm Rprev = GetRotation(c2w_prev);
@@ -385,6 +386,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 // frame's first ones are enqueued while the GPU still works on the previous frame's raycast — measured the same
                 // 2 900-2 950 frames/s as one: those gaps are the profiler's.)
                 enqueue_through(n + std::max(1, icp_lookahead), &device_Rcurr, &device_tcurr);
+                if (n == 0) EnqueueAnnouncedFrame();   // (behind the frame's first ICP launches)
                 // the last launch is in the queue: the integrate call's brick classification goes in behind it, for the pose that
                 // launch starts from — the final one differs by the last level-0 update, which IntegrateFrame checks is covered
                 // (with integrate_post_pose the integrate kernel follows the classification into the queue, and both go in as soon as the last
@@ -839,6 +841,31 @@ void KinectFusionReconstruction::ModelMapPyramid() {
     }
 }
 
+// The announced next frame's bilateral filter and depth pyramid (HintNextFrame), on the second stream.  Called once the frame's first ICP
+// launches are in the queue (PoseEstimate) — the host's time for these three launches is then off the path to that first launch — or at the
+// end of AlignDepthToReconstruction where there is no ICP loop.
+void KinectFusionReconstruction::EnqueueAnnouncedFrame() {
+    if (!next_hint_ptr_) return;
+    hipStream_t main_stream = current_stream();
+    current_stream() = aux_stream_;
+    // The NEXT frame's bilateral filter and depth pyramid (two thirds of a frame's map preparation) go into the queue now: they depend
+    // on that depth image alone and run while this frame's ICP launches — 45 to 256 workgroups each, waiting on one another — leave
+    // most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP launch waits for.
+    if (depths_next_d.size() != depths_curr_d.size()) depths_next_d.resize(depths_curr_d.size());
+    for (size_t i = 0; i < depths_curr_d.size(); ++i)
+        if (depths_next_d[i].rows() != depths_curr_d[i].rows() || depths_next_d[i].cols() != depths_curr_d[i].cols())
+            depths_next_d[i].create(depths_curr_d[i].rows(), depths_curr_d[i].cols());
+    const DeviceArray2D<ushort> next(depth_height, depth_width, const_cast<void *>(next_hint_ptr_), next_hint_step_);   // borrowed
+    // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
+    // on that pyramid's dispatch, the wait is a packet of this stream only
+    if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
+    SmoothDepthFrame(depths_next_d[0], next);
+    for (int i = 1; i < num_levels; ++i) pyrDown(depths_next_d[i - 1], depths_next_d[i]);
+    next_ready_ptr_ = next_hint_ptr_; next_ready_step_ = next_hint_step_; next_ready_ = true;
+    next_hint_ptr_ = nullptr;
+    current_stream() = main_stream;
+}
+
 // reference :280-299
 void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &depth_frame_d) {
     if (depth_width <= 0 || depth_height <= 0) {
@@ -924,23 +951,6 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     stage_end(ST_SCALE);
     hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
     scale_recorded_ = true;
-    if (next_hint_ptr_) {
-        // The NEXT frame's bilateral filter and depth pyramid (two thirds of a frame's map preparation) go into the queue now: they depend
-        // on that depth image alone and run while this frame's ICP launches — 45 to 256 workgroups each, waiting on one another — leave
-        // most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP launch waits for.
-        if (depths_next_d.size() != depths_curr_d.size()) depths_next_d.resize(depths_curr_d.size());
-        for (size_t i = 0; i < depths_curr_d.size(); ++i)
-            if (depths_next_d[i].rows() != depths_curr_d[i].rows() || depths_next_d[i].cols() != depths_curr_d[i].cols())
-                depths_next_d[i].create(depths_curr_d[i].rows(), depths_curr_d[i].cols());
-        const DeviceArray2D<ushort> next(depth_height, depth_width, const_cast<void *>(next_hint_ptr_), next_hint_step_);   // borrowed
-        // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
-        // on that pyramid's dispatch, the wait is a packet of this stream only
-        if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
-        SmoothDepthFrame(depths_next_d[0], next);
-        for (int i = 1; i < num_levels; ++i) pyrDown(depths_next_d[i - 1], depths_next_d[i]);
-        next_ready_ptr_ = next_hint_ptr_; next_ready_step_ = next_hint_step_; next_ready_ = true;
-        next_hint_ptr_ = nullptr;
-    }
     current_stream() = main_stream;
     // the main stream picks the maps up — without a wait packet when they are already there (the usual case once the
     // previous frame's tail is the longer of the two)

@@ -76,6 +76,7 @@ public:
     // frame's bilateral filter and depth pyramid are built during this frame's ICP loop.  A ProcessFrame call with any other image simply
     // prepares its own maps as always.  Same results bit for bit (tests/test_pipeline_gpu.py).
     void HintNextFrame(const ushort *depth_dev, size_t step_bytes) { next_hint_ptr_ = depth_dev; next_hint_step_ = step_bytes; }
+    void EnqueueAnnouncedFrame();
     bool list_ready_ = false;
     float list_Rv2c_[18]{}, list_tv2c_[6]{};
     void ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr);
