@@ -121,6 +121,9 @@ void xs_kf_debug_fail_icp_iteration(void *kf, int n);
 /* Rebuilds the sign map of the ray march (xslam_amd.h) from the volume: to be called by whoever writes the value array through
  * xs_kf_volume_ptr (loadCheckpoint does it itself).  No-op in shard mode or with raycast_sign_map: false. */
 void xs_kf_rebuild_sign_map(void *kf);
+/* integrate_post_pose: how many posted integrate launches were given their pose, and how many were told to leave because the final pose was
+ * not covered by the planes they had been given (those frames took the plain call) */
+void xs_kf_posted_integrate_counts(void *kf, long long *accepted, long long *refused);
 
 /* volume checkpoint (value + grad + weight + poses)   cf. saveTSDFVolume, .cpp:438-447 */
 int xs_kf_save_checkpoint(void *kf, const char *path);

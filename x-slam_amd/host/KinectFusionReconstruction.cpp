@@ -118,6 +118,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     integrate_classify_ahead = config.as<bool>("integrate_classify_ahead", true);
     integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
     integrate_post_pose = config.as<bool>("integrate_post_pose", false);
+    integrate_post_early = config.as<bool>("integrate_post_early", false);
     raycast_sign_map = config.as<bool>("raycast_sign_map", true);
     raycast_sign_map_shift = std::min(6, std::max(0, config.as<int>("raycast_sign_map_shift", 0)));   // 0: the finest usable one
     icp_lookahead = config.as<int>("icp_lookahead", 1);
@@ -389,9 +390,10 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 if (n == 0) EnqueueAnnouncedFrame();   // (behind the frame's first ICP launches)
                 // the last launch is in the queue: the integrate call's brick classification goes in behind it, for the pose that
                 // launch starts from — the final one differs by the last level-0 update, which IntegrateFrame checks is covered
-                // (with integrate_post_pose the integrate kernel follows the classification into the queue, and both go in as soon as the last
-                // ICP launch has — one iteration earlier — so that the host's share of three launches is over before the last reduction is)
-                if ((integrate_post_pose ? enqueued == total_iters : n == total_iters - 1) && !list_ready_ && integrate_classify_ahead && integrate_split())
+                // (with integrate_post_pose the integrate kernel follows the classification into the queue, gated on its mailbox: the host's three
+                // launches — classification, gate, integrate — go in while the last, 18 us, ICP launch runs; integrate_post_early puts them in one
+                // iteration earlier, with planes from a pose two updates old: 16 % of those were not covered at slack 2)
+                if ((integrate_post_pose && integrate_post_early ? enqueued == total_iters : n == total_iters - 1) && !list_ready_ && integrate_classify_ahead && integrate_split())
                     ClassifyAhead(Rcurr, tcurr);
                 const unsigned long long seq = seq_of[n];
                 if (n + 1 < total_iters) {
@@ -733,10 +735,12 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
                                       integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re)) {
             xs_icp_post_pose(integrate_mailbox_, &device_Rv2c.data[0].x.re, &device_tv2c.x.re, posted_seq_, 0);
             integrated_by_post = true;
+            ++posted_accepted_;
             list_ready_ = false;
             if (posted_split_) { integrate_header_clear_ = false; pending_fold_ = counters; }
         } else {   // (never seen: the last ICP update moved the frustum further than the widened planes allow for)
             xs_icp_post_pose(integrate_mailbox_, nullptr, nullptr, posted_seq_, 1);
+            ++posted_refused_;
             list_ready_ = false;
             check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
         }

@@ -58,11 +58,15 @@ public:
     // integrate_classify_ahead, default true; single GPU with the posted ICP loop): IntegrateFrame then finds the list ready
     bool integrate_classify_ahead = true;
     // the integrate kernel itself enqueued behind that classification, handed the final pose through a mailbox of its own and a one-wave gate
-    // kernel (YAML integrate_post_pose, default FALSE; needs integrate_classify_ahead and a mailbox in device memory).  Built and measured in
-    // round 3: the gap between the last ICP reduction and the integrate kernel falls from 16 to 10 us, but 16 % of the frames are not covered by
-    // the planes of a pose two updates old at slack 2 (they fall back), and at slack 4 the wider list costs the kernel what the gap saved:
-    // +0.7 % frames/s, inside the noise — off by default (profiles/r03_ab_integrate_post.txt).
+    // kernel (YAML integrate_post_pose, default FALSE; needs integrate_classify_ahead and a mailbox in device memory).  Round 3, first form: all
+    // three launches went in one ICP iteration early (YAML integrate_post_early) — 16 % of the frames were then not covered by the planes of a
+    // pose two updates old at slack 2 and fell back: +0.7 % (profiles/r03_ab_integrate_post.txt).  As it stands they go in while the last ICP launch
+    // runs, with the pose that launch starts from (as the classification alone does): 4.7 % of the frames still fail the posted launch's stricter
+    // coverage test and the kernel starts ~8 us earlier on the others: +0.8 % frames/s, inside the noise (profiles/r03_ab_integrate_post_late.txt)
+    // — still off by default; xs_kf_posted_integrate_counts says how many launches were given their pose and how many were told to leave.
     bool integrate_post_pose = false;
+    long long posted_accepted_ = 0, posted_refused_ = 0;   // posted integrate launches that were given their pose / told to leave (xs_kf_posted_integrate_counts)
+    bool integrate_post_early = false;       // YAML integrate_post_early: the posted launch goes in one ICP iteration earlier (list from a pose two updates old)
     float integrate_classify_slack = 2.0f;   // YAML integrate_classify_slack: how much wider than its own the list's frustum slack is (1 = every frame falls back)
     // The sign map of the ray march (include/xslam_amd.h, csrc/xs_signmap.h; YAML raycast_sign_map, default true; raycast_sign_map_shift, default 0 =
     // the finest bricks the march can use: 8^3 voxels at 512^3): the integrate kernel marks the bricks it writes negative values into, the march starts every ray at the first

@@ -254,6 +254,10 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4) {
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v) { ((KF *)kf)->DebugSetIcpSequence(v); }
 void xs_kf_debug_fail_icp_iteration(void *kf, int n) { ((KF *)kf)->debug_fail_icp_iteration_ = n; }
 void xs_kf_rebuild_sign_map(void *kf) { ((KF *)kf)->RebuildSignMap(); }
+void xs_kf_posted_integrate_counts(void *kf, long long *accepted, long long *refused) {
+    if (accepted) *accepted = ((KF *)kf)->posted_accepted_;
+    if (refused) *refused = ((KF *)kf)->posted_refused_;
+}
 
 int xs_kf_save_checkpoint(void *kf, const char *path) { ((KF *)kf)->saveCheckpoint(path); return 0; }
 int xs_kf_load_checkpoint(void *kf, const char *path) { return ((KF *)kf)->loadCheckpoint(path) ? 0 : -1; }

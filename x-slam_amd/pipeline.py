@@ -56,6 +56,7 @@ _SIGS = {
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
     "xs_kf_rebuild_sign_map": (None, [_vp]),
     "xs_kf_hint_next_frame": (None, [_vp, _vp, _sz]),
+    "xs_kf_posted_integrate_counts": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_cumulative_counters": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
@@ -279,6 +280,12 @@ class KinectFusion:
 
     def debug_fail_icp_iteration(self, n):
         _lib.xs_kf_debug_fail_icp_iteration(self.h, int(n))
+
+    def posted_integrate_counts(self):
+        """(accepted, refused) posted integrate launches so far (integrate_post_pose)."""
+        a, r = C.c_longlong(0), C.c_longlong(0)
+        _lib.xs_kf_posted_integrate_counts(self.h, C.byref(a), C.byref(r))
+        return int(a.value), int(r.value)
 
     def rebuild_sign_map(self):
         """After writing the value array through volume_ptr: the ray march's sign map is rebuilt from the volume."""
