@@ -2,7 +2,7 @@
 // No counterpart in the reference: its ray march (RayCaster.cu:222-247) evaluates every step from t = 0.2 m.  Every event that can end
 // that march — a step whose sample leaves the volume, a + to - crossing, a - to + crossing — needs either a sample outside the volume
 // or a NEGATIVE voxel on one side of the step, so steps whose samples are known to lie in bricks without negative voxels cannot end it
-// and need not be read: the march can start at the first step that may matter, from the same float time the reference's running sum
+// and need not be read: the march evaluates only the steps that may matter, each from the same float time the reference's running sum
 // has there, and produces the same bits.  The map is only ever a superset: the integrate kernels set a brick's byte when they write a
 // negative value into it (written values are never looked at again: bytes are never cleared except by reset / rebuild).
 //
@@ -11,8 +11,11 @@
 //   float t[SIGNMAP_MAX_STEPS]  t[0] = 0.2, t[j+1] = t[j] + time_step in float: the reference's time_curr at iteration j
 //   u8    raw[nb]               brick holds a voxel that was written with a negative value
 //   u8    dil[nb]               some brick of the 3x3x3 neighbourhood is raw, is missing, or overhangs the volume's end
-// The march samples `dil` every 0.9 brick edges: every point of the ray within 0.9 edges of a sample lies in the sample's brick or one
-// of its 26 neighbours, so a clear `dil` byte clears the whole stretch up to the next sample, and keeps it inside the volume.
+// The march (k_raycast, MAP) samples `dil` once per wave, along the ray through the centre of the wave's pixel tile, every dt with
+// dt + (5.2 + dt) * delta <= 0.9 brick edges (delta: the tile's half diagonal in normalised image coordinates): every point any of the
+// tile's rays reaches between two samples lies in the sample's brick or one of its 26 neighbours, so a clear `dil` byte clears that
+// stretch for the whole tile, and keeps it inside the volume; a ballot over the table t[] turns the cleared stretches into a bit mask of
+// the iterations that still have to be evaluated.
 #pragma once
 #include <hip/hip_runtime.h>
 
