@@ -315,3 +315,22 @@ angleThres: 15
     t2 = pl.yaml_text(prm)
     assert float(pl.flat_yaml_get(t2, "tsdf_voxel_size")) == prm["tsdf_voxel_size"]
     assert pl.flat_yaml_get(t2, "flag_use_gtPose") == "false" and int(pl.flat_yaml_get(t2, "csfd_seed_col")) == 3
+
+
+def test_sign_map_host_side_sizes_and_shifts():
+    """Host-only entry points of the sign map (csrc/xs_signmap.h): buffer sizes, and the finest brick shift the march can use — the bricks
+    must outgrow a wave's 8 x 8 pixel tile at 5 m (dt + (5.2 + dt) * delta <= 0.9 edges with at most 128 samples), the march at most 320 steps."""
+    capi = importlib.import_module("x-slam_amd.capi")
+    synth = importlib.import_module("x-slam_amd.synth")
+    head = 64 + 320 * 4
+    assert capi.signmap_bytes([512, 512, 512], 3) == head + 2 * 64 ** 3
+    assert capi.signmap_bytes([90, 70, 83], 3) == head + 2 * ((12 * 9 * 11 + 255) // 256 * 256)      # overhanging last bricks, padded to 256
+    assert capi.signmap_bytes([512, 512, 512], 1) == 0 and capi.signmap_bytes([512, 512, 512], 7) == 0 and capi.signmap_bytes([0, 1, 1], 3) == 0
+    for n, want in ((128, 2), (256, 2), (512, 3), (1024, 4)):
+        prm = synth.s1_params(n)
+        assert capi.raycast_signmap_shift(synth.intr_of(prm), prm["tsdf_voxel_size"], synth.tranc_dist(prm)) == want, n
+    prm = synth.s1_params(512)
+    assert capi.raycast_signmap_shift(synth.intr_of(prm), prm["tsdf_voxel_size"], 0.01) == 0       # 600 march steps: more than the table holds
+    assert capi.raycast_signmap_shift(synth.intr_of(prm), 1e-4, 3e-4) == 0                          # 16 000 steps
+    wide = synth.intr_of(prm) / 8.0                                                                 # a very wide lens: the tile outgrows the bricks
+    assert capi.raycast_signmap_shift(wide, prm["tsdf_voxel_size"], synth.tranc_dist(prm)) in (0, 5, 6)
