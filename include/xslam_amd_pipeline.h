@@ -52,8 +52,8 @@ void xs_kf_set_gt_poses(void *kf, int n, const float *c2w32);
  * when the alignment failed (frame_id is then not advanced, as in the reference). */
 int xs_kf_process_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes);
 /* Look-ahead (no reference counterpart: main.cpp:50-58 handles one frame at a time): the device depth image the NEXT xs_kf_process_frame
- * call will be given — it must stay unchanged until that call.  Its bilateral filter and depth pyramid are then built during the current
- * frame's ICP loop, when the GPU is mostly idle.  A call with any other image prepares its own maps as always; results are the same bits
+ * call will be given — it must stay unchanged until that call.  Its maps (bilateral filter, depth pyramid, vertex / normal maps, scaled depth) are then built
+ * during the current frame's ICP loop, when the GPU is mostly idle, into a second set of buffers.  A call with any other image prepares its own maps as always; results are the same bits
  * either way.  Call before xs_kf_process_frame of the current frame. */
 void xs_kf_hint_next_frame(void *kf, const uint16_t *depth_dev, size_t step_bytes);
 /* the reference demo's upload + ProcessFrame (main.cpp:50-58): host buffer, dense rows.  The frame is copied

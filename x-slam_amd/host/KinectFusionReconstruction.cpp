@@ -21,6 +21,8 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&scale_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&tail_done_, hipEventDisableTiming));
+    hipSafeCall(hipEventCreateWithFlags(&surface_done_next_, hipEventDisableTiming));
+    hipSafeCall(hipEventCreateWithFlags(&scale_done_next_, hipEventDisableTiming));
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, COUNTER_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, PINNED_DOUBLES * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < PINNED_DOUBLES; ++i) pinned_sums_[i] = 0.0;
@@ -37,6 +39,8 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (surface_done_) (void)hipEventDestroy(surface_done_);
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
     if (tail_done_) (void)hipEventDestroy(tail_done_);
+    if (surface_done_next_) (void)hipEventDestroy(surface_done_next_);
+    if (scale_done_next_) (void)hipEventDestroy(scale_done_next_);
     if (scale_done_) (void)hipEventDestroy(scale_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
@@ -852,47 +856,38 @@ void KinectFusionReconstruction::EnqueueAnnouncedFrame() {
     if (!next_hint_ptr_) return;
     hipStream_t main_stream = current_stream();
     current_stream() = aux_stream_;
-    // The NEXT frame's bilateral filter and depth pyramid (two thirds of a frame's map preparation) go into the queue now: they depend
-    // on that depth image alone and run while this frame's ICP launches — 45 to 256 workgroups each, waiting on one another — leave
-    // most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP launch waits for.
-    if (depths_next_d.size() != depths_curr_d.size()) depths_next_d.resize(depths_curr_d.size());
+    // The NEXT frame's map preparation — bilateral filter, depth pyramid, vertex / normal maps, scaled depth — goes into the queue now, into the
+    // second set of buffers: it depends on that depth image alone and runs while this frame's ICP launches (45 to 256 workgroups each, waiting
+    // on one another) leave most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP
+    // launch waits for.
+    SwapMapSets();
+    if (depths_curr_d.size() != depths_next_d.size()) depths_curr_d.resize(depths_next_d.size());
     for (size_t i = 0; i < depths_curr_d.size(); ++i)
-        if (depths_next_d[i].rows() != depths_curr_d[i].rows() || depths_next_d[i].cols() != depths_curr_d[i].cols())
-            depths_next_d[i].create(depths_curr_d[i].rows(), depths_curr_d[i].cols());
+        if (depths_curr_d[i].rows() != depths_next_d[i].rows() || depths_curr_d[i].cols() != depths_next_d[i].cols())
+            depths_curr_d[i].create(depths_next_d[i].rows(), depths_next_d[i].cols());
+    if (vmaps_curr_d.size() != vmaps_next_d.size()) { vmaps_curr_d.resize(vmaps_next_d.size()); nmaps_curr_d.resize(nmaps_next_d.size()); }
+    if (depthRawScaled_d.rows() != depth_height || depthRawScaled_d.cols() != depth_width) depthRawScaled_d.create(depth_height, depth_width);
+    if (!depth_max_.ptr()) depth_max_.create(4);
     const DeviceArray2D<ushort> next(depth_height, depth_width, const_cast<void *>(next_hint_ptr_), next_hint_step_);   // borrowed
     // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
     // on that pyramid's dispatch, the wait is a packet of this stream only
     if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
-    SmoothDepthFrame(depths_next_d[0], next);
-    for (int i = 1; i < num_levels; ++i) pyrDown(depths_next_d[i - 1], depths_next_d[i]);
+    // (this set's scaled depth was the previous frame's: that frame's integrate must be through with it — it is, wherever the pyramid's
+    // event above exists; the explicit wait covers the configurations without one)
+    if (integrate_recorded_ && hipEventQuery(integrate_done_now_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_now_, 0));
+    SmoothDepthFrame(depths_curr_d[0], next);
+    for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
+    EnqueueMapsFromPyramid();
+    hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
+    EnqueueScale(next);
+    SwapMapSets();
     next_ready_ptr_ = next_hint_ptr_; next_ready_step_ = next_hint_step_; next_ready_ = true;
     next_hint_ptr_ = nullptr;
     current_stream() = main_stream;
 }
 
-// reference :280-299
-void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &depth_frame_d) {
-    if (depth_width <= 0 || depth_height <= 0) {
-        std::cout << "error::KinectFusionReconstruction, not created yet" << std::endl;
-        return;
-    }
-    // The current-frame maps depend only on the new depth image, which must be complete when
-    // ProcessFrame is called: they are built on a second stream, so they run under whatever the
-    // main stream still has in flight from the previous frame (raycast, pyramid), and the main
-    // stream picks them up through an event before the first ICP launch.
-    hipStream_t main_stream = current_stream();
-    current_stream() = aux_stream_;
-    stage_begin(ST_SURFACE);
-    if (next_ready_ && next_ready_ptr_ == (const void *)depth_frame_d.ptr() && next_ready_step_ == depth_frame_d.step() &&
-        depths_next_d.size() == depths_curr_d.size()) {
-        // this frame was announced while the previous one was being tracked (HintNextFrame): its filtered depth and pyramid were built
-        // then, on this same stream — the kernels below are ordered behind them without an event
-        std::swap(depths_curr_d, depths_next_d);
-    } else {
-        SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
-        for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
-    }
-    next_ready_ = false;
+// createVMap + createNMap of the current set's depth pyramid, on current_stream()
+void KinectFusionReconstruction::EnqueueMapsFromPyramid() {
     {   // createVMap + createNMap per level (camera frame, +z forward), all levels in one launch
         Intr ks[3];
         const float *dp[3]; size_t ds[3], ms[3];
@@ -931,10 +926,61 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
                 createNMap(vmaps_curr_d[i], nmaps_curr_d[i]);
             }
     }
+}
+
+// scaleDepthKernal of integrateTsdfVolume (TsdfFusion.cu:182-187) into the current set, on the auxiliary stream
+void KinectFusionReconstruction::EnqueueScale(const DeviceArray2D<ushort> &depth_frame_d) {
+    hipSafeCall(hipMemsetAsync(depth_max_.ptr(), 0, sizeof(float), aux_stream_));
+    check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                                depthRawScaled_d.step(), depth_max_.ptr(), aux_stream_), "scaleDepth");
+    hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
+    scale_recorded_ = true;
+}
+
+// the two sets of per-frame buffers (filtered depth pyramid, vertex / normal maps and their real planes, scaled depth and its maximum,
+// the events that say when they are ready) change places
+void KinectFusionReconstruction::SwapMapSets() {
+    std::swap(depths_curr_d, depths_next_d);
+    std::swap(vmaps_curr_d, vmaps_next_d);
+    std::swap(nmaps_curr_d, nmaps_next_d);
+    std::swap(vreal_curr_d, vreal_next_d);
+    std::swap(nreal_curr_d, nreal_next_d);
+    std::swap(depthRawScaled_d, depthRawScaled_next_d);
+    std::swap(depth_max_, depth_max_next_);
+    std::swap(surface_done_, surface_done_next_);
+    std::swap(scale_done_, scale_done_next_);
+    std::swap(real_maps_valid_, real_maps_valid_next_);
+    std::swap(scale_recorded_, scale_recorded_next_);
+}
+
+// reference :280-299
+void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &depth_frame_d) {
+    if (depth_width <= 0 || depth_height <= 0) {
+        std::cout << "error::KinectFusionReconstruction, not created yet" << std::endl;
+        return;
+    }
+    // The current-frame maps depend only on the new depth image, which must be complete when
+    // ProcessFrame is called: they are built on a second stream, so they run under whatever the
+    // main stream still has in flight from the previous frame (raycast, pyramid), and the main
+    // stream picks them up through an event before the first ICP launch.
+    hipStream_t main_stream = current_stream();
+    current_stream() = aux_stream_;
+    stage_begin(ST_SURFACE);
+    const bool adopted = next_ready_ && next_ready_ptr_ == (const void *)depth_frame_d.ptr() && next_ready_step_ == depth_frame_d.step();
+    next_ready_ = false;
+    if (adopted) {
+        // this frame was announced while the previous one was being tracked (HintNextFrame): its maps and its scaled depth were built then, on
+        // this same stream, in the second set of buffers — the sets change places, and so do the events that say when they were ready
+        SwapMapSets();
+    } else {
+        SmoothDepthFrame(depths_curr_d[0], depth_frame_d);
+        for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
+        EnqueueMapsFromPyramid();
+    }
     stage_end(ST_SURFACE);
     // the ICP needs the maps and nothing else of this stream: the main stream picks them up here, not
     // behind the depth scaling below (two more kernels and their packets in front of the first ICP launch)
-    hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
+    if (!adopted) hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
     // scaleDepthKernal of integrateTsdfVolume (TsdfFusion.cu:182-187) also depends on the depth image
     // alone: metres + the frame's largest valid depth, ready long before integrate asks for them
     // (the previous frame's integrate, possibly still running on the main stream, reads the same
@@ -948,13 +994,11 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
         check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), aux_stream_), "integrate workspace");
         integrate_header_clear_ = true;
     }
-    stage_begin(ST_SCALE);
-    hipSafeCall(hipMemsetAsync(depth_max_.ptr(), 0, sizeof(float), aux_stream_));
-    check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
-                                depthRawScaled_d.step(), depth_max_.ptr(), aux_stream_), "scaleDepth");
-    stage_end(ST_SCALE);
-    hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
-    scale_recorded_ = true;
+    if (!adopted) {
+        stage_begin(ST_SCALE);
+        EnqueueScale(depth_frame_d);
+        stage_end(ST_SCALE);
+    }
     current_stream() = main_stream;
     // the main stream picks the maps up — without a wait packet when they are already there (the usual case once the
     // previous frame's tail is the longer of the two)

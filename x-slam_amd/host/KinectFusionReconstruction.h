@@ -81,6 +81,9 @@ public:
     // prepares its own maps as always.  Same results bit for bit (tests/test_pipeline_gpu.py).
     void HintNextFrame(const ushort *depth_dev, size_t step_bytes) { next_hint_ptr_ = depth_dev; next_hint_step_ = step_bytes; }
     void EnqueueAnnouncedFrame();
+    void EnqueueMapsFromPyramid();
+    void EnqueueScale(const DeviceArray2D<ushort> &depth_frame_d);
+    void SwapMapSets();
     bool list_ready_ = false;
     float list_Rv2c_[18]{}, list_tv2c_[6]{};
     void ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr);
@@ -227,7 +230,13 @@ private:
     DeviceArray<float> ray_ws_;                // raycast: crossing time per pixel (march kernel -> crossing kernel)
     hipEvent_t tail_done_ = nullptr;           // completion of a frame's model-map pyramid (rides on its dispatch)
     bool tail_recorded_ = false;
-    std::vector<MapArr> depths_next_d;         // the announced next frame's filtered depth pyramid (HintNextFrame)
+    // the second set of per-frame buffers: the announced next frame's maps are built into it (HintNextFrame, SwapMapSets)
+    std::vector<MapArr> depths_next_d, vmaps_next_d, nmaps_next_d;
+    std::vector<DeviceArray2D<float>> vreal_next_d, nreal_next_d;
+    DeviceArray2D<float> depthRawScaled_next_d;
+    DeviceArray<float> depth_max_next_;
+    hipEvent_t surface_done_next_ = nullptr, scale_done_next_ = nullptr;
+    bool real_maps_valid_next_ = false, scale_recorded_next_ = false;
     const void *next_hint_ptr_ = nullptr, *next_ready_ptr_ = nullptr;
     size_t next_hint_step_ = 0, next_ready_step_ = 0;
     bool next_ready_ = false;
