@@ -152,7 +152,7 @@ class KinectFusion:
         return _lib.xs_kf_process_frame(self.h, ptr, step)
 
     def hint_next_frame(self, depth_dev, step_bytes=None):
-        """The device depth image the NEXT process_frame call will be given (unchanged until then): its bilateral filter and pyramid are built
+        """The device depth image the NEXT process_frame call will be given (unchanged until then): its maps are built
         during this frame's ICP loop.  Call before process_frame of the current frame."""
         _lib.xs_kf_hint_next_frame(self.h, depth_dev.data_ptr(), step_bytes or self.width * 2)
 
