@@ -288,7 +288,7 @@ int KinectFusionReconstruction::ProcessFrameHost(const ushort *depth_host) {
 // reference :161-175
 int KinectFusionReconstruction::AlignDepthToReconstruction(const DeviceArray2D<ushort> &depth_frame_d, bool /*use_LM*/) {
     SurfaceMeasure(depth_frame_d);
-    struct AtExit { KinectFusionReconstruction *k; ~AtExit() { k->EnqueueAnnouncedFrame(); } } announced_at_exit{this};   // (whatever path is taken below)
+    struct AtExit { KinectFusionReconstruction *k; ~AtExit() { k->EnqueueAnnouncedFrame(true); } } announced_at_exit{this};   // (whatever path is taken below)
     if (use_gtPose) return 1;
     Matrix4cf c2w_prev = inverse(world2camera_record.back());
     Matrix3frm Rprev = GetRotation(c2w_prev);
@@ -391,7 +391,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 // frame's first ones are enqueued while the GPU still works on the previous frame's raycast — measured the same
                 // 2 900-2 950 frames/s as one: those gaps are the profiler's.)
                 enqueue_through(n + std::max(1, icp_lookahead), &device_Rcurr, &device_tcurr);
-                if (n == 0) EnqueueAnnouncedFrame();   // (behind the frame's first ICP launches)
+                EnqueueAnnouncedFrame(false);   // (one stage of the announced next frame's map preparation per iteration, behind this frame's ICP launches)
                 // the last launch is in the queue: the integrate call's brick classification goes in behind it, for the pose that
                 // launch starts from — the final one differs by the last level-0 update, which IntegrateFrame checks is covered
                 // (with integrate_post_pose the integrate kernel follows the classification into the queue, gated on its mailbox: the host's three
@@ -849,41 +849,52 @@ void KinectFusionReconstruction::ModelMapPyramid() {
     }
 }
 
-// The announced next frame's bilateral filter and depth pyramid (HintNextFrame), on the second stream.  Called once the frame's first ICP
-// launches are in the queue (PoseEstimate) — the host's time for these three launches is then off the path to that first launch — or at the
-// end of AlignDepthToReconstruction where there is no ICP loop.
-void KinectFusionReconstruction::EnqueueAnnouncedFrame() {
-    if (!next_hint_ptr_) return;
-    hipStream_t main_stream = current_stream();
-    current_stream() = aux_stream_;
-    // The NEXT frame's map preparation — bilateral filter, depth pyramid, vertex / normal maps, scaled depth — goes into the queue now, into the
-    // second set of buffers: it depends on that depth image alone and runs while this frame's ICP launches (45 to 256 workgroups each, waiting
-    // on one another) leave most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP
-    // launch waits for.
-    SwapMapSets();
-    if (depths_curr_d.size() != depths_next_d.size()) depths_curr_d.resize(depths_next_d.size());
-    for (size_t i = 0; i < depths_curr_d.size(); ++i)
-        if (depths_curr_d[i].rows() != depths_next_d[i].rows() || depths_curr_d[i].cols() != depths_next_d[i].cols())
-            depths_curr_d[i].create(depths_next_d[i].rows(), depths_next_d[i].cols());
-    if (vmaps_curr_d.size() != vmaps_next_d.size()) { vmaps_curr_d.resize(vmaps_next_d.size()); nmaps_curr_d.resize(nmaps_next_d.size()); }
-    if (depthRawScaled_d.rows() != depth_height || depthRawScaled_d.cols() != depth_width) depthRawScaled_d.create(depth_height, depth_width);
-    if (!depth_max_.ptr()) depth_max_.create(4);
-    const DeviceArray2D<ushort> next(depth_height, depth_width, const_cast<void *>(next_hint_ptr_), next_hint_step_);   // borrowed
-    // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
-    // on that pyramid's dispatch, the wait is a packet of this stream only
-    if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
-    // (this set's scaled depth was the previous frame's: that frame's integrate must be through with it — it is, wherever the pyramid's
-    // event above exists; the explicit wait covers the configurations without one)
-    if (integrate_recorded_ && hipEventQuery(integrate_done_now_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_now_, 0));
-    SmoothDepthFrame(depths_curr_d[0], next);
-    for (int i = 1; i < num_levels; ++i) pyrDown(depths_curr_d[i - 1], depths_curr_d[i]);
-    EnqueueMapsFromPyramid();
-    hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
-    EnqueueScale(next);
-    SwapMapSets();
-    next_ready_ptr_ = next_hint_ptr_; next_ready_step_ = next_hint_step_; next_ready_ = true;
-    next_hint_ptr_ = nullptr;
-    current_stream() = main_stream;
+// The announced next frame's map preparation (HintNextFrame), on the second stream, in stages: called from the ICP loop (PoseEstimate), one
+// stage per iteration, and with `all` at the end of AlignDepthToReconstruction for whatever is left (or where there is no ICP loop).
+void KinectFusionReconstruction::EnqueueAnnouncedFrame(bool all) {
+    // One stage per call from the ICP loop (the host has ~8 us to spare per iteration: one more launch next to the ICP launch it enqueues while
+    // the GPU runs the previous one — all six at once delayed the frame's second pose by 15 us), the rest at once when `all`.
+    while (next_hint_ptr_) {
+        hipStream_t main_stream = current_stream();
+        current_stream() = aux_stream_;
+        // The NEXT frame's map preparation — bilateral filter, depth pyramid, vertex / normal maps, scaled depth — goes into the second set of
+        // buffers: it depends on that depth image alone and runs while this frame's ICP launches (45 to 256 workgroups each, waiting on one
+        // another) leave most of the GPU idle, instead of next to this frame's integrate and raycast, which the next frame's first ICP launch
+        // waits for.  The sets change places around each stage only: the ICP launches enqueued in between read this frame's maps.
+        SwapMapSets();
+        const DeviceArray2D<ushort> next(depth_height, depth_width, const_cast<void *>(next_hint_ptr_), next_hint_step_);   // borrowed
+        if (next_stage_ == 0) {
+            if (depths_curr_d.size() != depths_next_d.size()) depths_curr_d.resize(depths_next_d.size());
+            for (size_t i = 0; i < depths_curr_d.size(); ++i)
+                if (depths_curr_d[i].rows() != depths_next_d[i].rows() || depths_curr_d[i].cols() != depths_next_d[i].cols())
+                    depths_curr_d[i].create(depths_next_d[i].rows(), depths_next_d[i].cols());
+            if (vmaps_curr_d.size() != vmaps_next_d.size()) { vmaps_curr_d.resize(vmaps_next_d.size()); nmaps_curr_d.resize(nmaps_next_d.size()); }
+            if (depthRawScaled_d.rows() != depth_height || depthRawScaled_d.cols() != depth_width) depthRawScaled_d.create(depth_height, depth_width);
+            if (!depth_max_.ptr()) depth_max_.create(4);
+            // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
+            // on that pyramid's dispatch, the wait is a packet of this stream only
+            if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
+            // (this set's scaled depth was the previous frame's: that frame's integrate must be through with it — it is, wherever the pyramid's
+            // event above exists; the explicit wait covers the configurations without one)
+            if (integrate_recorded_ && hipEventQuery(integrate_done_now_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, integrate_done_now_, 0));
+            SmoothDepthFrame(depths_curr_d[0], next);
+        } else if (next_stage_ < num_levels) {
+            pyrDown(depths_curr_d[next_stage_ - 1], depths_curr_d[next_stage_]);
+        } else if (next_stage_ == num_levels) {
+            EnqueueMapsFromPyramid();
+            hipSafeCall(hipEventRecord(surface_done_, aux_stream_));
+        } else {
+            EnqueueScale(next);
+        }
+        SwapMapSets();
+        current_stream() = main_stream;
+        if (++next_stage_ > num_levels + 1) {
+            next_ready_ptr_ = next_hint_ptr_; next_ready_step_ = next_hint_step_; next_ready_ = true;
+            next_hint_ptr_ = nullptr;
+            next_stage_ = 0;
+        }
+        if (!all) break;
+    }
 }
 
 // createVMap + createNMap of the current set's depth pyramid, on current_stream()

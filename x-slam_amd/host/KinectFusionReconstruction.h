@@ -79,8 +79,12 @@ public:
     // time): the caller names the depth image it will pass to the NEXT ProcessFrame call — device memory, unchanged until then — and that
     // frame's bilateral filter and depth pyramid are built during this frame's ICP loop.  A ProcessFrame call with any other image simply
     // prepares its own maps as always.  Same results bit for bit (tests/test_pipeline_gpu.py).
-    void HintNextFrame(const ushort *depth_dev, size_t step_bytes) { next_hint_ptr_ = depth_dev; next_hint_step_ = step_bytes; }
-    void EnqueueAnnouncedFrame();
+    void HintNextFrame(const ushort *depth_dev, size_t step_bytes) {
+        if (next_stage_ != 0) EnqueueAnnouncedFrame(true);   // (an announcement half enqueued is finished first: never expected)
+        next_hint_ptr_ = depth_dev; next_hint_step_ = step_bytes;
+    }
+    void EnqueueAnnouncedFrame(bool all);
+    int next_stage_ = 0;
     void EnqueueMapsFromPyramid();
     void EnqueueScale(const DeviceArray2D<ushort> &depth_frame_d);
     void SwapMapSets();
