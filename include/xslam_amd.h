@@ -202,7 +202,7 @@ void xs_raycast_set_step_buffer(int *steps_dev);
  * RayCaster.cu:222-247 evaluates every step of every ray from t = 0.2 m.  Each event that can end that loop — a sample outside the
  * volume, a + to - crossing, a - to + crossing — needs a sample outside or a NEGATIVE voxel on one side of the step.  The sign map keeps
  * one byte per brick of 2^shift voxels a side, set once a negative value has been written into the brick (never cleared but by reset /
- * rebuild: a superset); the single-GPU march samples it along the ray, finds the stretch that cannot hold an event, and resumes the
+ * rebuild: a superset); the march (single GPU, or a rank's slab march) samples it along the ray, finds the stretch that cannot hold an event, and resumes the
  * reference's loop behind it at the float time that loop would have there (a table of its running sum) with the value it would
  * carry — the same crossing, vertex and normal bits, about a fifth of the volume reads (march kernel 48 -> 22 us on the benchmark scene).  The owner of the volume is responsible for
  * the map seeing every write: xs_integrate_* mark it when xs_integrate_set_signmap names it; after any other write into the value
@@ -213,13 +213,16 @@ void xs_raycast_set_step_buffer(int *steps_dev);
  *   xs_signmap_bytes     size of the device buffer for a resolution and brick shift (2..6; 3 = 8^3 voxels), 0 if invalid
  *   xs_signmap_reset     empty map + the time table for tranc_dist (time step 0.8 * tranc_dist, RayCaster.cu:350)
  *   xs_signmap_rebuild   reset, then mark every brick of `value` that holds a negative voxel
- *   xs_integrate_set_signmap   thread-local: the map the following xs_integrate_* calls mark (whole-volume launches only; NULL = none)
- *   xs_raycast_set_signmap     thread-local: the map the following xs_raycast calls (with a workspace) start their rays from; it must
+ *   xs_integrate_set_signmap   thread-local: the map the following xs_integrate_* calls mark (slab launches mark the bricks of their own planes; NULL = none)
+ *   xs_raycast_set_signmap     thread-local: the map the following xs_raycast (with a workspace) and xs_raycast_slab calls march by — a rank of a
+ *                              sharded volume passes the map its own integrate calls (owned slab + halo) marked; it must
  *                              have been reset for the same tranc_dist, else xs_raycast refuses; NULL = march from t = 0.2 */
 int xs_raycast_signmap_shift(const float *intr4, float voxel_size, float tranc_dist);
 size_t xs_signmap_bytes(const int *res, int shift);
 int xs_signmap_reset(void *signmap, const int *res, int shift, float tranc_dist, void *stream);
 int xs_signmap_rebuild(void *signmap, const int *res, int shift, float tranc_dist, const float *value, size_t vol_step, void *stream);
+int xs_signmap_rebuild_slab(void *signmap, const int *res, int shift, float tranc_dist, const float *value, size_t vol_step, int zs0, int zs1,
+                            void *stream);   /* one rank's storage of a z-sharded volume: value holds planes [zs0, zs1) */
 void xs_integrate_set_signmap(void *signmap);
 void xs_raycast_set_signmap(const void *signmap, int shift, float tranc_dist);
 

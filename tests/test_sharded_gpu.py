@@ -110,6 +110,25 @@ def test_sharded_equals_single(dev, world, rows_sharded):
     single.close()
 
 
+def test_sharded_sign_map_changes_nothing(dev):
+    """Every rank keeps a sign map of the planes it stores (owned slab + halo, marked by its own integrate calls) and its slab march
+    evaluates only the iterations that map leaves: poses, counts and ICP sums of a three-rank run with and without, bit for bit."""
+    torch, pl, sh = dev
+    prm = synth.s1_params(128)
+    frames = list(range(6))
+    s_on, on = run_world(torch, sh, dict(prm, raycast_sign_map=True), 3, frames)
+    s_off, off = run_world(torch, sh, dict(prm, raycast_sign_map=False), 3, frames)
+    for a_, b_ in zip(on, off):
+        assert np.array_equal(a_[0], b_[0]) and a_[1] == b_[1] and a_[2] == b_[2]
+        assert np.array_equal(a_[3], b_[3])
+    assert on[0][2] > 0.5 * synth.HEIGHT * synth.WIDTH
+    for x, y in zip(s_on, s_off):
+        for u, v in zip(x.volume(), y.volume()):
+            assert np.array_equal(u, v)
+    for r in s_on + s_off:
+        r.close()
+
+
 def test_sharded_first_frame_bit_exact(dev):
     """Frame 0 has no ICP: the sharded integrate + raycast composite must reproduce the single-GPU
     volume and maps bit for bit."""

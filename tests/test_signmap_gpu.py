@@ -185,13 +185,31 @@ def test_sign_map_misuse_is_refused(dev):
         cast(torch, capi, prm, res, value, value, T, signmap=sm, tranc=2 * tranc_dist(prm))
     with pytest.raises(RuntimeError, match="time table"):      # more march steps than the table holds
         capi.signmap_reset(sm, res, 3, 1e-4)
-    # a slab launch cannot mark a whole-volume map
-    weight = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
-    scaled = torch.ones((H, W), dtype=torch.float32, device="cuda")
-    capi.integrate_set_signmap(sm)
-    try:
-        with pytest.raises(RuntimeError, match="slab"):
-            capi.integrate_scaled(scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm),
-                                  value, weight, value.clone(), n * 4, z0=0, z1=n // 2)
-    finally:
-        capi.integrate_set_signmap(None)
+    # slab launches mark the bricks of their own planes (a rank of a sharded volume)
+    prm2 = synth.s1_params(96)
+    res2 = [96, 96, 96]
+    marks = []
+    for bounds in ([0, 96], [0, 40, 96]):
+        sm2 = torch.zeros(capi.signmap_bytes(res2, 3), dtype=torch.uint8, device="cuda")
+        capi.signmap_reset(sm2, res2, 3, tranc_dist(prm2))
+        v = torch.zeros((96 * 96, 96), dtype=torch.float32, device="cuda")
+        w = torch.zeros((96 * 96, 96), dtype=torch.int32, device="cuda")
+        g = torch.zeros_like(v)
+        scaled2 = torch.empty((H, W), dtype=torch.float32, device="cuda")
+        depth = torch.from_numpy(synth.s1_frame(0).astype(np.int16)).cuda()
+        capi.scale_depth(depth, W * 2, H, W, scaled2, W * 4)
+        T2 = s1_transforms(0, prm2)
+        capi.integrate_set_signmap(sm2)
+        try:
+            for z0, z1 in zip(bounds[:-1], bounds[1:]):
+                off = z0 * 96
+                capi.integrate_scaled(scaled2, W * 4, H, W, intr_of(prm2), 100, res2, prm2["tsdf_voxel_size"], T2["Rv2c"], T2["tv2c"], tranc_dist(prm2),
+                                      v[off:], w[off:], g[off:], 96 * 4, z0=z0, z1=z1)
+        finally:
+            capi.integrate_set_signmap(None)
+        torch.cuda.synchronize()
+        raw2 = bricks_of(torch, sm2, res2, 3)[0]
+        neg2 = negatives_by_brick(torch, v, res2, 3)
+        assert int(neg2.sum()) > 20 and bool((raw2[neg2] == 1).all())     # a superset either way (the column walk marks a column's whole span)
+        marks.append(v.clone())
+    assert torch.equal(marks[0], marks[1])

@@ -118,6 +118,7 @@ _SIGS = {
     "xs_signmap_bytes": (C.c_size_t, [_i32p, C.c_int]),
     "xs_signmap_reset": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp]),
     "xs_signmap_rebuild": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp, C.c_size_t, _vp]),
+    "xs_signmap_rebuild_slab": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp, C.c_size_t, C.c_int, C.c_int, _vp]),
     "xs_integrate_set_signmap": (None, [_vp]),
     "xs_raycast_set_signmap": (None, [_vp, C.c_int, C.c_float]),
     "xs_const_div_state": (C.c_uint, [C.c_float]),

@@ -373,6 +373,70 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
             float pval = (gz >= a.zs0 && gz < a.zs1) ? vol.read_value(gx, gy, gz) : 0.f;
             bool pstored = gz >= a.zs0 && gz < a.zs1;
             bool done = false;
+            if (MAP) {
+                // The same march over the iterations this rank's sign map leaves (the wave's bit mask, top of the kernel): the map knows the
+                // negative voxels of the planes this rank stores — owned slab + halo, marked by its own integrate calls — and an iteration
+                // whose sample lies elsewhere is not this rank's to evaluate anyway.  Behind a jump the previous sample is taken as stored
+                // and positive: it lies in a brick without negative voxels, within one step of an owned sample, i.e. inside the halo.
+                int k = next_unsafe(0);
+                if (k != 0) { pval = 1.0f; pstored = true; }
+                while (k >= 0) {
+                    constexpr int NS = 8;
+                    float val[NS];
+                    unsigned term = 0, own = 0, stored = 0;
+                    const float tb = a.sm.t[k];
+                    if (!done) {
+                        float t = tb;
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) {
+                            const float tn = t + time_step;
+                            const int jx = voxel_index<SHORT>(sx + dx * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                            const int jy = voxel_index<SHORT>(sy + dy * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                            const int jz = voxel_index<SHORT>(sz + dz * tn, vs, a.inv_vs_lo, a.inv_vs_hi, a.dv);
+                            const bool inb = (unsigned)jx < (unsigned)a.X && (unsigned)jy < (unsigned)a.Y && (unsigned)jz < (unsigned)a.Z;
+                            const bool st = inb && jz >= a.zs0 && jz < a.zs1;
+                            term |= ((t < max_time) && inb ? 0u : 1u) << j;
+                            own |= ((inb && jz >= a.z0 && jz < a.z1) ? 1u : 0u) << j;
+                            stored |= (st ? 1u : 0u) << j;
+                            if (OFF32) val[j] = vol.value_at(st ? vol.offset32(jx, jy, jz) : 0u) + 1e-5f;
+                            else val[j] = vol.read_value(st ? jx : 0, st ? jy : 0, st ? jz : a.zs0);
+                            t += time_step;
+                        }
+                        unsigned thin = 0, up = 0, down = 0;
+                        float prev = pval;
+                        bool prev_st = pstored;
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) {
+                            const bool o = (own >> j) & 1u;
+                            thin |= ((o && !prev_st) ? 1u : 0u) << j;
+                            up |= ((o && prev_st && prev < 0.f && val[j] > 0.f) ? 1u : 0u) << j;
+                            down |= ((o && prev_st && prev > 0.f && val[j] < 0.f) ? 1u : 0u) << j;
+                            prev = val[j];
+                            prev_st = (stored >> j) & 1u;
+                        }
+                        const unsigned ev = term | thin | up | down;
+                        if (ev) {
+                            const int e = __ffs(ev) - 1;
+                            if (!((term >> e) & 1u)) {
+                                key = ((k + e) << 1) | 1;
+                                if ((down >> e) & 1u) {
+                                    float tce = tb;   // time_curr of iteration k + e: the same e additions once more
+                                    for (int j = 0; j < e; ++j) tce += time_step;
+                                    row_ptr(a.vmap, a.mstep, y)[x] = cfloat(tce, 1.0f);  // for MODE 5
+                                }
+                            }
+                            done = true;
+                        }
+                        pval = val[NS - 1];
+                        pstored = (stored >> (NS - 1)) & 1u;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                    const int kn = next_unsafe(k + NS);
+                    if (kn != k + NS) { pval = 1.0f; pstored = true; }
+                    k = kn;
+                }
+                done = true;
+            }
             while (!done && time_curr < max_time) {
                 constexpr int NS = 8;
                 float tc[NS], val[NS];
@@ -739,15 +803,27 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
     a.hits = nullptr; a.cross_t = nullptr; a.steps = nullptr;
-    a.sm = SignMap{};   // (a slab sees only its own planes: every rank marches every step it owns)
-    static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
-    a.wshift = (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
+    a.sm = SignMap{};
+    a.sm_dt = 0.0f; a.sm_rounds = 0;
+    if (g_ray_signmap) {
+        // this rank's sign map (marked by its own integrate calls: owned slab + halo): the march evaluates the iterations it leaves
+        if (g_ray_signmap_tranc * 0.8f != a.time_step || g_ray_signmap_shift < 2 || g_ray_signmap_shift > 6)
+            return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: the sign map was prepared for another truncation distance");
+        const int nt = signmap_steps(a.time_step);
+        if (nt == 0) return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: the march has more steps than the sign map's time table holds");
+        a.sm = signmap_view(g_ray_signmap, res, g_ray_signmap_shift, nt);
+    }
+    a.wshift = ray_wshift();
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);
+    if (a.sm.dil && !sign_map_spacing(a.intr.fx, a.intr.fy, a.wshift, voxel_size, a.sm.shift, a.sm_dt, a.sm_rounds))
+        return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: the sign map's bricks are too small for a wave's pixel tile (xs_raycast_signmap_shift gives a usable shift)");
     if (fits32(a)) {
-        hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<4, true, true> : k_raycast<4, true, false>), grid, block, 0, (hipStream_t)stream, a);
+        if (a.sm.dil) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<4, true, true, true> : k_raycast<4, true, false, true>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<4, true, true> : k_raycast<4, true, false>), grid, block, 0, (hipStream_t)stream, a);
         hipLaunchKernelGGL((k_raycast<5, true, false>), grid, block, 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL((k_raycast<4, false, false>), grid, block, 0, (hipStream_t)stream, a);
+        if (a.sm.dil) hipLaunchKernelGGL((k_raycast<4, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_raycast<4, false, false>), grid, block, 0, (hipStream_t)stream, a);
         hipLaunchKernelGGL((k_raycast<5, false, false>), grid, block, 0, (hipStream_t)stream, a);
     }
     XS_CHECK(hipGetLastError());

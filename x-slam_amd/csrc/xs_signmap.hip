@@ -26,14 +26,14 @@ __global__ void __launch_bounds__(256) k_signmap_reset(SignMap m, int *head, flo
     }
 }
 // one workgroup per brick row (all bricks of one (by, bz)): each thread scans voxels of the row's bricks and marks negative ones
-__global__ void __launch_bounds__(256) k_signmap_scan(SignMap m, const float *value, size_t vstep, int X, int Y, int Z) {
+__global__ void __launch_bounds__(256) k_signmap_scan(SignMap m, const float *value, size_t vstep, int X, int Y, int Z, int zs0, int zs1) {
     const int by = blockIdx.x % m.ny, bz = blockIdx.x / m.ny;
     const int e = 1 << m.shift;
     const int y0 = by << m.shift, z0 = bz << m.shift;
-    const int y1 = min(Y, y0 + e), z1 = min(Z, z0 + e);
-    for (int z = z0; z < z1; ++z)
+    const int y1 = min(Y, y0 + e), z1 = min(min(Z, z0 + e), zs1);
+    for (int z = max(z0, zs0); z < z1; ++z)     // (value holds planes zs0 .. zs1 - 1, the first at offset 0)
         for (int y = y0; y < y1; ++y) {
-            const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + ((size_t)z * Y + y) * vstep);
+            const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(value) + ((size_t)(z - zs0) * Y + y) * vstep);
             for (int x = threadIdx.x; x < X; x += 256)
                 if (row[x] < 0.0f) signmap_mark(m, x, y, z);
         }
@@ -62,11 +62,17 @@ extern "C" int xs_signmap_reset(void *signmap, const int *res, int shift, float 
 }
 
 extern "C" int xs_signmap_rebuild(void *signmap, const int *res, int shift, float tranc_dist, const float *value, size_t vol_step, void *stream) {
+    return xs_signmap_rebuild_slab(signmap, res, shift, tranc_dist, value, vol_step, 0, res ? res[2] : 0, stream);
+}
+/* the same for one rank's storage of a z-sharded volume: value holds planes [zs0, zs1) */
+extern "C" int xs_signmap_rebuild_slab(void *signmap, const int *res, int shift, float tranc_dist, const float *value, size_t vol_step, int zs0, int zs1,
+                                       void *stream) {
     if (!value) return xs_set_error(hipErrorInvalidValue, "xs_signmap_rebuild: null volume");
+    if (!res || zs0 < 0 || zs1 > res[2] || zs1 < zs0) return xs_set_error(hipErrorInvalidValue, "xs_signmap_rebuild_slab: bad slab");
     const int rc = xs_signmap_reset(signmap, res, shift, tranc_dist, stream);
     if (rc) return rc;
     SignMap m = signmap_view(signmap, res, shift, signmap_steps(tranc_dist * 0.8f));
-    hipLaunchKernelGGL(k_signmap_scan, dim3(m.ny * m.nz), dim3(256), 0, (hipStream_t)stream, m, value, vol_step, res[0], res[1], res[2]);
+    hipLaunchKernelGGL(k_signmap_scan, dim3(m.ny * m.nz), dim3(256), 0, (hipStream_t)stream, m, value, vol_step, res[0], res[1], res[2], zs0, zs1);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : xs_set_error(e, "xs_signmap_rebuild: launch failed");
 }

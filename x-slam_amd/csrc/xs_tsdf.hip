@@ -943,9 +943,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
-    a.signmap = g_signmap;
-    if (a.signmap && (z0 != 0 || z1 != res[2]))
-        return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: a sign map covers the whole volume, this launch a slab of it");
+    a.signmap = g_signmap;   // (a slab launch marks the bricks of its own planes: the map is indexed by whole-volume coordinates)
     if (posted) {
         if (!workspace || !(flags & XS_INTEGRATE_LIST_IS_READY) || !g_post_mailbox || !g_post_pose_dev)
             return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: a posted launch needs the classified list and a mailbox (xs_integrate_set_pose_mailbox)");

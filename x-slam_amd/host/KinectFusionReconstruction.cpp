@@ -773,7 +773,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     } else if (integrate_split())
         xs_integrate_set_timing_events(nullptr, integrate_stop);
     if (!integrated_by_post) {
-        xs_integrate_set_signmap(sign_map_ptr());   // (single GPU only: one whole-volume call)
+        xs_integrate_set_signmap(sign_map_ptr());   // (a rank of a sharded volume: the owned planes and both halo bands mark it)
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
         const int zr[3][2] = {{zo0, zo1}, {zs0, zo0}, {zo1, zs1}};
@@ -1045,9 +1045,11 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     const int rows = xyz_g_d.rows() / 3, cols = xyz_g_d.cols();
     hipStream_t st = current_stream();
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
+    xs_raycast_set_signmap(sign_map_ptr(), raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist());
     check_rc(xs_raycast_slab(&kinect_intrinsic.fx, &device_Rc2v.data[0].x.re, &device_tc2v.x.re, &device_Rv2w.data[0].x.re, &device_tv2w.x.re,
                              tsdf_volume_d_ptr->getTsdfTruncDist(), res, voxel_size, value.ptr(), grad.ptr(), value.step(), zs0, zs1, zo0, zo1,
                              &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, ray_keys_.ptr(), st), "raycast");
+    xs_raycast_set_signmap(nullptr, 0, 0.0f);
     hipSafeCall(hipMemcpyAsync(ray_min_keys_.ptr(), ray_keys_.ptr(), (size_t)rows * cols * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (collective) collective(collective_user, 1, ray_min_keys_.ptr(), (long)rows * cols);
     check_rc(xs_raycast_compose_mask(ray_keys_.ptr(), ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, st), "raycast");
@@ -1240,8 +1242,8 @@ void KinectFusionReconstruction::RebuildSignMap() {
     if (!sign_map_on() || !sign_map_.ptr() || !tsdf_volume_d_ptr) return;
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value();
-    check_rc(xs_signmap_rebuild(sign_map_.ptr(), res, raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), value.step(),
-                                current_stream()), "sign map");
+    check_rc(xs_signmap_rebuild_slab(sign_map_.ptr(), res, raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), value.step(),
+                                     zs0, zs1, current_stream()), "sign map");
 }
 
 bool KinectFusionReconstruction::loadCheckpoint(const std::string &filename) {

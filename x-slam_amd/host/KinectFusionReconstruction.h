@@ -70,8 +70,8 @@ public:
     float integrate_classify_slack = 2.0f;   // YAML integrate_classify_slack: how much wider than its own the list's frustum slack is (1 = every frame falls back)
     // The sign map of the ray march (include/xslam_amd.h, csrc/xs_signmap.h; YAML raycast_sign_map, default true; raycast_sign_map_shift, default 0 =
     // the finest bricks the march can use: 8^3 voxels at 512^3): the integrate kernel marks the bricks it writes negative values into, the march starts every ray at the first
-    // step that can end it — the same maps bit for bit (tests/test_signmap_gpu.py), about a fifth of the volume reads.  Single GPU only:
-    // a slab's march owns steps anywhere along the ray.
+    // step that can end it — the same maps bit for bit (tests/test_signmap_gpu.py), about a fifth of the volume reads.  A rank of a sharded
+    // volume keeps a map of the planes it stores (owned slab + halo) and its slab march evaluates the iterations that map leaves.
     bool raycast_sign_map = true;
     int raycast_sign_map_shift = 0;
     void RebuildSignMap();   // call after writing the value array through xs_kf_volume_ptr
@@ -245,7 +245,7 @@ private:
     size_t next_hint_step_ = 0, next_ready_step_ = 0;
     bool next_ready_ = false;
     DeviceArray<unsigned char> sign_map_;      // raycast: bricks that may hold a negative voxel (single GPU)
-    bool sign_map_on() const { return raycast_sign_map && shard_count == 1; }   // (marked whenever it exists: the composite path of a one-rank test run just does not read it)
+    bool sign_map_on() const { return raycast_sign_map; }   // (every rank of a sharded volume keeps one for the planes it stores)
     unsigned char *sign_map_ptr() { return sign_map_on() ? sign_map_.ptr() : nullptr; }
     DeviceArray<int> ray_keys_, ray_min_keys_; // sharded raycast: first-event keys (own, agreed)
     // host-coherent: [0..54] sums + count, [56] completion sequence word, [64..80) pose state of the
