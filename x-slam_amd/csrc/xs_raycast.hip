@@ -34,7 +34,7 @@ struct RaycastArgs {
     int *keys;     // slab mode: per pixel, (step << 1 | no_hit) of the first event among owned steps, INT_MAX if none
     unsigned long long *hits;
     int *steps;    // optional (measurement): per pixel, the march iterations the reference's loop (RayCaster.cu:222-247) runs for this ray
-    SignMap sm;    // sm.dil != null (single-GPU march only): start each ray at the first step that can end it (xs_signmap.h)
+    SignMap sm;    // sm.dil != null (the march kernels): evaluate only the iterations the sign map leaves (xs_signmap.h)
     float sm_dt; int sm_rounds;   // sign map: spacing of the per-wave samples along the tile's centre ray; 64 * sm_rounds of them
 };
 
