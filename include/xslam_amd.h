@@ -56,6 +56,17 @@ int xs_scale_depth(const uint16_t *depth, size_t depth_step, int rows, int cols,
  * depth of the frame, for xs_integrate_scaled's far clipping. */
 int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
                        float *max_dev, void *stream);
+/* Same, and tiles_dev (xs_depth_tiles_bytes(rows, cols) bytes, or NULL) receives the smallest and the largest scaled depth of every
+ * 8 x 8 pixel tile {float lo, hi} (an invalid pixel counts as 0).  No counterpart in the reference: the integrate kernel classifies
+ * whole bricks from it (free space in front of every surface it can see: written with tsdf = (1, 0) without a projection; behind
+ * everything it can see: skipped) and takes the reference's per-voxel path (TsdfFusion.cu:110-167) for the rest — same volume.
+ * xs_integrate_set_depth_tiles hands the table to the following xs_integrate_scaled* calls of the calling thread (NULL: each call
+ * builds its own from the scaled image, in its workspace); xs_depth_tiles builds it from an image that is already scaled. */
+size_t xs_depth_tiles_bytes(int rows, int cols);
+int xs_scale_depth_tiles(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
+                         float *max_dev, void *tiles_dev, void *stream);
+int xs_depth_tiles(const float *scaled, size_t scaled_step, int rows, int cols, void *tiles_dev, void *stream);
+void xs_integrate_set_depth_tiles(const void *tiles_dev);
 
 /* integrateTsdfVolume(const PtrStepSz<ushort>& depth, const Intr&, int max_weight, const int3& res,
  *     float voxel_size, const MatS33& Rv2c, const devComplex3& tv2c, const devComplex3& tc2v,
@@ -87,6 +98,8 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
 #define XS_INTEGRATE_NO_FOLD 2u
 #define XS_INTEGRATE_ALWAYS_STORE 8u    /* store all three words of every updated voxel, also where their bits do not change (the default stores only words that change: same volume, fewer bytes) */
 #define XS_INTEGRATE_POSE_POSTED 16u     /* the kernel takes its pose from a mailbox (xs_integrate_set_pose_mailbox / xs_integrate_post_pose): see below */
+#define XS_INTEGRATE_NO_TILES 32u        /* every brick takes the exact per-voxel walk: no free-space / nothing-to-write classification from the depth tiles (A/B and tests; same volume either way) */
+#define XS_INTEGRATE_COUNT_CLASSES 64u   /* the kernel counts the wave-sized boxes it classified: 32-bit words 48 / 49 / 50 of the workspace = free / nothing to write / exact walk (cleared with the header; tests and bench figures) */
 #define XS_INTEGRATE_LIST_IS_READY 4u   /* xs_integrate_classify has produced the brick list on this stream (see there) */
 int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,

@@ -443,3 +443,179 @@ def test_full_size_properties_512(dev):
     assert float(dv.max()) <= 1.2e-7 and float((dv > 0).float().mean()) < 0.5
     dg = (whole[2][written] - g0[written]).abs()
     assert float(dg.max()) <= 2.4e-7 * max(float(g0.abs().max()), 1e-30)
+
+
+# ---- round 4: depth tiles and the brick classification (free space / nothing to write / exact walk) ----------------------------
+def tiles_numpy(scaled, tw=8, th=8):
+    """{lo, hi} per tw x th pixels of a scaled depth image, invalid pixels counting as 0 (csrc/xs_tsdf.hip, k_scale_depth)."""
+    h, w = scaled.shape
+    ty, tx = -(-h // th), -(-w // tw)
+    out = np.zeros((ty, tx, 2), np.float32)
+    for j in range(ty):
+        for i in range(tx):
+            blk = scaled[j * th:(j + 1) * th, i * tw:(i + 1) * tw]
+            out[j, i] = (blk.min(), blk.max())
+    return out
+
+
+def holed(d, rng, n_holes=40, speckle=0.002):
+    """A depth frame with rectangular holes (0), out-of-range pixels and speckle."""
+    d = d.copy()
+    h, w = d.shape
+    for _ in range(n_holes):
+        y, x = rng.integers(0, h - 30), rng.integers(0, w - 40)
+        d[y:y + rng.integers(1, 30), x:x + rng.integers(1, 40)] = rng.choice([0, 150, 6000])
+    m = rng.random(d.shape) < speckle
+    d[m] = 0
+    return d
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (150, 200), (97, 131)])
+def test_depth_tile_table(dev, oracle, shape):
+    """xs_scale_depth_tiles: the scaled image and the frame maximum of xs_scale_depth_max, plus the per-tile depth range — against
+    numpy on whole, ragged and holed images; xs_depth_tiles builds the same table from the scaled image."""
+    torch, capi = dev
+    rng = np.random.default_rng(11)
+    h, w = shape
+    d = holed(synth.s1_frame(3)[:h, :w], rng)
+    d[0, 0] = 5000; d[h - 1, w - 1] = 200; d[5, 7] = 5001; d[6, 7] = 199
+    depth = torch.from_numpy(np.ascontiguousarray(d).astype(np.int16)).cuda()
+    scaled = torch.full((h, w), -1.0, dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    nb = capi.depth_tiles_bytes(h, w)
+    assert nb == (-(-h // 8) * -(-w // 8) + -(-h // 32) * -(-w // 64)) * 8     # 8 x 8 tiles, then 64 x 32 super tiles
+    tiles = torch.full((nb // 4,), -1.0, dtype=torch.float32, device="cuda")
+    capi.scale_depth_tiles(depth, w * 2, h, w, scaled, w * 4, dmax, tiles)
+    torch.cuda.synchronize()
+    ref = oracle.scale_depth(np.ascontiguousarray(d))
+    got = scaled.cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert float(dmax.item()) == float(ref.max())
+    want = np.concatenate([tiles_numpy(ref).reshape(-1, 2), tiles_numpy(ref, 64, 32).reshape(-1, 2)])
+    assert np.array_equal(tiles.cpu().numpy().reshape(-1, 2), want)
+    again = torch.full_like(tiles, -1.0)
+    capi.depth_tiles(scaled, w * 4, h, w, again)
+    torch.cuda.synchronize()
+    assert torch.equal(again, tiles)
+
+
+def class_counts(ws):
+    return [int(x) for x in ws[192:204].view(__import__("torch").int32).cpu().numpy()]
+
+
+@pytest.mark.parametrize("n,threshold", [(128, 0.0), (256, 0.02), (256, 0.0)])
+def test_brick_classification_is_invisible(dev, oracle, n, threshold):
+    """The kernel's own classification of each wave-sized box from the depth tiles (free space: tsdf = (1, 0) streamed without a
+    projection; nothing to write: skipped; else the per-voxel walk of TsdfFusion.cu:110-167) against XS_INTEGRATE_NO_TILES, which walks
+    every voxel: the same volume and count bit for bit over frames with holes, out-of-range pixels and speckle, a saturating weight,
+    the caller's tile table and the call's own, whole volume and slabs — and equal to the oracle.  The free and the skip class must
+    both have been taken."""
+    torch, capi = dev
+    prm = synth.s1_params(n, threshold=threshold)
+    res = [n, n, n]
+    Hh, Ww = synth.HEIGHT, synth.WIDTH
+    rng = np.random.default_rng(5)
+    frames = [0, 2, 2, 5, 7]
+    imgs = {k: holed(synth.s1_frame(k), rng, n_holes=25, speckle=0.0005 if n < 256 else 0.0) for k in sorted(set(frames))}
+    for k in imgs:
+        imgs[k][200:260, 300:420][rng.random((60, 120)) < 0.01] = 0      # speckle in one patch
+    k4, vs, trunc = intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm)
+
+    def run(flags, slabs=1, own_tiles=False):
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        scaled = torch.empty((Hh, Ww), dtype=torch.float32, device="cuda")
+        dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+        tiles = torch.zeros(capi.depth_tiles_bytes(Hh, Ww) // 4, dtype=torch.float32, device="cuda")
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        counts, classes = [], np.zeros(3, np.int64)
+        bounds = [n * i // slabs for i in range(slabs + 1)]
+        for k in frames:
+            depth = torch.from_numpy(imgs[k].astype(np.int16)).cuda()
+            dmax.zero_(); counter.zero_()
+            capi.scale_depth_tiles(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax, tiles)
+            T = s1_transforms(k, prm)
+            capi.integrate_set_depth_tiles(None if own_tiles else tiles)
+            try:
+                for s in range(slabs):
+                    z0, z1 = bounds[s], bounds[s + 1]
+                    ws = torch.zeros(capi.integrate_workspace_bytes(res, z1 - z0), dtype=torch.uint8, device="cuda")
+                    capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 3, res, vs, T["Rv2c"], T["tv2c"], trunc, v[z0 * n:], w[z0 * n:], g[z0 * n:], n * 4,
+                                             flags | 64, threshold=threshold, z0=z0, z1=z1, updated=counter, depth_max=dmax, workspace=ws)
+                    torch.cuda.synchronize()
+                    classes += class_counts(ws)
+            finally:
+                capi.integrate_set_depth_tiles(None)
+            counts.append(int(counter.item()))
+        return [t.cpu().numpy().reshape(-1) for t in (v, w, g)] + [counts], classes
+
+    exact, c0 = run(32)
+    assert c0.sum() == 0
+    for kw in (dict(), dict(own_tiles=True), dict(slabs=3)):
+        got, cls = run(0, **kw)
+        for a, b in zip(exact[:3], got[:3]):
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), kw
+        assert exact[3] == got[3], kw
+        assert (cls[0] > 20 or n < 256) and cls[1] > 0 and cls[2] > 20, (kw, cls)
+    cv, cw, cg = oracle.new_volume(res)
+    cc = []
+    for k in frames:
+        T = s1_transforms(k, prm)
+        cc.append(oracle.integrate(oracle.scale_depth(imgs[k]), cv, cw, cg, res, trunc, 3, T["Rv2c"], T["tv2c"], k4, vs, threshold))
+    compare(tuple(exact), (cv, cw, cg, cc))
+
+
+def test_brick_classification_adversarial_grazing_surfaces(dev):
+    """Surfaces that graze brick faces and tile borders: a staircase of planes whose depths sit within a few voxels of every brick
+    boundary along z, a one-pixel-wide pillar and a one-pixel hole inside otherwise free tiles, and the camera rotated so that the
+    boxes project onto slanted quadrilaterals.  Classified against exact, bit for bit, at several poses; all three classes taken."""
+    torch, capi = dev
+    n = 256
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    Hh, Ww = synth.HEIGHT, synth.WIDTH
+    k4, vs, trunc = intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm)
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:Hh, 0:Ww]
+    # depth staircase: 8 brick planes = 8 * vs metres per brick along z; steps land at brick faces -2 .. +2 voxels
+    step = ((xx // 37) + (yy // 29)) % 11
+    z_face = (np.floor((2.2 + 0.17 * step) / (8 * vs)) * 8 * vs)
+    d = z_face + vs * ((xx // 37) % 5 - 2) + trunc * 1.001 * (((yy // 29) % 3) - 1)
+    d = np.clip(np.round(d * 1000), 0, 65535).astype(np.uint16)
+    d[100:300:7, 50:250:11] = 900      # one-pixel pillars (nearer)
+    d[103:300:7, 53:250:11] = 0        # one-pixel holes
+    d[:, 320] = 4900                   # a one-pixel slit (farther)
+    depth = torch.from_numpy(d.astype(np.int16)).cuda()
+    scaled = torch.empty((Hh, Ww), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    capi.scale_depth_max(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax)
+    total = np.zeros(3, np.int64)
+    for trial in range(6):
+        ang = [0.0, 0.0, 0.3, -0.5, 0.8, 1.2][trial]
+        ax = np.array([[0, 0, 1.0], [0, 0, 1.0], [0, 1.0, 0], [1.0, 0, 0], [0.6, 0.8, 0], [0.5, 0.5, 0.7071]][trial])
+        ax = ax / np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        cam = np.array([prm["init_x"], prm["init_y"], prm["init_z"]]) + (rng.uniform(-0.3, 0.3, 3) if trial else 0.0)
+        R = np.zeros((3, 3, 2), np.float32); R[..., 0] = Rm.T; R[..., 1] = rng.normal(size=(3, 3)) * 1e-7
+        t = np.zeros((3, 2), np.float32); t[:, 0] = -Rm.T @ cam; t[:, 1] = rng.normal(size=3) * 1e-7
+        outs = []
+        for flags in (32, 0):
+            for threshold in (0.0, 0.05):
+                v = torch.zeros((n * n, n), dtype=torch.float32, device="cuda"); w = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
+                g = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+                ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+                counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+                for rep in range(2):
+                    capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, R, t, trunc, v, w, g, n * 4, flags | 64, threshold=threshold,
+                                             updated=counter, depth_max=dmax, workspace=ws)
+                torch.cuda.synchronize()
+                if flags == 0:
+                    total += class_counts(ws)
+                outs.append(([x.cpu().numpy().view(np.int32) for x in (v, w, g)], int(counter.item())))
+        for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+            for x, y in zip(a[0], b[0]):
+                assert np.array_equal(x, y), trial
+            assert a[1] == b[1] and a[1] > 1000, trial
+    assert total[0] > 20 and total[1] > 0 and total[2] > 100, total

@@ -53,6 +53,10 @@ _SIGS = {
     "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
     "xs_integrate_set_timing_events": (None, [_vp, _vp]),
     "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
+    "xs_scale_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "xs_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "xs_depth_tiles_bytes": (_sz, [C.c_int, C.c_int]),
+    "xs_integrate_set_depth_tiles": (None, [_vp]),
     "xs_tsdf_reduce_workspace_bytes": (_sz, []),
     "xs_compute_local_tsdf_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
                                                 _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -220,6 +224,24 @@ def integrate_tsdf_volume(depth, depth_step, rows, cols, intr, max_weight, res, 
 
 def scale_depth_max(depth, depth_step, rows, cols, scaled, scaled_step, max_dev, stream=None):
     check(_lib.xs_scale_depth_max(_ptr(depth), depth_step, rows, cols, _ptr(scaled), scaled_step, _ptr(max_dev), _stream(stream)))
+
+
+def depth_tiles_bytes(rows, cols):
+    return _lib.xs_depth_tiles_bytes(rows, cols)
+
+
+def scale_depth_tiles(depth, depth_step, rows, cols, scaled, scaled_step, max_dev, tiles, stream=None):
+    """scale_depth_max + the per-tile depth range table {lo, hi} per 8 x 8 pixels (depth_tiles_bytes(rows, cols) bytes)."""
+    check(_lib.xs_scale_depth_tiles(_ptr(depth), depth_step, rows, cols, _ptr(scaled), scaled_step, _ptr(max_dev), _ptr(tiles), _stream(stream)))
+
+
+def depth_tiles(scaled, scaled_step, rows, cols, tiles, stream=None):
+    check(_lib.xs_depth_tiles(_ptr(scaled), scaled_step, rows, cols, _ptr(tiles), _stream(stream)))
+
+
+def integrate_set_depth_tiles(tiles):
+    """The depth-tile table the following integrate calls classify their bricks with (None: each call builds its own)."""
+    _lib.xs_integrate_set_depth_tiles(_ptr(tiles))
 
 
 def integrate_scaled(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight,

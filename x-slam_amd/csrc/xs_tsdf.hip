@@ -66,42 +66,95 @@ extern "C" int xs_init_volume(float *value, int *weight, float *grad, size_t ste
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_scale_depth(const uint16_t *depth, size_t dstep, int rows, int cols, float *scaled, size_t sstep,
-                                                     unsigned *max_bits) {
-    // few, fat workgroups (grid-stride over pixels) so the optional maximum costs one atomic per
-    // workgroup instead of one per wave
-    const int n = rows * cols;
-    unsigned b = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int y = i / cols, x = i - y * cols;
-        const int Dp = row_ptr(depth, dstep, y)[x];
-        float r = 0.f;
-        if (!(Dp > 5000 || Dp < 200)) r = float(Dp) / 1000.f;  // metres
-        row_ptr(scaled, sstep, y)[x] = r;
-        b = max(b, __float_as_uint(r));  // non-negative floats order like their bit patterns
-    }
-    if (max_bits) {
-        __shared__ unsigned sm[4];
+// scaleDepthKernal (TsdfFusion.cu:68-82) + what the integrate kernel wants to know about the frame: its largest valid depth and the
+// smallest and the largest scaled depth per DEPTH_TILE x DEPTH_TILE pixel tile and per 64 x 32 pixel block of tiles ("super tile": what
+// one workgroup covers) — an invalid pixel counts as 0 in both: a tile with a hole has min 0.  A wave takes a strip of 64 pixels x
+// DEPTH_TILE rows — every row a coalesced 128-byte read and 256-byte write — lane l carries its column's min / max down the rows, three
+// cross-lane steps fold the eight columns of a tile, three more the eight tiles of the strip, and LDS the workgroup's four strips.
+enum { DEPTH_TILE = 8, SUPER_W = 64, SUPER_H = 4 * DEPTH_TILE };
+struct DepthTile { float lo, hi; };   // over the tile's pixels that lie in the image
+struct DepthTiles {                   // view of the table: tiles [ty][tx], then super tiles [sy][sx]
+    const DepthTile *tiles, *supers; int tiles_x, tiles_y, supers_x, supers_y;
+};
+static inline size_t depth_tiles_count(int rows, int cols) {
+    return (size_t)((cols + DEPTH_TILE - 1) / DEPTH_TILE) * ((rows + DEPTH_TILE - 1) / DEPTH_TILE) + (size_t)((cols + SUPER_W - 1) / SUPER_W) * ((rows + SUPER_H - 1) / SUPER_H);
+}
+static inline DepthTiles depth_tiles_view(const void *buf, int rows, int cols) {
+    DepthTiles t;
+    t.tiles_x = (cols + DEPTH_TILE - 1) / DEPTH_TILE; t.tiles_y = (rows + DEPTH_TILE - 1) / DEPTH_TILE;
+    t.supers_x = (cols + SUPER_W - 1) / SUPER_W; t.supers_y = (rows + SUPER_H - 1) / SUPER_H;
+    t.tiles = static_cast<const DepthTile *>(buf); t.supers = t.tiles ? t.tiles + (size_t)t.tiles_x * t.tiles_y : nullptr;
+    return t;
+}
+template <class Src> __device__ __forceinline__ float scaled_depth_of(Src v);
+template <> __device__ __forceinline__ float scaled_depth_of<uint16_t>(uint16_t v) {
+    const int Dp = v;
+    return (Dp > 5000 || Dp < 200) ? 0.f : float(Dp) / 1000.f;   // metres
+}
+template <> __device__ __forceinline__ float scaled_depth_of<float>(float v) { return v; }   // already scaled: tiles only
+// grid (ceil(cols / 64), ceil(rows / 32)), block 256: wave w of workgroup (bx, by) takes pixels [64 bx, +64) x rows [32 by + 8 w, +8)
+template <class Src>
+__global__ void __launch_bounds__(256) k_scale_depth(const Src *depth, size_t dstep, int rows, int cols, float *scaled, size_t sstep,
+                                                     unsigned *max_bits, DepthTile *tiles, int tiles_x, int tiles_y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, ty = blockIdx.y * 4 + wave;
+    float lo = __builtin_inff(), hi = 0.f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) b = max(b, (unsigned)__shfl_down((int)b, off, 64));
-        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = b;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            b = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-            if (b) atomicMax(max_bits, b);
+    for (int r = 0; r < DEPTH_TILE; ++r) {
+        const int y = ty * DEPTH_TILE + r;
+        if (x < cols && y < rows) {
+            const float v = scaled_depth_of<Src>(row_ptr(depth, dstep, y)[x]);
+            if (scaled) row_ptr(scaled, sstep, y)[x] = v;
+            lo = fminf(lo, v); hi = fmaxf(hi, v);
         }
     }
+    __shared__ float s_lo[4], s_hi[4];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        if (off == DEPTH_TILE / 2 && tiles && (lane & (DEPTH_TILE - 1)) == 0 && x < cols && ty < tiles_y)
+            tiles[ty * tiles_x + (x / DEPTH_TILE)] = DepthTile{lo, hi};
+    }
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])); hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+        if (tiles) tiles[(size_t)tiles_x * tiles_y + blockIdx.y * gridDim.x + blockIdx.x] = DepthTile{lo, hi};
+        const unsigned b = __float_as_uint(hi);  // non-negative floats order like their bit patterns
+        if (max_bits && b) atomicMax(max_bits, b);
+    }
+}
+template <class Src>
+static void launch_scale_depth(const Src *src, size_t src_step, int rows, int cols, float *scaled, size_t scaled_step, float *max_dev, void *tiles_dev, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale_depth<Src>, dim3(div_up(cols, SUPER_W), div_up(rows, SUPER_H)), dim3(256), 0, st, src, src_step, rows, cols, scaled, scaled_step,
+                       (unsigned *)max_dev, (DepthTile *)tiles_dev, div_up(cols, DEPTH_TILE), div_up(rows, DEPTH_TILE));
 }
 
 /* max_dev: optional device float that receives max(scaled) via atomicMax on its bits; the caller
- * zeroes it before the launch (used by integrate to stop walking behind the farthest surface) */
-extern "C" int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
-                                  float *max_dev, void *stream) {
+ * zeroes it before the launch (used by integrate to stop walking behind the farthest surface).
+ * tiles_dev: optional table of xs_depth_tiles_bytes(rows, cols) bytes that receives the per-tile depth range
+ * (xs_integrate_set_depth_tiles hands it to the integrate calls). */
+extern "C" size_t xs_depth_tiles_bytes(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return depth_tiles_count(rows, cols) * sizeof(DepthTile);
+}
+extern "C" int xs_scale_depth_tiles(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
+                                    float *max_dev, void *tiles_dev, void *stream) {
     if (!depth || !scaled) return xs_set_error(hipErrorInvalidValue, "xs_scale_depth: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
-    int blocks = div_up(rows * cols, 256 * 4);
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(k_scale_depth, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, depth_step, rows, cols, scaled, scaled_step, (unsigned *)max_dev);
+    launch_scale_depth(depth, depth_step, rows, cols, scaled, scaled_step, max_dev, tiles_dev, (hipStream_t)stream);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+extern "C" int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
+                                  float *max_dev, void *stream) {
+    return xs_scale_depth_tiles(depth, depth_step, rows, cols, scaled, scaled_step, max_dev, nullptr, stream);
+}
+/* the tile table of an image that is already scaled (what xs_integrate_scaled does itself when nobody handed it one) */
+extern "C" int xs_depth_tiles(const float *scaled, size_t scaled_step, int rows, int cols, void *tiles_dev, void *stream) {
+    if (!scaled || !tiles_dev) return xs_set_error(hipErrorInvalidValue, "xs_depth_tiles: null pointer");
+    if (rows <= 0 || cols <= 0) return 0;
+    launch_scale_depth(scaled, scaled_step, rows, cols, (float *)nullptr, (size_t)0, (float *)nullptr, tiles_dev, (hipStream_t)stream);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -160,8 +213,11 @@ struct IntegrateArgs {
     const unsigned *mailbox; unsigned mailbox_seq;   // posted pose: what k_pose_gate polls ...
     unsigned *pose_dev;                              // ... and where it leaves {cmd, 24 floats} for k_integrate_bricks<., ., true>
     unsigned char *signmap;       // xs_signmap.h buffer (whole-volume launches) or null: bricks that receive a negative value are marked
+    DepthTiles dt;                // per-tile depth range of the frame (k_scale_depth), for k_classify_boxes
+    unsigned char *box_class;     // [list entry][BOXES_PER_BRICK] BOX_* (k_classify_boxes) or null: every box takes the exact walk
 };
-enum { KF_ALWAYS_STORE = 1u };    // write every updated voxel's three words even where the bits do not change (measurement aid)
+enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u };  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
+enum { CLASS_COUNT_WORD = 48 };    // write every updated voxel's three words even where the bits do not change (measurement aid)
 
 namespace {
 // device side of the frustum: add the far limit (see struct Frustum).  Behind the farthest
@@ -348,7 +404,7 @@ __device__ __forceinline__ bool voxel_tsdf(const IntegrateArgs &a, const VoxelCt
     }
     return true;
 }
-__device__ __forceinline__ void running_mean(const IntegrateArgs &a, cfloat tsdf, float pre_v, float pre_g, int pre_w, float &out_v,
+__device__ __forceinline__ void running_mean(int max_weight, cfloat tsdf, float pre_v, float pre_g, int pre_w, float &out_v,
                                              float &out_g, int &out_w) {
     const cfloat tsdf_prev = unpack_tsdf(pre_v, pre_g);
     const cfloat num = tsdf_prev * __int2float_rn(pre_w) + 1.0f * tsdf;
@@ -359,7 +415,7 @@ __device__ __forceinline__ void running_mean(const IntegrateArgs &a, cfloat tsdf
         if (div_v) out_v = num.re / den;
         if (div_g) out_g = num.im / den;
     }
-    out_w = min(pre_w + 1, a.max_weight);
+    out_w = min(pre_w + 1, max_weight);
 }
 template <bool BILINEAR>
 __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, int z, float pre_v, float pre_g, int pre_w,
@@ -455,6 +511,118 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
     return n_upd;
 }
 
+
+// ---- what a brick is, before any of its voxels is touched ----------------------------------------------------------------------
+// The reference evaluates every voxel (TsdfFusion.cu:110-167); most written voxels of a frame lie in free space well in front of the
+// surface, where the result is known beforehand: tsdf = (1, 0) and the running mean.  k_classify_boxes decides that for each wave-sized
+// box of every listed brick (WX columns x WY rows x the brick's planes: what one wave of k_integrate_bricks walks) from the box's eight
+// corners and the frame's per-tile depth range:
+//   FREE   every voxel passes the in-image test (:123-124) and sees a valid depth farther than its own c by more than the truncation
+//          band (+ margin): each is written with tsdf = (1, 0) (:150-159) — no projection, no divide, no gather: a streaming update;
+//   EMPTY  every voxel projects outside the image, or onto depths nearer than its own c by more than the band (or invalid): none is
+//          written (:123-124, :150) — the box is skipped;
+//   MIXED  anything else: the exact walk.
+// Conservative by construction: the box's projections lie in the hull of its corners' (c > 0 over the box), the pixel range is padded
+// by 1.5 px (the exact path's nearest / bilinear picks reach at most half a pixel past a projection; the rest covers the float
+// difference between this projection and the exact one, ~1e-3 px), depths by 2e-4 m (~50x the float error of c at 8 m).
+// A class byte holds for every pose whose camera-frame coordinates differ from the classified pose's by at most (dX, dY, dC) anywhere
+// in the volume (BoxSlack; zero for a launch classified with its own pose): the pads grow by what such a pose can move a projection
+// and a depth, and the host accepts a list for another pose only after checking exactly that (xs_integrate_list_covers).
+enum { BOX_MIXED = 0, BOX_FREE = 1, BOX_EMPTY = 2, BOX_MAX_TILES = 128, FREE_CHUNK = 4 };
+enum { BOX_WX = BRICK_X < 64 ? BRICK_X : 64, BOX_WY = 64 / BOX_WX, BOXES_PER_BRICK = 4 };   // a wave's part of a brick
+struct BoxSlack { float dX, dY, dC; };
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }    // quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }    // quad_perm [2, 3, 0, 1]
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)); }   // lane i <- 7 - i of its 8
+__device__ __forceinline__ float dpp_row_mirror(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)); }    // lane i <- 15 - i of its 16
+template <bool MAX> __device__ __forceinline__ float pick(float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); }
+template <bool MAX> __device__ __forceinline__ float fold8(float v) {   // over each group of eight lanes, result in all of them
+    v = pick<MAX>(v, dpp_xor1(v)); v = pick<MAX>(v, dpp_xor2(v)); return pick<MAX>(v, dpp_half_mirror(v));
+}
+template <bool MAX> __device__ __forceinline__ float fold64(float v) {  // over the wave, result wave-uniform
+    v = fold8<MAX>(v); v = pick<MAX>(v, dpp_row_mirror(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return pick<MAX>(pick<MAX>(r0, r1), pick<MAX>(r2, r3));
+}
+// box = voxel indices [x0, x1) x [y0, y1) x [z0, z1), not empty.  Eight lanes per box (a wave classifies eight boxes at once): lane
+// c of the group evaluates corner c, three cross-lane steps fold the group, and the group's lanes share the tile reads; every lane of a
+// group returns the group's class.
+__device__ __forceinline__ int classify_box(const IntegrateArgs &a, const BoxSlack &sl, int x0, int x1, int y0, int y1, int z0, int z1, int corner) {
+    // voxel centres, in the exact path's own units: (index + 0.5) * voxel_size
+    const float vx = (((corner & 1) ? x1 - 1 : x0) + 0.5f) * a.voxel_size;
+    const float vy = (((corner & 2) ? y1 - 1 : y0) + 0.5f) * a.voxel_size;
+    const float vz = (((corner & 4) ? z1 - 1 : z0) + 0.5f) * a.voxel_size;
+    const float X = ((a.R.data[0].x.re * vx + a.R.data[0].y.re * vy) + a.R.data[0].z.re * vz) + a.t.x.re;
+    const float Y = ((a.R.data[1].x.re * vx + a.R.data[1].y.re * vy) + a.R.data[1].z.re * vz) + a.t.y.re;
+    const float c = ((a.R.data[2].x.re * vx + a.R.data[2].y.re * vy) + a.R.data[2].z.re * vz) + a.t.z.re;
+    const float cmin = fold8<false>(c) - sl.dC, cmax = fold8<true>(c) + sl.dC;
+    if (!(cmin > 1e-3f)) return BOX_MIXED;           // the camera plane cuts the box (or nearly): no hull argument
+    const float rc = __builtin_amdgcn_rcpf(c);
+    const float un = X * rc, vn = Y * rc;            // normalised image coordinates of the corner
+    const float u = a.intr.fx * un + a.intr.cx, v = a.intr.fy * vn + a.intr.cy;
+    // what a pose within the slack can move a projection by: |d(X/c)| <= (dX + |X/c| dC) / (c - dC)
+    const float rcm = __builtin_amdgcn_rcpf(cmin);
+    const float pad_u = 1.5f + fabsf(a.intr.fx) * (sl.dX + fold8<true>(fabsf(un)) * sl.dC) * rcm * 1.01f;
+    const float pad_v = 1.5f + fabsf(a.intr.fy) * (sl.dY + fold8<true>(fabsf(vn)) * sl.dC) * rcm * 1.01f;
+    const float ulo = fold8<false>(u) - pad_u, uhi = fold8<true>(u) + pad_u, vlo = fold8<false>(v) - pad_v, vhi = fold8<true>(v) + pad_v;
+    if (!(ulo > -1e6f && uhi < 1e6f && vlo > -1e6f && vhi < 1e6f)) return BOX_MIXED;   // (NaN / overflow: take the exact walk)
+    const int px0 = __float2int_rd(ulo), px1 = __float2int_ru(uhi), py0 = __float2int_rd(vlo), py1 = __float2int_ru(vhi);
+    const bool inside = px0 >= 2 && py0 >= 2 && px1 <= a.dcols - 2 && py1 <= a.drows - 2;
+    // the part of the pixel range that lies in the image (what is outside is never written)
+    const int qx0 = max(px0, 0), qx1 = min(px1, a.dcols - 1), qy0 = max(py0, 0), qy1 = min(py1, a.drows - 1);
+    if (qx0 > qx1 || qy0 > qy1) return BOX_EMPTY;
+    // the depth range over the pixel range: from the tiles, or — a box near the camera covers hundreds of them — from the super tiles
+    int tx0 = qx0 / DEPTH_TILE, tx1 = qx1 / DEPTH_TILE, ty0 = qy0 / DEPTH_TILE, ty1 = qy1 / DEPTH_TILE, pitch = a.dt.tiles_x;
+    const DepthTile *table = a.dt.tiles;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > BOX_MAX_TILES) {
+        tx0 = qx0 / SUPER_W; tx1 = qx1 / SUPER_W; ty0 = qy0 / SUPER_H; ty1 = qy1 / SUPER_H; pitch = a.dt.supers_x; table = a.dt.supers;
+        if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4 * BOX_MAX_TILES) return BOX_MIXED;
+    }
+    float lo = __builtin_inff(), hi = 0.f;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0 + corner; tx <= tx1; tx += 8) {
+            const DepthTile t = table[ty * pitch + tx];
+            lo = fminf(lo, t.lo); hi = fmaxf(hi, t.hi);
+        }
+    lo = fold8<false>(lo); hi = fold8<true>(hi);
+    const float band = (a.tranc_dist * 1.001f + 1e-5f) + 2e-4f;   // the walk's own band (update_voxel) + margin
+    if (cmin - hi > band) return BOX_EMPTY;          // behind everything the box can see (hi = 0: nothing valid there)
+    if (inside && lo - cmax > band) return BOX_FREE;  // (lo = 0 where a pixel is invalid)
+    return BOX_MIXED;
+}
+// FREE box: voxels (x, y, zb .. ze - 1) of this lane's column (which lies in the volume), FREE_CHUNK planes' state requested before the
+// first is used.  Addressed like the OFF32 walk: wave-uniform array bases + one 32-bit byte offset per lane and plane, shared by the
+// three arrays.  off: the column's first voxel (plane zb); plane: bytes between planes.
+template <bool SIGN>
+__device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int x, int y, int zb, int ze) {
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    float vmin = 0.0f;
+#pragma unroll 1
+    for (int z0 = zb; z0 < ze; z0 += FREE_CHUNK, off += FREE_CHUNK * plane) {
+        float v0[FREE_CHUNK], g0[FREE_CHUNK]; int w0[FREE_CHUNK];
+#pragma unroll
+        for (int j = 0; j < FREE_CHUNK; ++j)
+            if (z0 + j < ze) {
+                v0[j] = *reinterpret_cast<const float *>(bv + (off + j * plane));
+                g0[j] = *reinterpret_cast<const float *>(bg + (off + j * plane));
+                w0[j] = *reinterpret_cast<const int *>(bw + (off + j * plane));
+            }
+#pragma unroll
+        for (int j = 0; j < FREE_CHUNK; ++j)
+            if (z0 + j < ze) {
+                float ov, og; int ow;
+                running_mean(a.max_weight, cfloat(1.0f, 0.0f), v0[j], g0[j], w0[j], ov, og, ow);
+                if ((__float_as_uint(ov) ^ __float_as_uint(v0[j])) | always) *reinterpret_cast<float *>(bv + (off + j * plane)) = ov;
+                if ((unsigned)(ow ^ w0[j]) | always) *reinterpret_cast<int *>(bw + (off + j * plane)) = ow;
+                if ((__float_as_uint(og) ^ __float_as_uint(g0[j])) | always) *reinterpret_cast<float *>(bg + (off + j * plane)) = og;
+                if (SIGN) vmin = fminf(vmin, ov);
+            }
+    }
+    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
+    return (unsigned)(ze - zb);
+}
+
 }  // namespace
 
 // One atomic per workgroup (a same-address atomic costs ~12 ns on this chip: one per wave of a
@@ -532,6 +700,26 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     }
 }
 
+// The class of every box of every listed brick (see classify_box): eight lanes per box, 32 boxes = 8 bricks per workgroup and trip.
+__global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl) {
+    const unsigned count = *a.brick_count;
+    const int tid = (int)threadIdx.x, corner = tid & 7, box = (tid >> 3) & (BOXES_PER_BRICK - 1), slot = tid >> 5;
+    for (unsigned e0 = blockIdx.x * 8u; e0 < count; e0 += gridDim.x * 8u) {
+        const unsigned e = e0 + slot;
+        if (e >= count) continue;    // (whole groups of eight lanes: the cross-lane steps stay inside a group)
+        const int b = a.brick_list[e];
+        const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
+        const int wx0 = bx * BRICK_X + (box * 64) % BRICK_X, wy0 = by * BRICK_Y + (box * 64) / BRICK_X;
+        const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
+        int cls = BOX_EMPTY;   // a wave without a column of the brick in the volume
+        if (wx0 < a.X && wy0 < a.Y) cls = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
+        if (corner == 0) {
+            a.box_class[e * BOXES_PER_BRICK + box] = (unsigned char)cls;
+            if (a.kflags & KF_COUNT_CLASSES) atomicAdd(a.brick_count + CLASS_COUNT_WORD + (cls == BOX_FREE ? 0 : cls == BOX_EMPTY ? 1 : 2), 1u);
+        }
+    }
+}
+
 // One wave waits at the mailbox for the pose of a posted integrate launch and leaves it in device memory for the launch behind it on the
 // stream: a single poller (two thousand workgroups polling one line themselves serialise at the memory side: measured, 87 us instead of 27).
 __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsigned seq, unsigned *pose_dev) {
@@ -583,6 +771,22 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
         const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
         const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
+        if constexpr (OFF32) {
+            if (a.box_class) {   // what k_classify_boxes found for this wave's part of the brick
+                const int cls = __builtin_amdgcn_readfirstlane((int)a.box_class[e * BOXES_PER_BRICK + threadIdx.y]);
+                if (cls == BOX_EMPTY) continue;
+                if (cls == BOX_FREE) {
+                    if (x < a.X && y < a.Y) {
+                        const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
+                        const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
+                        n_upd += integrate_free_column<SIGN>(a, reinterpret_cast<char *>(a.value) + ubase, reinterpret_cast<char *>(a.weight) + ubase,
+                                                             reinterpret_cast<char *>(a.grad) + ubase, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u,
+                                                             (unsigned)a.Y * (unsigned)a.vstep, x, y, zb0, ze0);
+                    }
+                    continue;
+                }
+            }
+        }
         if (x < a.X && y < a.Y) {
             const int zb0 = a.z0 + bz * a.brick_z;
             int zb = zb0, ze = min(zb + a.brick_z, a.z1);
@@ -718,7 +922,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks_ring(const Integrat
             if (wr) {
                 const unsigned v0 = s_ring[wave][slot][0][lane], g0 = s_ring[wave][slot][1][lane], w0 = s_ring[wave][slot][2][lane];
                 float ov, og; int ow;
-                running_mean(a, tsdf, __uint_as_float(v0), __uint_as_float(g0), (int)w0, ov, og, ow);
+                running_mean(a.max_weight, tsdf, __uint_as_float(v0), __uint_as_float(g0), (int)w0, ov, og, ow);
                 char *qv = const_cast<char *>(pv) + j * plane_bytes, *qg = const_cast<char *>(pg) + j * plane_bytes, *qw = const_cast<char *>(pw) + j * plane_bytes;
                 if ((__float_as_uint(ov) ^ v0) | always) *reinterpret_cast<float *>(qv + lane_off) = ov;
                 if (((unsigned)ow ^ w0) | always) *reinterpret_cast<int *>(qw + lane_off) = ow;
@@ -809,11 +1013,22 @@ extern "C" void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mail
 // the sign map (xs_signmap.h) the following launches of this thread mark; null = none
 static thread_local unsigned char *g_signmap = nullptr;
 extern "C" void xs_integrate_set_signmap(void *signmap) { g_signmap = static_cast<unsigned char *>(signmap); }
+// the frame's depth-tile table (xs_scale_depth_tiles) for the following launches of this thread; null = the call builds its own from the
+// scaled image, in its workspace
+static thread_local const DepthTile *g_depth_tiles = nullptr;
+extern "C" void xs_integrate_set_depth_tiles(const void *tiles) { g_depth_tiles = static_cast<const DepthTile *>(tiles); }
+enum { TILE_ROOM_BYTES = 1 << 20 };   // the workspace's own tile table: images of up to 131 072 tiles (e.g. 4096 x 2048 pixels); larger ones take the exact walk everywhere
+// workspace: 256-byte header | brick list (int per brick) | box classes (BOXES_PER_BRICK bytes per list entry) | the call's own depth tiles
+static size_t workspace_bricks(const int *res, int nz) { return (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2); }   // room for 2-plane bricks
+static size_t workspace_list_bytes(const int *res, int nz) { return (256 + workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255; }
+static size_t workspace_class_bytes(const int *res, int nz) { return (workspace_bricks(res, nz) * BOXES_PER_BRICK + 255) & ~(size_t)255; }
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
-    const size_t nb = (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2);  // room for 2-plane bricks
-    return 256 + nb * sizeof(int);
+    return workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz) + TILE_ROOM_BYTES;
 }
+// the workspace whose box classes xs_integrate_classify has written on this thread's behalf (for the xs_integrate_scaled_ex call with
+// XS_INTEGRATE_LIST_IS_READY that follows), and the slack they were classified with
+static thread_local const void *g_classes_of = nullptr;
 
 /* The two tiny launches xs_integrate_scaled wraps around its kernels, for a caller that takes them off its critical path
  * (xs_integrate_scaled_ex with XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD): the clear of the workspace's 256-byte
@@ -829,6 +1044,41 @@ extern "C" int xs_integrate_fold_counts(void *workspace, unsigned long long *upd
     hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long *>(workspace) + 1, updated_dev);
     XS_CHECK(hipGetLastError());
     return 0;
+}
+// What a pose covered by a list classified with slack_scale may differ by from the list's pose, in camera-frame metres anywhere in the
+// volume: a tenth of the frustum planes' extra slack (2e-3 of the coordinate magnitudes per unit of slack_scale; 2.2 mm per axis for
+// the benchmark volume at slack 2 — a last ICP update is well inside, and the classes' pads stay small: ~3 px at 1 m, 2 mm of depth).
+// xs_integrate_list_covers checks a pose against exactly these.
+static BoxSlack box_slack(const IntegrateArgs &a, float slack_scale) {
+    const float vs = a.voxel_size, ext = (float)std::max(a.X, std::max(a.Y, a.Z));
+    auto mag = [&](const cfloat3 &row, float t) { return fabsf(t) + (fabsf(row.x.re) + fabsf(row.y.re) + fabsf(row.z.re)) * vs * ext; };
+    const float k = 0.1f * 2e-3f * (slack_scale - 1.0f);
+    BoxSlack sl;
+    sl.dX = k * mag(a.R.data[0], a.t.x.re); sl.dY = k * mag(a.R.data[1], a.t.y.re); sl.dC = k * mag(a.R.data[2], a.t.z.re);
+    return sl;
+}
+// largest camera-frame coordinate difference between two poses over the volume's voxels, per axis
+static void pose_delta(const IntegrateArgs &l, const IntegrateArgs &f, const int *res, double d[3]) {
+    const cfloat3 *lr = l.R.data, *fr = f.R.data;
+    const float lt[3] = {l.t.x.re, l.t.y.re, l.t.z.re}, ft[3] = {f.t.x.re, f.t.y.re, f.t.z.re};
+    for (int r = 0; r < 3; ++r)
+        d[r] = fabs((double)lt[r] - ft[r]) + (fabs((double)lr[r].x.re - fr[r].x.re) * res[0] + fabs((double)lr[r].y.re - fr[r].y.re) * res[1] +
+                                               fabs((double)lr[r].z.re - fr[r].z.re) * res[2]) * (double)l.voxel_size;
+}
+static bool box_slack_covers(const IntegrateArgs &l, const IntegrateArgs &f, const int *res, float slack_scale) {
+    const BoxSlack sl = box_slack(l, slack_scale);
+    double d[3];
+    pose_delta(l, f, res, d);
+    return d[0] <= 0.9 * sl.dX && d[1] <= 0.9 * sl.dY && d[2] <= 0.9 * sl.dC;   // (a tenth left for the float evaluation on the device)
+}
+// k_classify_boxes behind the brick classification, if a tile table is there and the class array fits; true = a.box_class is being written
+static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st) {
+    if (!tiles) return false;
+    a.dt = depth_tiles_view(tiles, a.drows, a.dcols);
+    a.box_class = reinterpret_cast<unsigned char *>((char *)workspace + workspace_list_bytes(res, nz));
+    const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
+    hipLaunchKernelGGL(k_classify_boxes, dim3(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048), dim3(256), 0, st, a, sl);
+    return true;
 }
 // the pose-dependent part of the arguments the classification needs (what xs_integrate_scaled_ex sets up for it)
 static void classify_args(IntegrateArgs &a, int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18,
@@ -868,6 +1118,16 @@ extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, con
     if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
     hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+    // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
+    // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
+    static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;
+    g_classes_of = nullptr;
+    const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
+    if (!env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32) {
+        if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
+        a.tranc_dist = tranc_dist;
+        if (launch_box_classes(a, res, z1 - z0, workspace, g_depth_tiles, box_slack(a, slack_scale), st)) g_classes_of = workspace;
+    }
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -888,7 +1148,7 @@ extern "C" int xs_integrate_list_covers(int rows, int cols, const float *intr4, 
         const double room = 1.5 * ((double)slack_scale * l.fr.slack[p] - f.fr.slack[p]);
         if (!(d <= 0.9 * room)) return 0;   // (a tenth of the room left for the kernel's float evaluation of the forms)
     }
-    return 1;
+    return box_slack_covers(l, f, res, slack_scale) ? 1 : 0;   // the boxes' classes hold for the pose too
 }
 /* Host only: the stricter cover test a POSTED integrate launch needs — it keeps the list pose's widened planes for its column clip too, where
  * a voxel is kept when alpha + b . index >= -slack (the brick test of xs_integrate_list_covers allows 1.5 slack): 1 if every half-space of
@@ -905,7 +1165,7 @@ extern "C" int xs_integrate_pose_covered(int rows, int cols, const float *intr4,
         const double room = (double)slack_scale * l.fr.slack[p] - f.fr.slack[p];
         if (!(d <= 0.8 * room)) return 0;   // (a fifth of the room left for the float evaluation of the forms and of the roots the clip solves them for)
     }
-    return 1;
+    return box_slack_covers(l, f, res, slack_scale) ? 1 : 0;
 }
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
@@ -941,8 +1201,10 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     a.brick_list = nullptr; a.brick_count = nullptr; a.kflags = 0;
     static const bool env_always = getenv("XS_INTEGRATE_ALWAYS_STORE") != nullptr;   // measurement aid, as the flag
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
+    if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
+    a.dt = depth_tiles_view(nullptr, rows, cols); a.box_class = nullptr;
     a.signmap = g_signmap;   // (a slab launch marks the bricks of its own planes: the map is indexed by whole-volume coordinates)
     if (posted) {
         if (!workspace || !(flags & XS_INTEGRATE_LIST_IS_READY) || !g_post_mailbox || !g_post_pose_dev)
@@ -978,6 +1240,24 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel; "off64" = 64-bit pointers per lane
         const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
         const bool sign = a.signmap != nullptr;
+        // the boxes' classes (free space / nothing to write / exact walk): those xs_integrate_classify left for this list, or classified
+        // here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here, in the workspace
+        static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;   // A/B aid, as the flag
+        const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace;
+        g_classes_of = nullptr;
+        if (off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES)) {
+            if (classes_ahead)
+                a.box_class = reinterpret_cast<unsigned char *>((char *)workspace + workspace_list_bytes(res, nz));
+            else if (!posted) {   // (a posted launch has no pose yet to classify with)
+                const DepthTile *tiles = g_depth_tiles;
+                if (!tiles && xs_depth_tiles_bytes(rows, cols) <= TILE_ROOM_BYTES) {
+                    DepthTile *own = reinterpret_cast<DepthTile *>((char *)workspace + workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz));
+                    launch_scale_depth(depth_scaled, scaled_step, rows, cols, (float *)nullptr, (size_t)0, (float *)nullptr, own, st);
+                    tiles = own;
+                }
+                launch_box_classes(a, res, nz, workspace, tiles, BoxSlack{0.f, 0.f, 0.f}, st);
+            }
+        }
         void (*kern)(const IntegrateArgs) =
             sign ? (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true, false, true> : k_integrate_bricks<true, false, false, true>)
                                      : (off32 ? k_integrate_bricks<false, true, false, true> : k_integrate_bricks<false, false, false, true>))

@@ -193,6 +193,7 @@ void KinectFusionReconstruction::AllocateBuffers() {
     counters_.create(2 * COUNTER_RING);
     hipSafeCall(hipMemsetAsync(counters_.ptr(), 0, 2 * COUNTER_RING * sizeof(unsigned long long), current_stream()));
     depth_max_.create(4);
+    depth_tiles_.create(xs_depth_tiles_bytes(depth_height, depth_width));
 }
 
 // reference :108-123
@@ -630,9 +631,11 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
     // the scaled depth's maximum and the cleared header come from the auxiliary stream
     if (scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
+    xs_integrate_set_depth_tiles(depth_tiles_.ptr());   // the boxes' classes are decided here too, with the slack's pads (xs_integrate_list_covers checks the final pose against them)
     check_rc(xs_integrate_classify(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
                                    tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
                                    integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
+    xs_integrate_set_depth_tiles(nullptr);
     list_ready_ = true;
     EnqueuePostedIntegrate();
 }
@@ -669,6 +672,7 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     posted_seq_ = integrate_mail_seq_;
     xs_integrate_set_pose_mailbox(integrate_mailbox_, posted_seq_, integrate_classify_slack, posted_pose_.ptr());
     xs_integrate_set_signmap(sign_map_ptr());
+    xs_integrate_set_depth_tiles(depth_tiles_.ptr());
     const bool split = integrate_header_clear_;   // header cleared and count folded on the auxiliary stream (SurfaceMeasure)
     check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_height, depth_width, &kinect_intrinsic.fx, max_integration_weight,
                                     res, voxel_size, list_Rv2c_, list_tv2c_, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), weight.ptr(0), grad.ptr(0),
@@ -678,6 +682,7 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     xs_integrate_set_timing_events(nullptr, nullptr);
     xs_integrate_set_pose_mailbox(nullptr, 0, 1.0f, nullptr);
     xs_integrate_set_signmap(nullptr);
+    xs_integrate_set_depth_tiles(nullptr);
     posted_pending_ = true;
     posted_stop_ = integrate_stop;
     posted_split_ = split;
@@ -774,6 +779,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
         xs_integrate_set_timing_events(nullptr, integrate_stop);
     if (!integrated_by_post) {
         xs_integrate_set_signmap(sign_map_ptr());   // (a rank of a sharded volume: the owned planes and both halo bands mark it)
+        xs_integrate_set_depth_tiles(depth_tiles_.ptr());
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
         const int zr[3][2] = {{zo0, zo1}, {zs0, zo0}, {zo1, zs1}};
@@ -804,6 +810,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);
         }
         xs_integrate_set_signmap(nullptr);
+        xs_integrate_set_depth_tiles(nullptr);
     }
 
     if (integrate_split()) integrate_done_now_ = integrate_stop;          // attached to the dispatch above
@@ -871,6 +878,7 @@ void KinectFusionReconstruction::EnqueueAnnouncedFrame(bool all) {
             if (vmaps_curr_d.size() != vmaps_next_d.size()) { vmaps_curr_d.resize(vmaps_next_d.size()); nmaps_curr_d.resize(nmaps_next_d.size()); }
             if (depthRawScaled_d.rows() != depth_height || depthRawScaled_d.cols() != depth_width) depthRawScaled_d.create(depth_height, depth_width);
             if (!depth_max_.ptr()) depth_max_.create(4);
+            if (!depth_tiles_.ptr()) depth_tiles_.create(xs_depth_tiles_bytes(depth_height, depth_width));
             // ... not before the previous frame's raycast and pyramid are through (the main stream's ICP launches start there): the event rides
             // on that pyramid's dispatch, the wait is a packet of this stream only
             if (tail_recorded_ && hipEventQuery(tail_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(aux_stream_, tail_done_, 0));
@@ -942,8 +950,9 @@ void KinectFusionReconstruction::EnqueueMapsFromPyramid() {
 // scaleDepthKernal of integrateTsdfVolume (TsdfFusion.cu:182-187) into the current set, on the auxiliary stream
 void KinectFusionReconstruction::EnqueueScale(const DeviceArray2D<ushort> &depth_frame_d) {
     hipSafeCall(hipMemsetAsync(depth_max_.ptr(), 0, sizeof(float), aux_stream_));
-    check_rc(xs_scale_depth_max(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
-                                depthRawScaled_d.step(), depth_max_.ptr(), aux_stream_), "scaleDepth");
+    // (+ the per-tile depth range the integrate call classifies its bricks with: free space / nothing to write / per-voxel walk)
+    check_rc(xs_scale_depth_tiles(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                                  depthRawScaled_d.step(), depth_max_.ptr(), depth_tiles_.ptr(), aux_stream_), "scaleDepth");
     hipSafeCall(hipEventRecord(scale_done_, aux_stream_));
     scale_recorded_ = true;
 }
@@ -958,6 +967,7 @@ void KinectFusionReconstruction::SwapMapSets() {
     std::swap(nreal_curr_d, nreal_next_d);
     std::swap(depthRawScaled_d, depthRawScaled_next_d);
     std::swap(depth_max_, depth_max_next_);
+    std::swap(depth_tiles_, depth_tiles_next_);
     std::swap(surface_done_, surface_done_next_);
     std::swap(scale_done_, scale_done_next_);
     std::swap(real_maps_valid_, real_maps_valid_next_);

@@ -239,6 +239,7 @@ private:
     std::vector<DeviceArray2D<float>> vreal_next_d, nreal_next_d;
     DeviceArray2D<float> depthRawScaled_next_d;
     DeviceArray<float> depth_max_next_;
+    DeviceArray<unsigned char> depth_tiles_, depth_tiles_next_;   // per-tile depth range of the frame (xs_scale_depth_tiles -> the integrate call's brick classes)
     hipEvent_t surface_done_next_ = nullptr, scale_done_next_ = nullptr;
     bool real_maps_valid_next_ = false, scale_recorded_next_ = false;
     const void *next_hint_ptr_ = nullptr, *next_ready_ptr_ = nullptr;
