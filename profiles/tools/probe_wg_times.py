@@ -1,0 +1,53 @@
+"""GPU box, repository root, library built with -DXS_PROBE_WG_TIMES: when every workgroup of the S1 integrate kernel begins and ends
+(100 MHz wall clock), by the class of its box.  python profiles/tools/probe_wg_times.py"""
+import importlib, sys
+sys.path.insert(0, '.')
+import numpy as np, torch
+capi = importlib.import_module('x-slam_amd.capi'); synth = importlib.import_module('x-slam_amd.synth')
+H, W, n = synth.HEIGHT, synth.WIDTH, 512
+prm = synth.s1_params(n); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel_size"])); trunc = synth.tranc_dist(prm)
+value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+capi.init_volume(value, weight, grad, n * 4, res)
+scaled = torch.empty((H, W), dtype=torch.float32, device="cuda"); dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+nws = capi.integrate_workspace_bytes(res)
+ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
+intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
+s = torch.cuda.current_stream()
+nb = 16 * 64 * 64
+list_bytes = (256 + nb * 4 * 4 + 255) // 256 * 256          # workspace_list_bytes: bricks of 2 planes -> 4x the 8-plane count
+class_bytes = (nb * 4 * 4 + 255) // 256 * 256
+off = list_bytes + class_bytes + (1 << 18)
+for k in range(12):
+    depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
+    capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+    T = synth.s1_transforms(k, prm)
+    capi.integrate_scaled(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, depth_max=dmax, workspace=ws, stream=s)
+    torch.cuda.synchronize()
+count = int(ws[:4].view(torch.int32).item())
+rec = ws[off:off + 8192 * 4 * 16].view(torch.int32).cpu().numpy().astype(np.int64).reshape(8192, 4, 4) & 0xffffffff
+t0 = rec[..., 0].min()
+b = (rec[..., 0] - t0) * 0.01; e = (rec[..., 1] - t0) * 0.01
+print(f"bricks {count}; workgroups 8192; kernel span {e.max():.2f} us; last workgroup begins at {b.max():.2f} us")
+work = rec[:count]
+for cls, name in ((1, "free"), (2, "nothing to write"), (0, "per-voxel walk")):
+    m = work[..., 2] == cls
+    if m.any():
+        d = (work[..., 1] - work[..., 0])[m] * 0.01
+        print(f"{name:18s} waves {m.sum():5d}  begin {b[:count][m].mean():6.2f} us (max {b[:count][m].max():6.2f})  duration mean {d.mean():6.2f}  p50 {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}  end max {e[:count][m].max():6.2f}")
+idle = rec[count:]
+print(f"workgroups without a brick: {len(idle)}  begin mean {((idle[..., 0] - t0) * 0.01).mean():.2f}  last end {((idle[..., 1] - t0) * 0.01).max():.2f} us")
+hist, edges = np.histogram(e[:count].max(axis=1), bins=12)
+print("end-time histogram of working workgroups (us):", [(round(float(a), 1), int(c)) for a, c in zip(edges[:-1], hist)])
+lst = ws[256:256 + count * 4].view(torch.int32).cpu().numpy()
+dur = (work[..., 1] - work[..., 0]) * 0.01
+order = np.argsort(-dur.max(axis=1))[:16]
+print("slowest workgroups: duration per wave (us), classes, lane-0 voxels written, brick (bx, by, bz)")
+for i in order:
+    b_ = int(lst[i])
+    print(f"  wg {i:5d}  {np.round(dur[i], 1).tolist()}  cls {work[i, :, 2].tolist()}  n0 {work[i, :, 3].tolist()}  brick {(b_ & 1023, (b_ >> 10) & 1023, b_ >> 20)}  begin {b[i].min():.2f}")
+m = work[..., 2] == 0
+for k in range(9):
+    sel = m & (work[..., 3] == k)
+    if sel.any():
+        print(f"walk waves whose lane 0 wrote {k} voxels: {sel.sum():5d}  mean {dur[sel].mean():6.2f} us  max {dur[sel].max():6.2f}")

@@ -215,6 +215,7 @@ struct IntegrateArgs {
     unsigned char *signmap;       // xs_signmap.h buffer (whole-volume launches) or null: bricks that receive a negative value are marked
     DepthTiles dt;                // per-tile depth range of the frame (k_scale_depth), for k_classify_boxes
     unsigned char *box_class;     // [list entry][BOXES_PER_BRICK] BOX_* (k_classify_boxes) or null: every box takes the exact walk
+    size_t probe_offset;          // XS_PROBE_WG_TIMES only: bytes from box_class to the record area
 };
 enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u };  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
 enum { CLASS_COUNT_WORD = 48 };    // write every updated voxel's three words even where the bits do not change (measurement aid)
@@ -425,6 +426,26 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Po
     return update_voxel(a, k, p, pre_v, pre_g, pre_w, out_v, out_g, out_w);
 }
 
+// Three LDS-DMA loads (value, grad, weight rows of one plane: no destination register) into a 768-byte LDS slot.
+__device__ __forceinline__ void lds_dma3(unsigned voff, const void *pv, const void *pg, const void *pw, unsigned lds) {
+    unsigned keep;
+    const unsigned l1 = lds + 256, l2 = lds + 512;
+    // M0 holds the LDS address of lane 0's word; the compiler does not preserve it around a statement, so it is saved and put back.
+    // (s_nop 4 first: a base pointer the compiler has just fetched back from a spill lane (v_readlane) needs five wait states before a
+    // vector-memory instruction reads it, and the compiler pads nothing inside a statement)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(pv), "s"(pg), "s"(pw), "s"(lds), "s"(l1), "s"(l2) : "memory");
+}
+// XS_WALK_PREFETCH (experiment, r04): before its first trip the OFF32 walk asks for the state of all its planes at once — by LDS-DMA into
+// a junk slot, so no register holds them: the lines are in L2 when the trips ask again.  A wave's vector-memory operations complete in
+// issue order, so the walk's trips each expose one full HBM latency; with the prefetch the brick pays it once.
+#ifndef XS_WALK_PREFETCH
+#define XS_WALK_PREFETCH 0
+#endif
 // z in [zb, ze) of column (x, y).  The voxel's current state (coalesced 256 B rows) is requested
 // before the projection arithmetic so its HBM latency runs under it.  (Two planes per trip with
 // six reads in flight was measured slower: 102 VGPRs halve the resident waves.)
@@ -456,6 +477,15 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
         char *bv = reinterpret_cast<char *>(a.value) + ubase, *bw = reinterpret_cast<char *>(a.weight) + ubase, *bg = reinterpret_cast<char *>(a.grad) + ubase;
         const unsigned plane = (unsigned)a.Y * (unsigned)a.vstep;
         unsigned off = lane_off + (unsigned)(zb - zb0) * plane;
+#if XS_WALK_PREFETCH
+        {
+            __shared__ unsigned s_junk[3 * 64];
+            const unsigned junk = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&s_junk[0]);
+            unsigned poff = off;
+#pragma unroll 1
+            for (int z = zb; z < ze; ++z, poff += plane) lds_dma3(poff, bv, bg, bw, junk);
+        }
+#endif
         for (int z = zb; z < ze; ++z, off += plane) {
             float *pos = reinterpret_cast<float *>(bv + off), *gpos = reinterpret_cast<float *>(bg + off);
             int *wpos = reinterpret_cast<int *>(bw + off);
@@ -528,7 +558,10 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
 // A class byte holds for every pose whose camera-frame coordinates differ from the classified pose's by at most (dX, dY, dC) anywhere
 // in the volume (BoxSlack; zero for a launch classified with its own pose): the pads grow by what such a pose can move a projection
 // and a depth, and the host accepts a list for another pose only after checking exactly that (xs_integrate_list_covers).
-enum { BOX_MIXED = 0, BOX_FREE = 1, BOX_EMPTY = 2, BOX_MAX_TILES = 128, FREE_CHUNK = 4 };
+#ifndef XS_FREE_CHUNK
+#define XS_FREE_CHUNK 4
+#endif
+enum { BOX_MIXED = 0, BOX_FREE = 1, BOX_EMPTY = 2, BOX_MAX_TILES = 128, FREE_CHUNK = XS_FREE_CHUNK };
 enum { BOX_WX = BRICK_X < 64 ? BRICK_X : 64, BOX_WY = 64 / BOX_WX, BOXES_PER_BRICK = 4 };   // a wave's part of a brick
 struct BoxSlack { float dX, dY, dC; };
 __device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }    // quad_perm [1, 0, 3, 2]
@@ -753,6 +786,9 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
         }
         ps.t.x = cfloat(f(18), f(19)); ps.t.y = cfloat(f(20), f(21)); ps.t.z = cfloat(f(22), f(23));
     }
+#if defined(XS_PROBE_WG_TIMES)   // measurement only: every workgroup's begin / end on the 100 MHz wall clock, 512 KiB into the tile room of the workspace
+    const unsigned long long probe_t0 = wall_clock64();
+#endif
     const unsigned count = *a.brick_count;
     unsigned n_upd = 0;
     const float far = far_limit(a);
@@ -760,20 +796,35 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     // whole kernel they push the voxel loop's own operands out (99 spilled scalars, ~30 v_readlane per voxel to fetch them
     // back — VALU slots, and this kernel is bound by VALU issue: 101 M wave instructions per S2 launch): they live in LDS.
     __shared__ ClipPlanes s_cp;
-    if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4))
-        reinterpret_cast<float *>(&s_cp)[threadIdx.x] = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
+    float cp_word = 0.f;
+    if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) cp_word = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
+    // (A bit-reversed entry order for launches with fewer bricks than workgroups — so that list neighbours, the bricks of one surface, land
+    // on different CUs — measured 29 -> 42 us on S1: the dispatcher deals consecutive workgroups round the CUs, so the eight workgroups of
+    // a CU already take entries 256 apart; profiles/r04_integrate_wg_times.txt.)
+    const unsigned first = blockIdx.x, stride = gridDim.x;
+    // the first entry and its class are requested together, in front of the barrier
+    int b_next = 0, cls_next = BOX_MIXED;
+    if (first < count) {
+        b_next = a.brick_list[first];
+        if (OFF32 && a.box_class) cls_next = (int)a.box_class[first * BOXES_PER_BRICK + threadIdx.y];
+    }
+    if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[threadIdx.x] = cp_word;
     __syncthreads();
-    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+    for (unsigned e = first; e < count; e += stride) {
         // (OFF32: the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
         // or every address derived from it would be a 64-bit vector quantity)
-        const int b = OFF32 ? __builtin_amdgcn_readfirstlane(a.brick_list[e]) : a.brick_list[e];
+        if (e != first) {
+            b_next = a.brick_list[e];
+            if (OFF32 && a.box_class) cls_next = (int)a.box_class[e * BOXES_PER_BRICK + threadIdx.y];
+        }
+        const int b = OFF32 ? __builtin_amdgcn_readfirstlane(b_next) : b_next;
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
         const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
         const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
         if constexpr (OFF32) {
             if (a.box_class) {   // what k_classify_boxes found for this wave's part of the brick
-                const int cls = __builtin_amdgcn_readfirstlane((int)a.box_class[e * BOXES_PER_BRICK + threadIdx.y]);
+                const int cls = __builtin_amdgcn_readfirstlane(cls_next);
                 if (cls == BOX_EMPTY) continue;
                 if (cls == BOX_FREE) {
                     if (x < a.X && y < a.Y) {
@@ -800,6 +851,12 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
             }
         }
     }
+#if defined(XS_PROBE_WG_TIMES)
+    if (a.box_class && threadIdx.x == 0) {
+        unsigned *rec = reinterpret_cast<unsigned *>(a.box_class + a.probe_offset) + 4u * (blockIdx.x * 4 + threadIdx.y);
+        rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[blockIdx.x * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = n_upd;
+    }
+#endif
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
 }
 
@@ -813,19 +870,6 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
 // gather and everything older, which includes plane j's state (requested a whole trip ago), but not for the three requests it has
 // just made.  One asm statement holds the gather, the three DMAs (with their own lane mask: the lanes whose column has plane
 // j + 1) and the wait, so the count is exact by construction.
-__device__ __forceinline__ void lds_dma3(unsigned voff, const void *pv, const void *pg, const void *pw, unsigned lds) {
-    unsigned keep;
-    const unsigned l1 = lds + 256, l2 = lds + 512;
-    // M0 holds the LDS address of lane 0's word; the compiler does not preserve it around a statement, so it is saved and put back.
-    // (s_nop 4 first: a base pointer the compiler has just fetched back from a spill lane (v_readlane) needs five wait states before a
-    // vector-memory instruction reads it, and the compiler pads nothing inside a statement)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
-                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(pv), "s"(pg), "s"(pw), "s"(lds), "s"(l1), "s"(l2) : "memory");
-}
 struct RingRefill {   // wave-uniform but for voff: the next plane's state -> the slot at lds, for the lanes in mask (never empty when has)
     bool has; unsigned long long mask; const void *pv, *pg, *pw; unsigned lds, voff;
 };
@@ -1076,6 +1120,7 @@ static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *w
     if (!tiles) return false;
     a.dt = depth_tiles_view(tiles, a.drows, a.dcols);
     a.box_class = reinterpret_cast<unsigned char *>((char *)workspace + workspace_list_bytes(res, nz));
+    a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
     hipLaunchKernelGGL(k_classify_boxes, dim3(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048), dim3(256), 0, st, a, sl);
     return true;
@@ -1246,8 +1291,10 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace;
         g_classes_of = nullptr;
         if (off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES)) {
-            if (classes_ahead)
+            if (classes_ahead) {
                 a.box_class = reinterpret_cast<unsigned char *>((char *)workspace + workspace_list_bytes(res, nz));
+                a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
+            }
             else if (!posted) {   // (a posted launch has no pose yet to classify with)
                 const DepthTile *tiles = g_depth_tiles;
                 if (!tiles && xs_depth_tiles_bytes(rows, cols) <= TILE_ROOM_BYTES) {
@@ -1271,8 +1318,9 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         }
         if (env_k && !strcmp(env_k, "ring") && !a.signmap && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
             kern = k_integrate_bricks_ring<false>;
-        if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, 0, st, g_int_ev0, g_int_ev1, 0, a);
-        else hipLaunchKernelGGL(kern, dim3(g), block, 0, st, a);
+        static const int env_lds = getenv("XS_INTEGRATE_DYN_LDS") ? atoi(getenv("XS_INTEGRATE_DYN_LDS")) : 0;   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU
+        if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, g_int_ev0, g_int_ev1, 0, a);
+        else hipLaunchKernelGGL(kern, dim3(g), block, env_lds, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
             hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
     } else {
