@@ -217,7 +217,7 @@ struct IntegrateArgs {
     unsigned char *box_class;     // [list entry][BOXES_PER_BRICK] BOX_* (k_classify_boxes) or null: every box takes the exact walk
     size_t probe_offset;          // XS_PROBE_WG_TIMES only: bytes from box_class to the record area
 };
-enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u };  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
+enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };   // KF_FAR_FIRST: the list is taken from its end (see k_integrate_bricks)  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
 enum { CLASS_COUNT_WORD = 48 };    // write every updated voxel's three words even where the bits do not change (measurement aid)
 
 namespace {
@@ -559,7 +559,7 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
 // in the volume (BoxSlack; zero for a launch classified with its own pose): the pads grow by what such a pose can move a projection
 // and a depth, and the host accepts a list for another pose only after checking exactly that (xs_integrate_list_covers).
 #ifndef XS_FREE_CHUNK
-#define XS_FREE_CHUNK 4
+#define XS_FREE_CHUNK 1
 #endif
 enum { BOX_MIXED = 0, BOX_FREE = 1, BOX_EMPTY = 2, BOX_MAX_TILES = 128, FREE_CHUNK = XS_FREE_CHUNK };
 enum { BOX_WX = BRICK_X < 64 ? BRICK_X : 64, BOX_WY = 64 / BOX_WX, BOXES_PER_BRICK = 4 };   // a wave's part of a brick
@@ -624,33 +624,47 @@ __device__ __forceinline__ int classify_box(const IntegrateArgs &a, const BoxSla
     if (inside && lo - cmax > band) return BOX_FREE;  // (lo = 0 where a pixel is invalid)
     return BOX_MIXED;
 }
-// FREE box: voxels (x, y, zb .. ze - 1) of this lane's column (which lies in the volume), FREE_CHUNK planes' state requested before the
-// first is used.  Addressed like the OFF32 walk: wave-uniform array bases + one 32-bit byte offset per lane and plane, shared by the
-// three arrays.  off: the column's first voxel (plane zb); plane: bytes between planes.
+// FREE box: voxels (x, y, zb .. ze - 1) of this lane's column (which lies in the volume).  A rolling pipeline over groups of FREE_CHUNK
+// planes: the next group's state is requested before the current group is updated and stored, so the wave always has reads in flight
+// (a wave's memory operations complete in issue order: the stores of one group would otherwise stand between two groups of reads).
+// Addressed like the OFF32 walk: wave-uniform array bases + one 32-bit byte offset per lane and plane, shared by the three arrays.
+// off: the column's first voxel (plane zb); plane: bytes between planes.
+struct FreeGroup { float v[FREE_CHUNK], g[FREE_CHUNK]; int w[FREE_CHUNK]; };
+__device__ __forceinline__ void free_group_load(FreeGroup &s, const char *bv, const char *bw, const char *bg, unsigned off, unsigned plane, int left) {
+#pragma unroll
+    for (int j = 0; j < FREE_CHUNK; ++j)
+        if (j < left) {
+            s.v[j] = *reinterpret_cast<const float *>(bv + (off + j * plane));
+            s.g[j] = *reinterpret_cast<const float *>(bg + (off + j * plane));
+            s.w[j] = *reinterpret_cast<const int *>(bw + (off + j * plane));
+        }
+}
+template <bool SIGN>
+__device__ __forceinline__ void free_group_store(const IntegrateArgs &a, const FreeGroup &s, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int left,
+                                                 unsigned always, float &vmin) {
+#pragma unroll
+    for (int j = 0; j < FREE_CHUNK; ++j)
+        if (j < left) {
+            float ov, og; int ow;
+            running_mean(a.max_weight, cfloat(1.0f, 0.0f), s.v[j], s.g[j], s.w[j], ov, og, ow);
+            if ((__float_as_uint(ov) ^ __float_as_uint(s.v[j])) | always) *reinterpret_cast<float *>(bv + (off + j * plane)) = ov;
+            if ((unsigned)(ow ^ s.w[j]) | always) *reinterpret_cast<int *>(bw + (off + j * plane)) = ow;
+            if ((__float_as_uint(og) ^ __float_as_uint(s.g[j])) | always) *reinterpret_cast<float *>(bg + (off + j * plane)) = og;
+            if (SIGN) vmin = fminf(vmin, ov);
+        }
+}
 template <bool SIGN>
 __device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int x, int y, int zb, int ze) {
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
     float vmin = 0.0f;
+    FreeGroup A, B;
+    free_group_load(A, bv, bw, bg, off, plane, ze - zb);
 #pragma unroll 1
-    for (int z0 = zb; z0 < ze; z0 += FREE_CHUNK, off += FREE_CHUNK * plane) {
-        float v0[FREE_CHUNK], g0[FREE_CHUNK]; int w0[FREE_CHUNK];
-#pragma unroll
-        for (int j = 0; j < FREE_CHUNK; ++j)
-            if (z0 + j < ze) {
-                v0[j] = *reinterpret_cast<const float *>(bv + (off + j * plane));
-                g0[j] = *reinterpret_cast<const float *>(bg + (off + j * plane));
-                w0[j] = *reinterpret_cast<const int *>(bw + (off + j * plane));
-            }
-#pragma unroll
-        for (int j = 0; j < FREE_CHUNK; ++j)
-            if (z0 + j < ze) {
-                float ov, og; int ow;
-                running_mean(a.max_weight, cfloat(1.0f, 0.0f), v0[j], g0[j], w0[j], ov, og, ow);
-                if ((__float_as_uint(ov) ^ __float_as_uint(v0[j])) | always) *reinterpret_cast<float *>(bv + (off + j * plane)) = ov;
-                if ((unsigned)(ow ^ w0[j]) | always) *reinterpret_cast<int *>(bw + (off + j * plane)) = ow;
-                if ((__float_as_uint(og) ^ __float_as_uint(g0[j])) | always) *reinterpret_cast<float *>(bg + (off + j * plane)) = og;
-                if (SIGN) vmin = fminf(vmin, ov);
-            }
+    for (int z = zb; z < ze; z += 2 * FREE_CHUNK, off += 2 * FREE_CHUNK * plane) {
+        free_group_load(B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK);
+        free_group_store<SIGN>(a, A, bv, bw, bg, off, plane, ze - z, always, vmin);
+        free_group_load(A, bv, bw, bg, off + 2 * FREE_CHUNK * plane, plane, ze - z - 2 * FREE_CHUNK);
+        free_group_store<SIGN>(a, B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK, always, vmin);
     }
     if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
     return (unsigned)(ze - zb);
@@ -746,6 +760,9 @@ __global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, c
         const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
         int cls = BOX_EMPTY;   // a wave without a column of the brick in the volume
         if (wx0 < a.X && wy0 < a.Y) cls = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
+#if defined(XS_PROBE_ALL_FREE)   // measurement only (wrong volume): every walked box streams like free space — the free path's ceiling
+        if (cls == BOX_MIXED) cls = BOX_FREE;
+#endif
         if (corner == 0) {
             a.box_class[e * BOXES_PER_BRICK + box] = (unsigned char)cls;
             if (a.kflags & KF_COUNT_CLASSES) atomicAdd(a.brick_count + CLASS_COUNT_WORD + (cls == BOX_FREE ? 0 : cls == BOX_EMPTY ? 1 : 2), 1u);
@@ -802,29 +819,35 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     // on different CUs — measured 29 -> 42 us on S1: the dispatcher deals consecutive workgroups round the CUs, so the eight workgroups of
     // a CU already take entries 256 apart; profiles/r04_integrate_wg_times.txt.)
     const unsigned first = blockIdx.x, stride = gridDim.x;
+    // The list is in plane order (z slowest).  Where the camera looks up the z axis the bricks of the surfaces — the walked, expensive
+    // ones — come last, and a launch ends with a tail of them, bound by instruction issue, after the free-space bricks have streamed:
+    // taken from its far end the list starts with them and the streaming fills in around (KF_FAR_FIRST, set by the launcher from the pose).
+    const bool far_first = (a.kflags & KF_FAR_FIRST) != 0;
+    auto entry = [&](unsigned e) { return far_first ? count - 1u - e : e; };
     // the first entry and its class are requested together, in front of the barrier
     int b_next = 0, cls_next = BOX_MIXED;
     if (first < count) {
-        b_next = a.brick_list[first];
-        if (OFF32 && a.box_class) cls_next = (int)a.box_class[first * BOXES_PER_BRICK + threadIdx.y];
+        b_next = a.brick_list[entry(first)];
+        if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(first) * BOXES_PER_BRICK + threadIdx.y];
     }
     if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[threadIdx.x] = cp_word;
     __syncthreads();
     for (unsigned e = first; e < count; e += stride) {
         // (OFF32: the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
         // or every address derived from it would be a 64-bit vector quantity)
-        if (e != first) {
-            b_next = a.brick_list[e];
-            if (OFF32 && a.box_class) cls_next = (int)a.box_class[e * BOXES_PER_BRICK + threadIdx.y];
-        }
         const int b = OFF32 ? __builtin_amdgcn_readfirstlane(b_next) : b_next;
+        const int cls_now = cls_next;
+        if (e + stride < count) {   // the next entry and its class, requested before this one is worked on
+            b_next = a.brick_list[entry(e + stride)];
+            if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(e + stride) * BOXES_PER_BRICK + threadIdx.y];
+        }
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
         const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
         const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
         if constexpr (OFF32) {
             if (a.box_class) {   // what k_classify_boxes found for this wave's part of the brick
-                const int cls = __builtin_amdgcn_readfirstlane(cls_next);
+                const int cls = __builtin_amdgcn_readfirstlane(cls_now);
                 if (cls == BOX_EMPTY) continue;
                 if (cls == BOX_FREE) {
                     if (x < a.X && y < a.Y) {
@@ -854,7 +877,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
 #if defined(XS_PROBE_WG_TIMES)
     if (a.box_class && threadIdx.x == 0) {
         unsigned *rec = reinterpret_cast<unsigned *>(a.box_class + a.probe_offset) + 4u * (blockIdx.x * 4 + threadIdx.y);
-        rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[blockIdx.x * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = n_upd;
+        rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[entry(blockIdx.x) * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = n_upd;
     }
 #endif
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
@@ -1247,6 +1270,8 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     static const bool env_always = getenv("XS_INTEGRATE_ALWAYS_STORE") != nullptr;   // measurement aid, as the flag
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
+    static const char *env_order = getenv("XS_INTEGRATE_ORDER");   // A/B aid: "near" / "far" force the list direction
+    if (env_order ? !strcmp(env_order, "far") : a.R.data[2].z.re > 0.0f) a.kflags |= KF_FAR_FIRST;   // camera depth grows with z: the far bricks end the list
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
     a.dt = depth_tiles_view(nullptr, rows, cols); a.box_class = nullptr;
