@@ -155,6 +155,59 @@ def test_sign_map_on_adversarial_volumes(dev):
                         assert np.array_equal(x.view(np.int32) if x.dtype != np.int64 else x, y.view(np.int32) if y.dtype != np.int64 else y), (name, res, shift, k, out)
 
 
+@pytest.mark.parametrize("thres_range", [3.0, 6.0, 10.0])
+def test_sign_map_when_a_ray_leaves_a_negative_region(dev, thres_range):
+    """The march's '- to +' event (RayCaster.cu:243) is decided by the PREVIOUS sample: a ray that starts inside, or passes through, a
+    negative region and comes out into free space ends there without a vertex — also when a second surface lies further along.  With a
+    long time step (thres_range 6 / 10: 0.8 * tranc_dist exceeds the map's sampling distance) the step that leaves the region has its
+    own sample in a clear brick: the map must still have it evaluated.  Negative shells round the camera, thick and thin negative slabs
+    across the view with a far surface behind them; every shift, against the full march, bit for bit."""
+    torch, capi = dev
+    n = 128
+    prm = dict(synth.s1_params(n), thres_range=thres_range)
+    res = [n, n, n]
+    vs = prm["tsdf_voxel_size"]
+    zz, yy, xx = np.mgrid[0:n, 0:n, 0:n].astype(np.float32)
+    T = s1_transforms(0, prm)
+    cam = np.asarray(T["tc2v"], np.float32).reshape(3, 2)[:, 0] / vs        # the camera in voxel units
+    r = np.sqrt((xx - cam[0]) ** 2 + (yy - cam[1]) ** 2 + (zz - cam[2]) ** 2)
+    cases = []
+    for r_in, r_out in ((0.0, 9.0), (0.0, 14.5), (6.0, 11.0), (4.0, 5.5)):
+        v = np.full((n, n, n), 0.4, np.float32)
+        v[(r >= r_in) & (r < r_out)] = -0.3                                 # the camera inside (or just inside of) a negative shell
+        v[zz > cam[2] + 30] = -0.6                                          # a surface further along: a + to - crossing the march must not reach
+        cases.append((v, f"shell {r_in}-{r_out}"))
+    for z0, thick in ((12, 1), (12, 3), (17, 9), (20, 2)):
+        v = np.full((n, n, n), 0.4, np.float32)
+        v[(zz >= cam[2] + z0) & (zz < cam[2] + z0 + thick) & (xx > cam[0] - 10)] = -0.3     # a slab across the right part of the view ...
+        v[(zz >= cam[2] + z0 - 6) & (zz < cam[2] + z0) & (xx <= cam[0] - 10)] = -0.3        # ... and one nearer across the left
+        v[zz > cam[2] + 40] = -0.6
+        cases.append((v, f"slab at {z0} x {thick}"))
+    ok_shift = 0
+    for v, name in cases:
+        value = torch.from_numpy(v.reshape(n * n, n)).cuda()
+        grad = torch.zeros_like(value)
+        full = cast(torch, capi, prm, res, value, grad, T)
+        assert 0 < int(full[4][0]) < H * W or "shell 0.0" in name, name       # some rays end without a vertex, some find one
+        for shift in (2, 3, 4):
+            nbytes = capi.signmap_bytes(res, shift)
+            if nbytes == 0:
+                continue
+            sm = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            try:
+                capi.signmap_rebuild(sm, res, shift, tranc_dist(prm), value, n * 4)
+            except RuntimeError:
+                continue          # this spacing cannot serve this time step: the library refuses (and the orchestrator marches in full)
+            try:
+                fast = cast(torch, capi, prm, res, value, grad, T, signmap=sm, shift=shift)
+            except RuntimeError:
+                continue
+            ok_shift += 1
+            for x, y in zip(full, fast):
+                assert np.array_equal(x.view(np.int32) if x.dtype != np.int64 else x, y.view(np.int32) if y.dtype != np.int64 else y), (name, shift)
+    assert ok_shift >= len(cases)
+
+
 def test_sign_map_of_the_column_walk_and_the_bilinear_branch(dev):
     """The integrate paths other than the brick list mark the map too: the column walk (no workspace) and the bilinear depth lookup."""
     torch, capi = dev

@@ -229,9 +229,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                 flagged[h] = __builtin_amdgcn_ballot_w64(!in || f);
             }
         }
-        // Iteration k (lane k % 64 of word k / 64) samples the volume at parameter t[k + 1] — the table holds the reference's running
-        // float sum t[0] = 0.2, t[j + 1] = t[j] + time_step.  It may be left out if that parameter lies in the stretch of a clear sample
-        // (within 2 % of a stretch's end, of the neighbouring one as well: the float error of the position is ~1e-6 of it).
+        // Iteration k (lane k % 64 of word k / 64) samples the volume at parameter t[k + 1] and holds that sample against the one at t[k]
+        // (the clamped start voxel for k = 0) — the table holds the reference's running float sum t[0] = 0.2, t[j + 1] = t[j] + time_step.
+        // It may be left out only if BOTH parameters lie in the stretch of a clear sample (within 2 % of a stretch's end, of the
+        // neighbouring one as well: the float error of the position is ~1e-6 of it): the '- to +' event that ends a march
+        // (RayCaster.cu:243) is decided by the sample at t[k], and a ray that leaves a negative region has t[k] flagged and t[k + 1] clear.
+        // Every iteration the march jumps over thereby has a positive previous sample, which is what the jump assumes (prev = 1).
         const float inv_dt = 1.0f / a.sm_dt;
         auto is_set = [&](int i) -> bool {   // sample i flagged (or none such: beyond the samples taken)
             return (unsigned)i >= (unsigned)(64 * a.sm_rounds) || (((i < 64 ? flagged[0] : flagged[1]) >> (i & 63)) & 1ull) != 0ull;
@@ -241,11 +244,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
             const int k = 64 * w + lane;
             if (64 * w <= a.sm.nt - 2) {   // (wave-uniform)
                 const bool runs = k <= a.sm.nt - 2;   // iteration k runs while t[k] < max_time, i.e. k <= nt - 2
-                const float tau = a.sm.t[runs ? k + 1 : 0];
-                const float xq = (tau - 0.2f) * inv_dt;
-                const int i = cvt_flr(xq);
-                const float fr = xq - (float)i;
-                const bool uns = is_set(i) || (fr < 0.02f && is_set(i - 1)) || (fr > 0.98f && is_set(i + 1));
+                auto flagged_at = [&](float tau) -> bool {
+                    const float xq = (tau - 0.2f) * inv_dt;
+                    const int i = cvt_flr(xq);
+                    const float fr = xq - (float)i;
+                    return is_set(i) || (fr < 0.02f && is_set(i - 1)) || (fr > 0.98f && is_set(i + 1));
+                };
+                const bool uns = flagged_at(a.sm.t[runs ? k + 1 : 0]) || flagged_at(a.sm.t[runs ? k : 0]);
                 unsafe[w] = __builtin_amdgcn_ballot_w64(runs && uns);
             }
         }

@@ -787,8 +787,16 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
 // (~16 us -> ~4).  The frustum planes (brick test, column clip) stay those of the pose the list was classified with, widened: they
 // only bound the voxels that take the exact tests, and the host posts only after checking that the final pose's planes lie inside
 // them (xs_integrate_pose_covered); otherwise it posts an abandon command and the launch leaves without touching the volume.
+#ifndef XS_INTEGRATE_WAVES
+// Workgroups per CU = waves per SIMD the brick kernel is compiled for.  8 (64 VGPRs, 78 SGPRs) was round 3's choice: with the free-space
+// path and the class look-up next to the walk the instance the pipeline runs then spills 36-48 bytes per lane, and a spill is not free
+// even when it is rare: every wave's scratch lines are written back to HBM (2-3 KB per wave, ~15 MB per S1 launch: the traffic counters,
+// profiles/r04_integrate_pmc.json).  At 6 (80 VGPRs, 106 SGPRs) no instance has scratch and far fewer scalars live in VGPR lanes: the S1
+// kernel inside the pipeline 33 -> 28 us, S2 unchanged (profiles/r04_ab_integrate_waves.txt).
+#define XS_INTEGRATE_WAVES 6
+#endif
 template <bool BILINEAR, bool OFF32 = false, bool POSTED = false, bool SIGN = false>
-__global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs a) {
+__global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(const IntegrateArgs a) {
     PoseRT ps{a.R, a.t};
     if constexpr (POSTED) {
         // the pose k_pose_gate (the launch in front of this one) took from the mailbox: word 0 = command (0: run), words 1..24 = R, t
@@ -835,12 +843,12 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks(const IntegrateArgs
     for (unsigned e = first; e < count; e += stride) {
         // (OFF32: the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
         // or every address derived from it would be a 64-bit vector quantity)
+        if (e != first) {
+            b_next = a.brick_list[entry(e)];
+            if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(e) * BOXES_PER_BRICK + threadIdx.y];
+        }
         const int b = OFF32 ? __builtin_amdgcn_readfirstlane(b_next) : b_next;
         const int cls_now = cls_next;
-        if (e + stride < count) {   // the next entry and its class, requested before this one is worked on
-            b_next = a.brick_list[entry(e + stride)];
-            if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(e + stride) * BOXES_PER_BRICK + threadIdx.y];
-        }
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
         const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
