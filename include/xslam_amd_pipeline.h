@@ -118,6 +118,9 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4);
  * iteration n (0-based, over all levels) of the next alignment fail as for a singular system (KinectFusionReconstruction.cpp:203-210). */
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v);
 void xs_kf_debug_fail_icp_iteration(void *kf, int n);
+/* test aid: a random host sleep of [min_us, max_us] microseconds in front of every ICP pose post (0, 0 = none): a slow host must neither
+ * time a resident launch out nor change a pose */
+void xs_kf_debug_post_delay(void *kf, int min_us, int max_us);
 /* Rebuilds the sign map of the ray march (xslam_amd.h) from the volume: to be called by whoever writes the value array through
  * xs_kf_volume_ptr (loadCheckpoint does it itself).  No-op in shard mode or with raycast_sign_map: false. */
 void xs_kf_rebuild_sign_map(void *kf);

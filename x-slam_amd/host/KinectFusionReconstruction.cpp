@@ -461,6 +461,13 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
             const double det = real_determinant6(A);
             bool singular = fabs(det) < 1e-15 || std::isnan(det);
             if (debug_fail_icp_iteration_ == n) { singular = true; debug_fail_icp_iteration_ = -1; }   // (test aid)
+            if (debug_post_delay_us_[1] > 0) {   // (test aid: a slow host — the enqueued launch keeps polling)
+                debug_post_rng_ = debug_post_rng_ * 1664525u + 1013904223u;
+                const int span = debug_post_delay_us_[1] - debug_post_delay_us_[0] + 1;
+                const int us = debug_post_delay_us_[0] + (int)((debug_post_rng_ >> 8) % (unsigned)(span > 0 ? span : 1));
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(us);
+                while (std::chrono::steady_clock::now() < until) {}
+            }
             if (next_enqueued) {
                 if (singular) xs_icp_post_pose(mailbox, nullptr, nullptr, last_mail_seq, 1);
                 else xs_icp_post_pose(mailbox, &device_cast<MatS33>(Rnext).data[0].x.re, &device_cast<devComplex3>(tnext).x.re, next_mail_seq, 0);

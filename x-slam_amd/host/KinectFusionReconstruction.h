@@ -282,6 +282,8 @@ public:
     // next PoseEstimate (-1: off)
     void DebugSetIcpSequence(unsigned long long v);
     int debug_fail_icp_iteration_ = -1;
+    int debug_post_delay_us_[2] = {0, 0};   // test aid: a random host sleep of [min, max] microseconds in front of every pose post (a slow host)
+    unsigned debug_post_rng_ = 12345u;
 private:
     void AbandonClassifiedList();
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
