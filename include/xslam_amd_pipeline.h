@@ -97,7 +97,9 @@ int xs_kf_download_volume(void *kf, float *value, int *weight, float *grad);
 /* which: 0 depths_curr 1 vmaps_curr 2 nmaps_curr 3 vmaps_g_prev 4 nmaps_g_prev; out: planes x
  * rows x cols x (re, im), dense */
 int xs_kf_download_map(void *kf, int which, int level, float *out);
-/* device pointers + pitch of the live arrays: which 0 value 1 weight 2 grad */
+/* device pointers + pitch of the live arrays: which 0 value 1 weight 2 grad.  Asking for the value array (which 0) marks the ray march's
+ * sign map stale: it is rebuilt from the volume in front of the next raycast (one pass over the value array), so a caller that writes
+ * values through the pointer needs no further call; a caller that only reads pays that pass once per request. */
 void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes);
 
 /* HIP-event timing.  level 0: off.  1: the integrate kernel's own event pair (stage 3) and the per-frame
@@ -121,8 +123,9 @@ void xs_kf_debug_fail_icp_iteration(void *kf, int n);
 /* test aid: a random host sleep of [min_us, max_us] microseconds in front of every ICP pose post (0, 0 = none): a slow host must neither
  * time a resident launch out nor change a pose */
 void xs_kf_debug_post_delay(void *kf, int min_us, int max_us);
-/* Rebuilds the sign map of the ray march (xslam_amd.h) from the volume: to be called by whoever writes the value array through
- * xs_kf_volume_ptr (loadCheckpoint does it itself).  No-op in shard mode or with raycast_sign_map: false. */
+/* Rebuilds the sign map of the ray march (xslam_amd.h) from the volume now (in shard mode: from the planes this rank stores, on every
+ * rank).  xs_kf_volume_ptr(kf, 0, .) schedules the same in front of the next raycast and loadCheckpoint does it itself, so this is
+ * only for a caller that kept the pointer and wrote through it again later.  No-op with raycast_sign_map: false. */
 void xs_kf_rebuild_sign_map(void *kf);
 /* integrate_post_pose: how many posted integrate launches were given their pose, and how many were told to leave because the final pose was
  * not covered by the planes they had been given (those frames took the plain call) */

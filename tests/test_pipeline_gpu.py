@@ -290,6 +290,45 @@ def test_ray_march_from_the_sign_map_changes_nothing(dev, tmp_path, n, scene):
         r.close()
 
 
+def test_volume_written_through_its_pointer_invalidates_the_sign_map(dev):
+    """A caller that writes the value array through volume_ptr (xs_kf_volume_ptr) need not know about the sign map: asking for the
+    pointer marks the map stale and the next raycast rebuilds it from the volume.  A slab of negative values is written into free space
+    in front of the camera of two pipelines — one with the map, one marching every step — and the next frames give the same poses,
+    counts and model maps (the rays now stop at the slab)."""
+    torch, pl = dev
+    n = 128
+    prm = synth.s1_params(n)
+    runs = [pl.KinectFusion(dict(prm, raycast_sign_map=False)), pl.KinectFusion(dict(prm, raycast_sign_map=True))]
+    for k in range(3):
+        d = upload(torch, synth.s1_frame(k))
+        assert all(r.process_frame(d) == 1 for r in runs)
+    hits_before = runs[0].last_hits()
+    for r in runs:
+        ptr, step = r.volume_ptr("value")
+        assert step == n * 4
+
+        class View:
+            __cuda_array_interface__ = {"shape": (n, n, n), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        vol = torch.as_tensor(View(), device="cuda")
+        cz = int(prm["init_z"] / prm["tsdf_voxel_size"])
+        vol[cz + 10:cz + 12, 40:90, 30:100] = -0.5        # a negative slab 0.6 m in front of the camera, in bricks the integrate kernels never marked
+        torch.cuda.synchronize()
+    for k in (3, 4):
+        d = upload(torch, synth.s1_frame(k))
+        rcs = [r.process_frame(d) for r in runs]
+        assert rcs[0] == rcs[1]
+        assert np.array_equal(runs[0].world2camera(), runs[1].world2camera())
+        assert runs[0].last_hits() == runs[1].last_hits() and runs[0].last_U() == runs[1].last_U()
+        H_ = synth.HEIGHT
+        a_, b_ = runs[1].map("vmaps_g_prev", 0), runs[0].map("vmaps_g_prev", 0)
+        valid = np.isfinite(b_[:H_, :, 0])
+        assert np.array_equal(valid, np.isfinite(a_[:H_, :, 0]))
+        assert np.array_equal(a_[:H_][valid].view(np.int32), b_[:H_][valid].view(np.int32))
+    assert runs[0].last_hits() != hits_before            # the slab changed what the rays see
+    for r in runs:
+        r.close()
+
+
 def test_sign_map_over_a_long_trajectory(dev):
     """Sixty frames of the box room at 256^3 — the camera sweeps, surfaces enter and leave the view, bricks marked early stay marked —
     with and without the sign map: every pose, count and the final volume identical, bit for bit."""

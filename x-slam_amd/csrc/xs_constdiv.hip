@@ -59,9 +59,13 @@ xs::ConstDiv xs_const_div_get(float c) {
     d.c = fabsf(c); d.rc = 1.0f / d.c; d.ok = xs_const_div_state(c);
     return d;
 }
-/* Checks constant c on the current device (all 2^32 operands, ~2 ms + one synchronisation) unless it is already in the table;
- * returns its verdict bits (1: short division exact on its domain, 2: floor exact), 0 if the device could not be used.  Call once
- * per constant, at set-up time: the orchestrator does for voxel_size, fx and fy. */
+/* Checks constant c on the current device (all 2^32 operands, ~2 ms + one synchronisation, on the null stream) unless it is already
+ * in the table; returns its verdict bits (1: short division exact on its domain, 2: floor exact), 0 if the device could not be used.
+ * Call once per constant, at set-up time: the orchestrator does for voxel_size, fx and fy.
+ * The table is per process, keyed by the constant alone: a verdict found on one device is used on every device of the process — sound
+ * because the check exercises IEEE operations (multiply, fma, divide, floor) that every gfx942 / gfx950 device evaluates identically
+ * (this library builds for nothing else).  It holds 32 constants; a 33rd is still checked and its verdict returned, but not kept:
+ * xs_const_div_state then reports 0 for it and the launchers take the IEEE divide (correct, just not the short form). */
 extern "C" unsigned xs_const_div_prepare(float c) {
     const float m = fabsf(c);
     if (!(m >= 0x1p-20f && m <= 0x1p20f)) return 0;   // (also rejects NaN / 0 / inf; the bound is what floor_div_by's saturation argument needs)

@@ -409,6 +409,10 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(pinned_sums_ + 56);
                 auto launch_gave_up = [&]() {   // never expected: the launch gave up on its pose
                     if (next_enqueued) xs_icp_post_pose(mailbox, nullptr, nullptr, last_mail_seq, 1);
+                    if (posted_pending_) {   // the integrate launch gated on this frame's pose leaves too — before the stream is drained, or the drain waits out its gate
+                        xs_icp_post_pose(integrate_mailbox_, nullptr, nullptr, posted_seq_, 1);
+                        posted_pending_ = false;
+                    }
                     hipSafeCall(hipStreamSynchronize(current_stream()));
                     check_rc(xs_icp_workspace_init(icp_ws_.ptr(), current_stream()), "icp workspace");
                     stage_end(ST_ICP);
@@ -691,6 +695,7 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     xs_integrate_set_signmap(nullptr);
     xs_integrate_set_depth_tiles(nullptr);
     posted_pending_ = true;
+    posted_at_ = std::chrono::steady_clock::now();
     posted_stop_ = integrate_stop;
     posted_split_ = split;
 }
@@ -747,8 +752,11 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     if (posted_pending_) {
         posted_pending_ = false;
         const int res_[3] = {volume_res.x, volume_res.y, volume_res.z};
-        if (xs_integrate_pose_covered(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res_, voxel_size, list_Rv2c_, list_tv2c_,
-                                      integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re)) {
+        // (a launch whose gate has waited long may have given up — MAILBOX_MAX_POLLS, about a second — and left without writing: a host that
+        // took more than a quarter of that between enqueue and post tells it to leave and integrates the plain way, whatever the gate did)
+        const bool in_time = std::chrono::steady_clock::now() - posted_at_ < std::chrono::milliseconds(250);
+        if (in_time && xs_integrate_pose_covered(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res_, voxel_size, list_Rv2c_, list_tv2c_,
+                                                 integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re)) {
             xs_icp_post_pose(integrate_mailbox_, &device_Rv2c.data[0].x.re, &device_tv2c.x.re, posted_seq_, 0);
             integrated_by_post = true;
             ++posted_accepted_;
@@ -1050,6 +1058,7 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.x = volume_resolution.x();
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
+    if (sign_map_stale_) { RebuildSignMap(); sign_map_stale_ = false; }   // (xs_kf_volume_ptr handed the value array out since the last raycast)
     if (shard_count == 1 && !force_shard_composite) {
         xs_raycast_set_signmap(sign_map_ptr(), raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist());
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,

@@ -12,6 +12,7 @@
 #pragma once
 #include "TsdfVolume.h"
 #include "flat_yaml.hpp"
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,10 @@ public:
     bool raycast_sign_map = true;
     int raycast_sign_map_shift = 0;
     void RebuildSignMap();   // call after writing the value array through xs_kf_volume_ptr
+    // the value array's address has been handed out (xs_kf_volume_ptr): whoever holds it may write the volume behind the integrate kernels'
+    // back, after which the sign map is no longer a superset — it is rebuilt from the volume in front of the next raycast
+    void MarkSignMapStale() { sign_map_stale_ = true; }
+    bool sign_map_stale_ = false;
     // Look-ahead of the map preparation (no counterpart in the reference, whose main.cpp:50-58 reads, uploads and processes one frame at a
     // time): the caller names the depth image it will pass to the NEXT ProcessFrame call — device memory, unchanged until then — and that
     // frame's bilateral filter and depth pyramid are built during this frame's ICP loop.  A ProcessFrame call with any other image simply
@@ -265,6 +270,7 @@ private:
     unsigned integrate_mail_seq_ = 0;
     DeviceArray<unsigned> posted_pose_;        // {command, 24 floats}: the gate kernel's hand-over to the posted integrate launch
     bool posted_pending_ = false;              // a posted integrate launch is in the stream, waiting for its pose
+    std::chrono::steady_clock::time_point posted_at_{};   // when it was enqueued (a pose that comes too late is not posted: the gate may have given up)
     unsigned posted_seq_ = 0;
     hipEvent_t posted_stop_ = nullptr;         // its completion event
     bool posted_split_ = false;

@@ -225,6 +225,7 @@ void *xs_kf_volume_ptr(void *kf, int which, size_t *step_bytes) {
     if (which == 1) { auto a = k->tsdf_volume_d_ptr->weight(); if (step_bytes) *step_bytes = a.step(); return a.ptr(); }
     auto a = which == 0 ? k->tsdf_volume_d_ptr->value() : k->tsdf_volume_d_ptr->grad();
     if (step_bytes) *step_bytes = a.step();
+    if (which == 0) k->MarkSignMapStale();   // a caller that writes values through this pointer need not know about the sign map
     return a.ptr();
 }
 
