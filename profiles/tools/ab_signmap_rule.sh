@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box: the two correct forms of the sign map's skip rule — default: iteration k is marked by its own sample t[k+1] (and iteration 0 by
+# the start), and the march does not jump while a ray carries a negative value out of a batch; XS_PROBE_SIGNMAP_BOTH: marked when t[k] OR
+# t[k+1] is flagged — raycast alone on the tracked 512^3 volume, frames/s
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
+F="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize"
+for rep in 1 2 3; do for d in "" "-DXS_PROBE_SIGNMAP_BOTH"; do
+  touch x-slam_amd/csrc/xs_raycast.hip; make -C x-slam_amd/csrc HIPFLAGS="$F $d" xs_raycast.o > /dev/null 2>&1 && make -C x-slam_amd/csrc > /dev/null 2>&1 || exit 1
+  echo -n "rule [${d:-carried sign}]: "
+  timeout -k 10 240 python3 bench.py --workload track --no-cpu-baseline --no-s2 --no-legs --steps 60 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['raycast']; print('raycast alone ms', r['ms_per_frame_alone'], 'every step', r['every_step']['ms_per_frame_alone'], 'stage', d['stages_ms']['raycast'], 'fps', d['value'])" || exit 1
+done; done
+touch x-slam_amd/csrc/xs_raycast.hip; make -C x-slam_amd/csrc > /dev/null 2>&1

@@ -180,7 +180,10 @@ struct Vol {
 // eight gathers in flight, like MODE 2).
 // (crossing kernels: five waves per SIMD — a 640 x 480 frame is 4 800 waves on 1 024 SIMDs, all resident at once; the
 // two-samples-per-round-trip form would otherwise take 104 registers, i.e. four)
-constexpr int raycast_min_waves(int mode, bool map) { return mode == 3 || mode == 5 || (mode == 0 && map) ? 5 : 1; }
+#ifndef XS_RAYCAST_CROSS_WAVES
+#define XS_RAYCAST_CROSS_WAVES 5
+#endif
+constexpr int raycast_min_waves(int mode, bool map) { return mode == 3 || mode == 5 || (mode == 0 && map) ? XS_RAYCAST_CROSS_WAVES : 1; }
 template <int MODE, bool OFF32, bool SHORT, bool MAP = false>   // MAP (MODE 2 or 0): the march evaluates only the iterations the sign map (a.sm) leaves
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycast_min_waves(MODE, MAP)))) k_raycast(const RaycastArgs a) {
     constexpr bool SLAB = MODE == 1 || MODE == 4 || MODE == 5;
@@ -231,10 +234,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
         }
         // Iteration k (lane k % 64 of word k / 64) samples the volume at parameter t[k + 1] and holds that sample against the one at t[k]
         // (the clamped start voxel for k = 0) — the table holds the reference's running float sum t[0] = 0.2, t[j + 1] = t[j] + time_step.
-        // It may be left out only if BOTH parameters lie in the stretch of a clear sample (within 2 % of a stretch's end, of the
-        // neighbouring one as well: the float error of the position is ~1e-6 of it): the '- to +' event that ends a march
-        // (RayCaster.cu:243) is decided by the sample at t[k], and a ray that leaves a negative region has t[k] flagged and t[k + 1] clear.
-        // Every iteration the march jumps over thereby has a positive previous sample, which is what the jump assumes (prev = 1).
+        // It is marked for evaluation when t[k + 1] lies in the stretch of a flagged sample (within 2 % of a stretch's end, of the
+        // neighbouring one as well: the float error of the position is ~1e-6 of it) — and iteration 0 also when the start, t[0], does.
+        // That alone would miss one event: the '- to +' that ends a march (RayCaster.cu:243) is decided by the PREVIOUS sample, and a ray
+        // that leaves a negative region has t[k] flagged and t[k + 1] clear.  But then iteration k - 1 was evaluated and its sample — this
+        // iteration's previous one — is in hand: the march does not jump while any of the wave's unfinished rays carries a negative value
+        // out of a batch (the loops below).  Every iteration that is jumped over therefore has a positive previous sample, which is what
+        // the jump assumes (prev = 1).  (Marking every iteration whose t[k] OR t[k + 1] is flagged, the simpler static rule, costs one more
+        // iteration behind every flagged run a ray leaves: raycast alone 42.2 us against 41.4, profiles/r04_ab_signmap_rule.txt.)
         const float inv_dt = 1.0f / a.sm_dt;
         auto is_set = [&](int i) -> bool {   // sample i flagged (or none such: beyond the samples taken)
             return (unsigned)i >= (unsigned)(64 * a.sm_rounds) || (((i < 64 ? flagged[0] : flagged[1]) >> (i & 63)) & 1ull) != 0ull;
@@ -250,7 +257,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                     const float fr = xq - (float)i;
                     return is_set(i) || (fr < 0.02f && is_set(i - 1)) || (fr > 0.98f && is_set(i + 1));
                 };
-                const bool uns = flagged_at(a.sm.t[runs ? k + 1 : 0]) || flagged_at(a.sm.t[runs ? k : 0]);
+#if defined(XS_PROBE_SIGNMAP_BOTH)   // measurement only: the simpler static rule (see above)
+                const bool uns = flagged_at(a.sm.t[runs ? k + 1 : 0]) || (k == 0 ? is_set(0) : flagged_at(a.sm.t[runs ? k : 0]));
+#else
+                const bool uns = flagged_at(a.sm.t[runs ? k + 1 : 0]) || (k == 0 && is_set(0));   // (t[0] = 0.2 is sample 0's own position)
+#endif
                 unsafe[w] = __builtin_amdgcn_ballot_w64(runs && uns);
             }
         }
@@ -436,7 +447,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                         pstored = (stored >> (NS - 1)) & 1u;
                     }
                     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-                    const int kn = next_unsafe(k + NS);
+                    // no jump while an unfinished ray of the wave is inside a negative region (its next iteration may be the '- to +' exit)
+                    const bool inside = __builtin_amdgcn_ballot_w64(!done && pval < 0.f) != 0ull;
+                    const int kn = inside ? (k + NS <= a.sm.nt - 2 ? k + NS : -1) : next_unsafe(k + NS);
                     if (kn != k + NS) { pval = 1.0f; pstored = true; }
                     k = kn;
                 }
@@ -576,7 +589,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                         }
                     }
                     if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) break;
-                    const int kn = next_unsafe(k + NS);
+                    // no jump while an unfinished ray of the wave is inside a negative region (its next iteration may be the '- to +' exit)
+                    const bool inside = __builtin_amdgcn_ballot_w64(!finished && prev < 0.f) != 0ull;
+                    const int kn = inside ? (k + NS <= a.sm.nt - 2 ? k + NS : -1) : next_unsafe(k + NS);
                     if (kn != k + NS) prev = 1.0f;
                     k = kn;
                 }
