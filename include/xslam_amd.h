@@ -254,6 +254,15 @@ int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_keys_dev, fl
                             int cols, void *stream);
 int xs_raycast_compose_finish(const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows, int cols,
                               unsigned long long *hits_dev, void *stream);
+/* The composite without the sum of the maps (round 4): xs_raycast_compose_pack packs the pixels this rank owns with a vertex (own key ==
+ * min key) into entries of xs_raycast_compose_entry_bytes() = 52 bytes {pixel index, vertex (3 complex), normal (3 complex)} and advances
+ * *count_dev (zeroed by the caller; room for rows * cols entries) by their number; the caller gathers the ranks' packs (variable sizes)
+ * and hands all of them to xs_raycast_compose_scatter, which writes them into the maps; then xs_raycast_compose_finish as before.  Per
+ * rank and frame a ring all-reduce of the maps moves 2 (N - 1) / N x 14.7 MB, the gathered packs (N - 1) / N x 52 B x hits: half. */
+size_t xs_raycast_compose_entry_bytes(void);
+int xs_raycast_compose_pack(const int *own_keys_dev, const int *min_keys_dev, const float *vmap, const float *nmap, size_t map_step, int rows, int cols,
+                            void *entries_dev, int *count_dev, void *stream);
+int xs_raycast_compose_scatter(const void *entries_dev, long n, float *vmap, float *nmap, size_t map_step, int rows, int cols, void *stream);
 
 /* First-order CSFD Gauss-Newton terms of ComputeLocalTsdfHessianKernel's residual for six seeded poses in one
  * pass over the volume (BASELINE config 5; the reference has only the single-direction kernels above).

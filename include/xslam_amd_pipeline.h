@@ -39,8 +39,11 @@ void *xs_kf_create(const char *yaml_text);
  * every ICP level.  collective(user, op, dev_ptr, count) must all-reduce dev_ptr in place over
  * the ranks, ordered on the current stream: op 0 = sum of doubles (the 27 complex<double>
  * normal-equation sums + inlier count), 1 = min of int32 (first raycast event per pixel),
- * 2 = sum of int32 (vertex / normal maps as bit patterns).  xs_kf_download_volume then returns
- * the stored planes only (xs_kf_shard_planes). */
+ * 2 = sum of int32 (the owned-pixel counts of the raycast composite; with shard_composite_gather: false the vertex / normal maps as bit
+ * patterns), 3 = gather of variable-size parts: dev_ptr is then a HOST array of count + 2 64-bit words — [0] the device buffer's address,
+ * [1 + r] .. [2 + r] the byte range of rank r's part in it — this rank's part is in place when the call is made, every rank's when the
+ * operation has completed on the stream (count = the number of ranks; the parts are whole 52-byte entries).
+ * xs_kf_download_volume then returns the stored planes only (xs_kf_shard_planes). */
 void *xs_kf_create_sharded(const char *yaml_text, int rank, int count, void (*collective)(void *user, int op, void *dev_ptr, long n),
                            void *user);
 void xs_kf_shard_planes(void *kf, int *owned2, int *stored2);
@@ -127,6 +130,9 @@ void xs_kf_debug_post_delay(void *kf, int min_us, int max_us);
  * rank).  xs_kf_volume_ptr(kf, 0, .) schedules the same in front of the next raycast and loadCheckpoint does it itself, so this is
  * only for a caller that kept the pointer and wrote through it again later.  No-op with raycast_sign_map: false. */
 void xs_kf_rebuild_sign_map(void *kf);
+/* shard mode: bytes this rank has received through the raycast composite's collectives since creation (a ring all-reduce of S bytes over N
+ * ranks counted as 2 (N - 1) / N x S, the gather of the owned pixels as the other ranks' parts) */
+long long xs_kf_composite_bytes(void *kf);
 /* integrate_post_pose: how many posted integrate launches were given their pose, and how many were told to leave because the final pose was
  * not covered by the planes they had been given (those frames took the plain call) */
 void xs_kf_posted_integrate_counts(void *kf, long long *accepted, long long *refused);

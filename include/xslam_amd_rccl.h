@@ -27,8 +27,11 @@ int xs_rccl_comm_destroy(void *comm);
 /* the collective callback xs_kf_create_sharded takes; user = the comm handle.  Errors print and exit(-1), like every
  * runtime failure of the reference (Common/include/cx.h:125-130). */
 void xs_rccl_collective(void *user, int op, void *dev_ptr, long count);
-/* the same with a status instead of exit: 0, or the ncclResult_t */
+/* the same with a status instead of exit: 0, or the ncclResult_t (ops 0 - 2: all-reduce) */
 int xs_rccl_all_reduce(void *comm, int op, void *dev_ptr, long count);
+/* op 3 (include/xslam_amd_pipeline.h): desc = host array {device buffer address, byte offsets of the count + 1 part boundaries}; every
+ * rank's part is broadcast from its owner inside one ncclGroupStart / ncclGroupEnd */
+int xs_rccl_gatherv(void *comm, const long long *desc, long count);
 int xs_rccl_rank(void *comm);
 int xs_rccl_count(void *comm);
 /* ncclGetVersion */

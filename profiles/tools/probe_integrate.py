@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "sweep":
     sys.exit(0)
 import numpy as np, torch
 capi = importlib.import_module('x-slam_amd.capi'); synth = importlib.import_module('x-slam_amd.synth')
-H, W, n = synth.HEIGHT, synth.WIDTH, 512
+H, W, n = synth.HEIGHT, synth.WIDTH, int(os.environ.get('XS_PROBE_N', '512'))
 prm = synth.s1_params(n); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel_size"])); trunc = synth.tranc_dist(prm)
 value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
 grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
@@ -29,10 +29,11 @@ for k in range(24):
     capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
     T = synth.s1_transforms(k, prm)
     counter.zero_()
-    capi.integrate_scaled(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, updated=counter, depth_max=dmax, workspace=ws, stream=s)
+    capi.integrate_scaled_ex(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, 64, updated=counter, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
+    classes = [int(x) for x in ws[192:204].view(torch.int32).cpu().numpy()]
     dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0
     if k >= 4:
         times.append(dt.value * 1e3); bricks.append(int(ws[:4].view(torch.int32).item())); Us.append(int(counter.item()))
 b, U, t = np.median(bricks), np.median(Us), np.median(times)
-print(f"bricks listed {b:.0f}  voxels written {U:.0f}  kernel {t:.1f} us  ->  {24 * U / t / 1e6:.2f} TB/s algorithmic; written / listed-brick voxel capacity unknown here")
+print(f"bricks listed {b:.0f}  voxels written {U:.0f}  kernel {t:.1f} us  ->  {24 * U / t / 1e6:.2f} TB/s algorithmic; boxes free / nothing / walk (last frame) {classes}")

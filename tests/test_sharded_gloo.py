@@ -1,6 +1,6 @@
 """CPU, world_size 2 over gloo: the multi-GPU protocol of x-slam_amd/sharded.py — z-slab bounds and
 halo, pixel-row shards, the 55-double all-reduce, and the raycast composite (min of first-event
-keys, masked int32 sum of the maps) — driven with the CPU oracle's kernels in place of the HIP
+keys, then the gather of every rank's packed owned pixels) — driven with the CPU oracle's kernels in place of the HIP
 ones (there is no GPU here).  Sharded and unsharded runs of the same protocol must agree: bit
 for bit on the volume and the composed maps, to double rounding on the ICP sums."""
 import importlib
@@ -57,6 +57,7 @@ class ProtocolKinFu:
         self.frame_id = 0
         self.violations = 0
         self.U = 0
+        self.bytes_sum_form = self.bytes_gather_form = 0.0
 
     def allreduce(self, op, arr):
         if self.world == 1:
@@ -122,8 +123,35 @@ class ProtocolKinFu:
         for m in (vm, nm):
             for p in range(3):
                 m[p * H:(p + 1) * H][~mine] = 0
-        vm = self.allreduce(self.sh.OP_SUM_I32, vm.view(np.int32).copy()).view(np.float32)
-        nm = self.allreduce(self.sh.OP_SUM_I32, nm.view(np.int32).copy()).view(np.float32)
+        # the owner-compacted exchange (KinectFusionReconstruction::CalculatePointCloud, shard mode): every rank packs the pixels it owns —
+        # {pixel index, vertex x / y / z (re, im), normal x / y / z (re, im)}: 13 words —, the counts travel as an int32 sum with one non-zero
+        # entry per rank, the packs are gathered at the offsets every rank derives from the counts, and a scatter writes them into the maps
+        ring = 2.0 * (self.world - 1) / self.world if self.world > 1 else 0.0
+        self.bytes_sum_form += ring * (keys.nbytes + vm.nbytes + nm.nbytes)           # what round 3's form (an int32 sum of both maps) moved
+        self.bytes_gather_form += ring * keys.nbytes
+        if self.world > 1:
+            import torch
+            idx = np.flatnonzero(mine.reshape(-1)).astype(np.int32)
+            ys, xs = idx // W, idx % W
+            pack = np.empty((len(idx), 13), np.int32)
+            pack[:, 0] = idx
+            for q in range(3):
+                pack[:, 1 + 2 * q:3 + 2 * q] = vm[q * H:(q + 1) * H][ys, xs].view(np.int32)
+                pack[:, 7 + 2 * q:9 + 2 * q] = nm[q * H:(q + 1) * H][ys, xs].view(np.int32)
+            counts = np.zeros(self.world, np.int32)
+            counts[self.rank] = len(idx)
+            counts = self.allreduce(self.sh.OP_SUM_I32, counts)
+            off = [0] + [int(v) for v in np.cumsum(counts.astype(np.int64)) * 52]
+            buf = torch.zeros(max(off[-1], 1), dtype=torch.uint8)
+            buf[off[self.rank]:off[self.rank + 1]] = torch.from_numpy(pack.reshape(-1).view(np.uint8).copy())
+            self.sh.gatherv_tensor(self.dist, torch, buf, off)
+            self.bytes_gather_form += ring * counts.nbytes + (off[-1] - (off[self.rank + 1] - off[self.rank]))
+            got = buf[:off[-1]].numpy().view(np.int32).reshape(-1, 13)
+            assert len(np.unique(got[:, 0])) == len(got)          # every pixel has one owner at most
+            gy, gx = got[:, 0] // W, got[:, 0] % W
+            for q in range(3):
+                vm[q * H:(q + 1) * H][gy, gx] = got[:, 1 + 2 * q:3 + 2 * q].view(np.float32)
+                nm[q * H:(q + 1) * H][gy, gx] = got[:, 7 + 2 * q:9 + 2 * q].view(np.float32)
         nohit = (((mk & 1) == 1) | (mk == 0x7FFFFFFF)).reshape(H, W)
         qnan = np.array([0x7FFFFFFF], np.uint32).view(np.float32)[0]
         for m in (vm, nm):
@@ -164,6 +192,10 @@ def _worker(rank, world, port, n, nframes):
     import torch
     u = torch.tensor([part.U], dtype=torch.int64)
     dist.all_reduce(u)
+    # the composite's bytes, summed over the ranks: the gathered packs against round 3's sum of the maps
+    bb = torch.tensor([part.bytes_gather_form, part.bytes_sum_form], dtype=torch.float64)
+    dist.all_reduce(bb)
+    assert 0 < bb[0].item() <= 0.55 * bb[1].item(), bb
     if same_pose:
         assert int(u.item()) == whole.U and part.hits == whole.hits
         plane = n * n

@@ -110,6 +110,38 @@ def test_sharded_equals_single(dev, world, rows_sharded):
     single.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_composite_by_gather_equals_the_sum_of_maps_and_halves_the_bytes(dev, world):
+    """The raycast composite as an owner-compacted exchange (every rank packs the pixels it owns, the packs are gathered and scattered:
+    shard_composite_gather, the default) against the int32 sum of the maps (round 3): the same poses, counts, ICP sums and composed maps on
+    every rank, bit for bit, over six frames — and at most 0.55 of the bytes received, summed over the ranks and counting the min-key
+    all-reduce both forms share (a ring all-reduce moves every pixel's 48 bytes twice, the gather each owned pixel's 52 once)."""
+    torch, pl, sh = dev
+    prm = synth.s1_params(96)
+    frames = list(range(6))
+    s_g, g = run_world(torch, sh, dict(prm, shard_composite_gather=True), world, frames)
+    s_s, a = run_world(torch, sh, dict(prm, shard_composite_gather=False), world, frames)
+    for r in range(world):
+        assert np.array_equal(g[r][0], a[r][0]) and g[r][1] == a[r][1] and g[r][2] == a[r][2]
+        assert np.array_equal(g[r][3], a[r][3])
+        for which in ("vmaps_g_prev", "nmaps_g_prev"):
+            for level in range(3):
+                # every pixel with a value, all three planes (the y and z planes of a pixel without one are not written: they keep what the buffer held)
+                x, y = s_g[r].map(which, level), s_s[r].map(which, level)
+                rows_ = x.shape[0] // 3
+                valid = np.isfinite(y[:rows_, :, 0])
+                assert np.array_equal(valid, np.isfinite(x[:rows_, :, 0])), (r, which, level)
+                for p_ in range(3):
+                    assert np.array_equal(x[p_ * rows_:(p_ + 1) * rows_][valid].view(np.int32), y[p_ * rows_:(p_ + 1) * rows_][valid].view(np.int32)), (r, which, level, p_)
+    assert g[0][2] > 0.5 * synth.HEIGHT * synth.WIDTH
+    # bytes received, summed over the ranks (in this scene one rank owns nearly every hit: it receives next to nothing and the others all of
+    # it, where the ring all-reduce loads every rank alike)
+    bg, bs = sum(s.composite_bytes() for s in s_g), sum(s.composite_bytes() for s in s_s)
+    assert 0 < bg <= 0.55 * bs, (bg, bs)
+    for s in s_g + s_s:
+        s.close()
+
+
 def test_sharded_sign_map_changes_nothing(dev):
     """Every rank keeps a sign map of the planes it stores (owned slab + halo, marked by its own integrate calls) and its slab march
     evaluates only the iterations that map leaves: poses, counts and ICP sums of a three-rank run with and without, bit for bit."""
@@ -185,10 +217,18 @@ def test_single_rank_composite_path(dev):
             assert np.array_equal(na, nb)
             for p in range(3):
                 assert np.array_equal(a[p * rows:(p + 1) * rows][~na], b[p * rows:(p + 1) * rows][~nb])
-    # per frame: one min over W*H keys, one sum over both level-0 model maps (contiguous allocation)
+    # per frame: one min over W*H keys, the sum of the owned-pixel counts (one per rank), the gather of the packed owned pixels
+    per_frame = calls[-3:]
+    assert per_frame[0] == (1, 640 * 480) and per_frame[1] == (2, 1) and per_frame[2] == (3, 1)
+    # ... and with shard_composite_gather: false, round 3's form: one sum over both level-0 model maps (contiguous allocation), same maps
+    calls.clear()
+    summed = sh.ShardedKinectFusion(dict(prm, force_shard_composite=True, shard_composite_gather=False), 0, 1, collective=ident)
+    for k in frames:
+        assert summed.process_frame(torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()) == 1
     per_frame = calls[-2:]
     assert per_frame[0] == (1, 640 * 480) and per_frame[1][0] == 2 and per_frame[1][1] == 2 * 3 * 480 * (640 * 8 // 4)
-    single.close(); forced.close()
+    assert np.array_equal(summed.world2camera(), forced.world2camera()) and summed.last_hits() == forced.last_hits()
+    single.close(); forced.close(); summed.close()
 
 
 def test_sharded_checkpoint_roundtrip(dev, tmp_path):
@@ -248,8 +288,8 @@ def test_sharded_checkpoint_roundtrip(dev, tmp_path):
 def test_cpp_host_runs_shard_mode_over_rccl_without_python():
     """x-slam_amd/smoke_rccl (host/smoke_rccl.cpp): a C++ program that creates an RCCL communicator through
     libxslam_rccl.so (include/xslam_amd_rccl.h), hands xs_rccl_collective to xs_kf_create_sharded and tracks four frames
-    of a synthetic room corner in shard mode — world = 1 here (one GPU), so the raycast composite's collectives (two per
-    frame) are single-rank ncclAllReduce calls on the orchestrator's stream; with N ranks (`smoke_rccl <rank> <N> <id-file>`,
+    of a synthetic room corner in shard mode — world = 1 here (one GPU), so the raycast composite's collectives (three per
+    frame: min of the keys, sum of the owned-pixel counts, gather of the packed owned pixels) are single-rank RCCL calls on the orchestrator's stream; with N ranks (`smoke_rccl <rank> <N> <id-file>`,
     one process per GPU) the 12 per-frame ICP all-reduces join them."""
     import json
     import os
@@ -263,7 +303,7 @@ def test_cpp_host_runs_shard_mode_over_rccl_without_python():
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["tracked"] == 1 and out["collective_calls"] == 8 and out["rccl_version"] > 0
+    assert out["tracked"] == 1 and out["collective_calls"] == 12 and out["rccl_version"] > 0 and len(out["world2camera"]) == 32
 
 
 def _gpu_count():
@@ -290,10 +330,18 @@ def test_two_ranks_over_rccl_on_two_gpus():
         idf = os.path.join(tmp, "rccl_id")
         procs = [subprocess.Popen([exe, str(r), "2", idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
         outs = [p.communicate(timeout=600) for p in procs]
+    poses = []
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (p.returncode, so[-1500:], se[-1500:])
         o = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
-        assert o["count"] == 2 and o["tracked"] == 1 and o["collective_calls"] == 4 * 2 + 3 * 12
+        assert o["count"] == 2 and o["tracked"] == 1 and o["collective_calls"] == 4 * 3 + 3 * 12
+        poses.append(np.array(o["world2camera"], np.float32))
+    # both ranks hold the same pose, bit for bit, and it is the one-GPU run's up to the association of the all-reduced double sums
+    one = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0, (one.stdout[-1500:], one.stderr[-1500:])
+    ref = np.array(json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["world2camera"], np.float32)
+    assert np.array_equal(poses[0].view(np.int32), poses[1].view(np.int32))
+    assert np.allclose(poses[0], ref, rtol=0, atol=2e-7)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--native-rccl", "--size", "256",
                         "--reloc-size", "256", "--no-alt"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])

@@ -78,6 +78,9 @@ _SIGS = {
                                   C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "xs_raycast_compose_entry_bytes": (_sz, []),
+    "xs_raycast_compose_pack": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "xs_raycast_compose_scatter": (C.c_int, [_vp, C.c_long, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_resize_pyramid": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "xs_tsdf_gauss_newton_terms": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, C.c_int,
                                              C.c_int, _vp, _vp, _vp]),
@@ -475,6 +478,19 @@ def raycast_compose_mask(own_keys, min_keys, vmap, nmap, map_step, rows, cols, s
 
 def raycast_compose_finish(min_keys, vmap, nmap, map_step, rows, cols, hits=None, stream=None):
     check(_lib.xs_raycast_compose_finish(_ptr(min_keys), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
+
+
+def raycast_compose_entry_bytes():
+    return _lib.xs_raycast_compose_entry_bytes()
+
+
+def raycast_compose_pack(own_keys, min_keys, vmap, nmap, map_step, rows, cols, entries, count, stream=None):
+    """The pixels this rank owns with a vertex, packed (52-byte entries); *count (int32, zeroed by the caller) advances by their number."""
+    check(_lib.xs_raycast_compose_pack(_ptr(own_keys), _ptr(min_keys), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(entries), _ptr(count), _stream(stream)))
+
+
+def raycast_compose_scatter(entries, n, vmap, nmap, map_step, rows, cols, stream=None):
+    check(_lib.xs_raycast_compose_scatter(_ptr(entries), int(n), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _stream(stream)))
 
 
 def icp_workspace_bytes():

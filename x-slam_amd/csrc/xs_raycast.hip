@@ -890,6 +890,86 @@ __global__ void __launch_bounds__(256) k_compose_finish(const int *min_keys, cfl
         }
     }
 }
+// ---- owner-compacted exchange of the composite (round 4) ---------------------------------------------------------------------------
+// Adding the ranks' maps moves every pixel's 48 bytes through a ring all-reduce although one rank at most has anything but zeros there:
+// 2 (N - 1) / N x 14.7 MB per rank and frame.  Instead every rank packs the pixels it owns — {pixel index, vertex (3 complex), normal
+// (3 complex)}: 13 words — the ranks' packs are gathered (variable sizes: the counts travel first, as an int32 sum with one non-zero
+// entry per rank) and a scatter writes them into the maps: (N - 1) / N x 52 bytes x hits received per rank, about half.
+enum { COMPOSE_ENTRY_WORDS = 13 };
+__global__ void __launch_bounds__(256) k_compose_pack(const int *own_keys, const int *min_keys, const cfloat *vmap, const cfloat *nmap, size_t mstep, int rows,
+                                                      int cols, unsigned *entries, int *count) {
+    // one workgroup-wide slot reservation per 256 pixels: a ballot per wave, one LDS exchange, one atomic
+    __shared__ unsigned s_base[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p0 = blockIdx.x * 256; p0 < rows * cols; p0 += gridDim.x * 256) {
+        const int p = p0 + tid;
+        bool mine = false;
+        int x = 0, y = 0;
+        if (p < rows * cols) {
+            const int k = own_keys[p], m = min_keys[p];
+            mine = k == m && !(k & 1) && k != 0x7fffffff;
+            y = p / cols; x = p - y * cols;
+        }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(mine);
+        if (lane == 0) s_base[wave] = (unsigned)__popcll(b);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned n0 = s_base[0], n1 = s_base[1], n2 = s_base[2], n3 = s_base[3];
+            const unsigned tot = n0 + n1 + n2 + n3;
+            const unsigned base = tot ? (unsigned)atomicAdd(count, (int)tot) : 0u;
+            s_base[0] = base; s_base[1] = base + n0; s_base[2] = base + n0 + n1; s_base[3] = base + n0 + n1 + n2;
+        }
+        __syncthreads();
+        if (mine) {
+            unsigned *e = entries + (size_t)(s_base[wave] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) * COMPOSE_ENTRY_WORDS;
+            e[0] = (unsigned)p;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const cfloat v = row_ptr(vmap, mstep, y + q * rows)[x], n = row_ptr(nmap, mstep, y + q * rows)[x];
+                e[1 + 2 * q] = __float_as_uint(v.re); e[2 + 2 * q] = __float_as_uint(v.im);
+                e[7 + 2 * q] = __float_as_uint(n.re); e[8 + 2 * q] = __float_as_uint(n.im);
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_compose_scatter(const unsigned *entries, long n, cfloat *vmap, cfloat *nmap, size_t mstep, int rows, int cols) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        const unsigned *e = entries + i * COMPOSE_ENTRY_WORDS;
+        const unsigned p = e[0];
+        if (p >= (unsigned)(rows * cols)) continue;   // (never: the packs hold pixel indices)
+        const int y = (int)(p / (unsigned)cols), x = (int)(p - (unsigned)y * (unsigned)cols);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            row_ptr(vmap, mstep, y + q * rows)[x] = cfloat(__uint_as_float(e[1 + 2 * q]), __uint_as_float(e[2 + 2 * q]));
+            row_ptr(nmap, mstep, y + q * rows)[x] = cfloat(__uint_as_float(e[7 + 2 * q]), __uint_as_float(e[8 + 2 * q]));
+        }
+    }
+}
+/* The pixels this rank owns with a vertex (own key == min key, event with a vertex), packed: entries_dev receives 13 32-bit words per
+ * pixel {pixel index y * cols + x, vertex x / y / z (re, im), normal x / y / z (re, im)} in no particular order, *count_dev is advanced
+ * by their number (the caller zeroes it; room for rows * cols entries). */
+extern "C" int xs_raycast_compose_pack(const int *own_keys_dev, const int *min_keys_dev, const float *vmap, const float *nmap, size_t map_step, int rows,
+                                       int cols, void *entries_dev, int *count_dev, void *stream) {
+    if (!own_keys_dev || !min_keys_dev || !vmap || !nmap || !entries_dev || !count_dev) return xs_set_error(hipErrorInvalidValue, "xs_raycast_compose_pack: null pointer");
+    if (rows <= 0 || cols <= 0) return 0;
+    const int blocks = div_up(rows * cols, 256);
+    hipLaunchKernelGGL(k_compose_pack, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, (hipStream_t)stream, own_keys_dev, min_keys_dev, (const cfloat *)vmap,
+                       (const cfloat *)nmap, map_step, rows, cols, (unsigned *)entries_dev, count_dev);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+/* n packed entries (any ranks') written into the maps */
+extern "C" int xs_raycast_compose_scatter(const void *entries_dev, long n, float *vmap, float *nmap, size_t map_step, int rows, int cols, void *stream) {
+    if (!entries_dev || !vmap || !nmap) return xs_set_error(hipErrorInvalidValue, "xs_raycast_compose_scatter: null pointer");
+    if (n <= 0 || rows <= 0 || cols <= 0) return 0;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_compose_scatter, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, (const unsigned *)entries_dev, n, (cfloat *)vmap,
+                       (cfloat *)nmap, map_step, rows, cols);
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+extern "C" size_t xs_raycast_compose_entry_bytes(void) { return COMPOSE_ENTRY_WORDS * sizeof(unsigned); }
 /* keep this rank's vertex / normal only where it owns the ray's first event (own key == min key) */
 extern "C" int xs_raycast_compose_mask(const int *own_keys_dev, const int *min_keys_dev, float *vmap, float *nmap, size_t map_step, int rows,
                                        int cols, void *stream) {

@@ -43,6 +43,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (scale_done_next_) (void)hipEventDestroy(scale_done_next_);
     if (scale_done_) (void)hipEventDestroy(scale_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
+    if (gather_counts_host_) (void)hipHostFree(gather_counts_host_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
     if (pinned_records_) (void)hipHostFree(pinned_records_);
     if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
@@ -128,6 +129,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_lookahead = config.as<int>("icp_lookahead", 1);
     icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
+    shard_composite_gather = config.as<bool>("shard_composite_gather", true);
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
     if (sign_map_on()) {
@@ -1078,8 +1080,41 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     xs_raycast_set_signmap(nullptr, 0, 0.0f);
     hipSafeCall(hipMemcpyAsync(ray_min_keys_.ptr(), ray_keys_.ptr(), (size_t)rows * cols * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (collective) collective(collective_user, 1, ray_min_keys_.ptr(), (long)rows * cols);
+    // (what a rank receives: a ring all-reduce of S bytes over N ranks moves 2 (N - 1) / N x S through every rank, a gather the other ranks' parts)
+    const double ring = shard_count > 1 ? 2.0 * (shard_count - 1) / shard_count : 0.0;
+    composite_bytes_ += (long long)(ring * (double)rows * cols * sizeof(int));
     check_rc(xs_raycast_compose_mask(ray_keys_.ptr(), ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, st), "raycast");
-    if (collective) {
+    if (collective && shard_composite_gather) {
+        // Owner-compacted exchange: every rank packs the pixels it owns (52 bytes each), the counts travel as an int32 sum with one non-zero
+        // entry per rank, the packs are gathered at the offsets every rank derives from the counts, and a scatter writes them into the maps.
+        // One host wait per frame (the counts); half the bytes of adding the maps (a ring all-reduce moves every pixel's 48 bytes twice).
+        const int n_ranks = shard_count;
+        const size_t eb = xs_raycast_compose_entry_bytes();
+        if (!gather_buf_.ptr()) {
+            gather_buf_.create((size_t)rows * cols * eb);       // every pixel has at most one owner: the gathered packs fit
+            pack_buf_.create((size_t)rows * cols * eb);
+            gather_counts_.create((size_t)n_ranks);
+            hipSafeCall(hipHostMalloc((void **)&gather_counts_host_, (size_t)n_ranks * sizeof(int)));
+        }
+        hipSafeCall(hipMemsetAsync(gather_counts_.ptr(), 0, (size_t)n_ranks * sizeof(int), st));
+        check_rc(xs_raycast_compose_pack(ray_keys_.ptr(), ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols,
+                                         pack_buf_.ptr(), gather_counts_.ptr() + shard_rank, st), "raycast");
+        collective(collective_user, 2, gather_counts_.ptr(), n_ranks);
+        hipSafeCall(hipMemcpyAsync(gather_counts_host_, gather_counts_.ptr(), (size_t)n_ranks * sizeof(int), hipMemcpyDeviceToHost, st));
+        hipSafeCall(hipStreamSynchronize(st));
+        std::vector<long long> desc((size_t)n_ranks + 2);
+        desc[0] = (long long)(size_t)gather_buf_.ptr();
+        desc[1] = 0;
+        for (int r = 0; r < n_ranks; ++r) desc[(size_t)r + 2] = desc[(size_t)r + 1] + (long long)gather_counts_host_[r] * (long long)eb;
+        const long long total = desc[(size_t)n_ranks + 1];
+        if (total > (long long)rows * cols * (long long)eb) { std::cout << "error::KinectFusionReconstruction, composite: more owned pixels than pixels" << std::endl; exit(-1); }
+        const long long mine = desc[(size_t)shard_rank + 2] - desc[(size_t)shard_rank + 1];
+        if (mine > 0)
+            hipSafeCall(hipMemcpyAsync(gather_buf_.ptr() + desc[(size_t)shard_rank + 1], pack_buf_.ptr(), (size_t)mine, hipMemcpyDeviceToDevice, st));
+        collective(collective_user, 3, desc.data(), n_ranks);   // gather-v: afterwards every rank holds every rank's part
+        composite_bytes_ += total - mine + (long long)(ring * n_ranks * sizeof(int));
+        check_rc(xs_raycast_compose_scatter(gather_buf_.ptr(), (long)(total / (long long)eb), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, st), "raycast");
+    } else if (collective) {
         const long words = (long)(xyz_g_d.step() / 4) * xyz_g_d.rows();
         const bool adjacent = normal_g_d.step() == xyz_g_d.step() && normal_g_d.rows() == xyz_g_d.rows() &&
                               (const char *)normal_g_d.ptr() == (const char *)xyz_g_d.ptr() + xyz_g_d.step() * (size_t)xyz_g_d.rows();
@@ -1088,6 +1123,7 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
             collective(collective_user, 2, xyz_g_d.ptr(), words);
             collective(collective_user, 2, normal_g_d.ptr(), words);
         }
+        composite_bytes_ += (long long)(ring * 2.0 * words * 4.0);
     }
     check_rc(xs_raycast_compose_finish(ray_min_keys_.ptr(), &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols,
                                        hits_counter_, st), "raycast");

@@ -66,6 +66,7 @@ public:
     // coverage test and the kernel starts ~8 us earlier on the others: +0.8 % frames/s, inside the noise (profiles/r03_ab_integrate_post_late.txt)
     // — still off by default; xs_kf_posted_integrate_counts says how many launches were given their pose and how many were told to leave.
     bool integrate_post_pose = false;
+    long long composite_bytes_ = 0;   // bytes this rank received through the raycast composite's collectives so far (ring all-reduce: 2 (N - 1) / N x size; gather: the other ranks' parts)
     long long posted_accepted_ = 0, posted_refused_ = 0;   // posted integrate launches that were given their pose / told to leave (xs_kf_posted_integrate_counts)
     bool integrate_post_early = false;       // YAML integrate_post_early: the posted launch goes in one ICP iteration earlier (list from a pose two updates old)
     float integrate_classify_slack = 2.0f;   // YAML integrate_classify_slack: how much wider than its own the list's frustum slack is (1 = every frame falls back)
@@ -244,6 +245,11 @@ private:
     std::vector<DeviceArray2D<float>> vreal_next_d, nreal_next_d;
     DeviceArray2D<float> depthRawScaled_next_d;
     DeviceArray<float> depth_max_next_;
+    // shard mode, raycast composite by owner-compacted exchange (YAML shard_composite_gather, default true; false = the int32 sum of the maps)
+    bool shard_composite_gather = true;
+    DeviceArray<unsigned char> gather_buf_, pack_buf_;   // the ranks' packed owned pixels (52 bytes each), all of them / this rank's
+    DeviceArray<int> gather_counts_;                     // [rank] = owned pixels with a vertex
+    int *gather_counts_host_ = nullptr;                  // pinned
     DeviceArray<unsigned char> depth_tiles_, depth_tiles_next_;   // per-tile depth range of the frame (xs_scale_depth_tiles -> the integrate call's brick classes)
     hipEvent_t surface_done_next_ = nullptr, scale_done_next_ = nullptr;
     bool real_maps_valid_next_ = false, scale_recorded_next_ = false;

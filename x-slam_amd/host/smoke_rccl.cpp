@@ -74,14 +74,18 @@ int main(int argc, char **argv) {
     double drift = 0;
     for (int i = 0; i < 3; ++i) drift += (double)pose[(i * 4 + 3) * 2] * pose[(i * 4 + 3) * 2];
     printf("{\"rank\": %d, \"count\": %d, \"rccl_version\": %d, \"tracked\": %d, \"collective_calls\": %ld, \"U_last\": %lld, \"hits_last\": %lld, "
-           "\"static_camera_translation_sq\": %.3e}\n", rank, count, xs_rccl_version(), ok, g_calls, U, hits, drift);
+           "\"static_camera_translation_sq\": %.3e, \"composite_bytes\": %lld, \"world2camera\": [", rank, count, xs_rccl_version(), ok, g_calls, U, hits, drift,
+           xs_kf_composite_bytes(kf));
+    for (int i = 0; i < 32; ++i) printf("%s%.9g", i ? ", " : "", (double)pose[i]);   // (9 significant digits: a float round-trips)
+    printf("]}\n");
     xs_kf_destroy(kf);
     (void)hipFree(dd);
     xs_rccl_comm_destroy(g_comm);
-    // four frames: 4 raycast composites (2 collectives each); with more than one rank also 3 tracked frames x 12 ICP all-reduces
+    // four frames: 4 raycast composites (3 collectives each: the min of the keys, the sum of the owned-pixel counts, the gather of the
+    // packed owned pixels); with more than one rank also 3 tracked frames x 12 ICP all-reduces
     // (a single rank evaluates every pixel row itself).  The camera does not move: the estimate may settle a few millimetres off
     // (6 cm voxels round the room's corners), not more.
-    const long expect_calls = 4 * 2 + (count > 1 ? 3 * 12 : 0);
+    const long expect_calls = 4 * 3 + (count > 1 ? 3 * 12 : 0);
     const bool good = ok == 1 && g_calls == expect_calls && hits > 0.8 * W * H && drift < 1e-4;
     return good ? 0 : 1;
 }

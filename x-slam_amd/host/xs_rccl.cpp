@@ -73,15 +73,34 @@ int xs_rccl_all_reduce(void *comm, int op, void *dev_ptr, long count) {
     switch (op) {
         case 0: dt = ncclDouble; ro = ncclSum; break;   // ICP normal equations (55), Gauss-Newton sums (29), Hessian sums (4)
         case 1: dt = ncclInt32; ro = ncclMin; break;    // first raycast event per pixel
-        case 2: dt = ncclInt32; ro = ncclSum; break;    // owner-select of the vertex / normal maps (bit patterns, one non-zero owner)
+        case 2: dt = ncclInt32; ro = ncclSum; break;    // the ranks' owned-pixel counts (or, shard_composite_gather: false, the maps as bit patterns)
         default: g_err = "xs_rccl_all_reduce: bad op"; return -1;
     }
     const ncclResult_t r = ncclAllReduce(dev_ptr, dev_ptr, (size_t)count, dt, ro, c->comm, c->stream);
     return r == ncclSuccess ? 0 : fail(r, "ncclAllReduce");
 }
 
+// op 3 of the orchestrator's callback: the ranks' variable-size parts of one device buffer, each broadcast from its owner — one group
+// call, so RCCL schedules the N broadcasts together.  desc: host array {buffer address, offset[0], .., offset[count]} (bytes).
+int xs_rccl_gatherv(void *comm, const long long *desc, long count) {
+    if (!comm || !desc) { g_err = "xs_rccl_gatherv: bad arguments"; return -1; }
+    Comm *c = static_cast<Comm *>(comm);
+    if (count != c->count) { g_err = "xs_rccl_gatherv: the descriptor is for another number of ranks"; return -1; }
+    char *base = reinterpret_cast<char *>((size_t)desc[0]);
+    ncclResult_t r = ncclGroupStart();
+    if (r != ncclSuccess) return fail(r, "ncclGroupStart");
+    for (int k = 0; k < c->count; ++k) {
+        const long long a = desc[1 + k], b = desc[2 + k];
+        if (b <= a) continue;
+        r = ncclBroadcast(base + a, base + a, (size_t)(b - a), ncclChar, k, c->comm, c->stream);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(r, "ncclBroadcast"); }
+    }
+    r = ncclGroupEnd();
+    return r == ncclSuccess ? 0 : fail(r, "ncclGroupEnd");
+}
+
 void xs_rccl_collective(void *user, int op, void *dev_ptr, long count) {
-    if (xs_rccl_all_reduce(user, op, dev_ptr, count) != 0) {
+    if ((op == 3 ? xs_rccl_gatherv(user, static_cast<const long long *>(dev_ptr), count) : xs_rccl_all_reduce(user, op, dev_ptr, count)) != 0) {
         printf("RCCL error(%s)\n", g_err.c_str());
         exit(-1);
     }

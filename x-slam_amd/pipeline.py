@@ -55,6 +55,7 @@ _SIGS = {
     "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
     "xs_kf_debug_post_delay": (None, [_vp, C.c_int, C.c_int]),
+    "xs_kf_composite_bytes": (C.c_longlong, [_vp]),
     "xs_kf_rebuild_sign_map": (None, [_vp]),
     "xs_kf_hint_next_frame": (None, [_vp, _vp, _sz]),
     "xs_kf_posted_integrate_counts": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -285,6 +286,10 @@ class KinectFusion:
     def debug_post_delay(self, min_us, max_us):
         """Test aid: a random host sleep of [min_us, max_us] microseconds in front of every ICP pose post."""
         _lib.xs_kf_debug_post_delay(self.h, int(min_us), int(max_us))
+
+    def composite_bytes(self):
+        """Shard mode: bytes this rank received through the raycast composite's collectives so far (see xs_kf_composite_bytes)."""
+        return int(_lib.xs_kf_composite_bytes(self.h))
 
     def posted_integrate_counts(self):
         """(accepted, refused) posted integrate launches so far (integrate_post_pose)."""

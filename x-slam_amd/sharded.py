@@ -7,7 +7,11 @@ xGMI on the GPU box):
   op 0  sum of 55 doubles      — the 27 complex<double> ICP normal-equation sums + inlier count,
                                  once per ICP iteration (440 bytes, latency-bound)
   op 1  min of W*H int32       — first raycast event along every ray
-  op 2  sum of int32 patterns  — vertex / normal maps, only the owning rank non-zero
+  op 2  sum of int32           — the ranks' owned-pixel counts (one non-zero entry per rank); with shard_composite_gather: false the
+                                 vertex / normal maps as bit patterns, only the owning rank non-zero
+  op 3  gather of variable parts — the ranks' packed owned pixels (52 bytes each: pixel index, vertex, normal), each rank's part at the
+                                 offset every rank derives from the counts: one broadcast per rank (a ring all-reduce of the maps moves
+                                 every pixel's 48 bytes twice; this moves each owned pixel's 52 bytes once)
 
 No volume data ever crosses ranks: halo planes are integrated redundantly by both neighbours
 (the update is per voxel and deterministic, so the bits agree).
@@ -23,7 +27,7 @@ HALO = 6  # planes each side; KinectFusionReconstruction::HALO
 
 _CB = pl.COLLECTIVE_CB
 
-OP_SUM_F64, OP_MIN_I32, OP_SUM_I32 = 0, 1, 2
+OP_SUM_F64, OP_MIN_I32, OP_SUM_I32, OP_GATHERV = 0, 1, 2, 3
 _TYPESTR = {OP_SUM_F64: "<f8", OP_MIN_I32: "<i4", OP_SUM_I32: "<i4"}
 
 
@@ -37,6 +41,20 @@ def slab_bounds(rank, world, Z, halo=HALO):
 
 def row_bounds(rank, world, rows):
     return rows * rank // world, rows * (rank + 1) // world
+
+
+def gatherv_descriptor(ptr, world):
+    """(device buffer address, [byte offset of rank r's part for r = 0 .. world]) from the host array the orchestrator hands op 3."""
+    words = (C.c_longlong * (world + 2)).from_address(int(ptr))
+    return int(words[0]), [int(words[1 + r]) for r in range(world + 1)]
+
+
+def gatherv_tensor(dist, torch, buf, offsets):
+    """Every rank's part of the uint8 tensor `buf` (rank r's bytes offsets[r] .. offsets[r + 1]) to every rank: one broadcast per part."""
+    for r in range(len(offsets) - 1):
+        if offsets[r + 1] > offsets[r]:
+            dist.broadcast(buf[offsets[r]:offsets[r + 1]], src=r)
+    return buf
 
 
 def reduce_tensor(dist, op, t):
@@ -69,6 +87,17 @@ class LocalWorld:
 
     def collective_for(self, rank):
         def cb(_user, op, ptr, count):
+            if op == OP_GATHERV:
+                base, off = gatherv_descriptor(ptr, count)
+                t = self.torch.as_tensor(_DevView(base, max(off[-1], 1), "|u1"), device="cuda")
+                self.slots[rank] = t
+                self.barrier.wait()
+                for r in range(count):          # every rank copies every other rank's part out of that rank's buffer
+                    if r != rank and off[r + 1] > off[r]:
+                        t[off[r]:off[r + 1]].copy_(self.slots[r][off[r]:off[r + 1]])
+                self.torch.cuda.synchronize()
+                self.barrier.wait()
+                return
             t = device_tensor(self.torch, ptr, count, op)
             self.slots[rank] = t
             self.barrier.wait()
@@ -164,6 +193,14 @@ class ShardedKinectFusion(pl.KinectFusion):
                         # per-call cost of wrapping a raw pointer (tens of microseconds) is paid once
 
             def collective(_user, op, ptr, count):
+                if op == OP_GATHERV:
+                    base, off = gatherv_descriptor(ptr, count)
+                    key = (base, -1, OP_GATHERV)
+                    t = views.get(key)
+                    if t is None:     # the whole gather buffer (the orchestrator allocates it once: room for every pixel)
+                        t = views[key] = self._torch.as_tensor(_DevView(base, self.width * self.height * 52, "|u1"), device="cuda")
+                    gatherv_tensor(self._dist, self._torch, t, off)
+                    return
                 key = (int(ptr), int(count), int(op))
                 t = views.get(key)
                 if t is None:
