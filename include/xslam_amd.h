@@ -239,6 +239,15 @@ int xs_signmap_rebuild_slab(void *signmap, const int *res, int shift, float tran
 void xs_integrate_set_signmap(void *signmap);
 void xs_raycast_set_signmap(const void *signmap, int shift, float tranc_dist);
 
+/* The one-launch form of xs_raycast (workspace + sign map) can build the model-map pyramid too — levels 1 and 2 of the vertex and of the
+ * normal map, the values xs_resize_pyramid writes (resizeVMap / resizeNMap twice, Map.h:46-54): every workgroup halves its own pixel tile
+ * twice, so the frame's tail loses a launch.  xs_raycast_set_pyramid names the four maps for the next xs_raycast call of the thread (NULLs:
+ * none); xs_raycast_pyramid_built() tells whether that call built them (0: launch xs_resize_pyramid as before).
+ * xs_raycast_set_completion_event: an event that rides on that launch's dispatch (its completion), or NULL. */
+void xs_raycast_set_pyramid(float *vmap1, float *nmap1, size_t step1, float *vmap2, float *nmap2, size_t step2);
+int xs_raycast_pyramid_built(void);
+void xs_raycast_set_completion_event(void *event);
+
 /* Slab form for a z-sharded volume (the reference is single-GPU; per-ray semantics are those of
  * RayCaster.cu:197-310).  value / grad hold planes [zs0, zs1) = owned slab + halo (6 planes);
  * only march steps whose sample voxel lies in the owned planes [z0, z1) are evaluated.

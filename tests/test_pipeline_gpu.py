@@ -189,6 +189,34 @@ def test_pipeline_quarter_size_sensor_against_live_oracle(dev, oracle):
     kf.close()
 
 
+@pytest.mark.parametrize("sensor", ["640x480", "320x240", "600x452"])
+def test_model_map_pyramid_built_inside_the_raycast_launch(dev, sensor):
+    """raycast_builds_pyramid (default): the one-launch raycast also halves its own pixel tiles twice — levels 1 and 2 of the model
+    vertex / normal maps — against the pyramid as a launch of its own (false): poses, counts and all three levels of both maps, bit for
+    bit, over six frames; a sensor whose width and height are no multiples of the 16 x 16 workgroup tile among them."""
+    torch, pl = dev
+    w_, h_ = (int(v) for v in sensor.split("x"))
+    sx, sy = w_ / W, h_ / H
+    cam = dict(width=w_, height=h_, fx=synth.FX * sx, fy=synth.FY * sy, cx=synth.CX * sx, cy=synth.CY * sy)
+    prm = dict(synth.s1_params(128), depth_width=w_, depth_height=h_, fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"])
+    a, b = pl.KinectFusion(dict(prm, raycast_builds_pyramid=True)), pl.KinectFusion(dict(prm, raycast_builds_pyramid=False))
+    for k in range(6):
+        d = upload(torch, synth.s1_frame(k, **cam) if sensor != "640x480" else synth.s1_frame(k))
+        assert a.process_frame(d) == 1 and b.process_frame(d) == 1
+        assert np.array_equal(a.world2camera(), b.world2camera()) and a.last_hits() == b.last_hits() and a.last_U() == b.last_U()
+        for which in ("vmaps_g_prev", "nmaps_g_prev"):
+            for level in range(3):
+                x, y = a.map(which, level), b.map(which, level)
+                rows_ = x.shape[0] // 3
+                assert rows_ == h_ >> level and x.shape[1] == w_ >> level
+                valid = np.isfinite(y[:rows_, :, 0])
+                assert np.array_equal(valid, np.isfinite(x[:rows_, :, 0])), (k, which, level)
+                assert valid.mean() > 0.5
+                for p_ in range(3):
+                    assert np.array_equal(x[p_ * rows_:(p_ + 1) * rows_][valid].view(np.int32), y[p_ * rows_:(p_ + 1) * rows_][valid].view(np.int32)), (k, which, level, p_)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("levels", [1, 2])
 def test_pipeline_fewer_pyramid_levels_against_live_oracle(dev, oracle, levels):
     """num_levels 1 and 2 (the model-map pyramid then goes through the separate resize launches, the ICP runs 5 or 5 + 4

@@ -78,6 +78,9 @@ _SIGS = {
                                   C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "xs_raycast_set_pyramid": (None, [_vp, _vp, _sz, _vp, _vp, _sz]),
+    "xs_raycast_pyramid_built": (C.c_int, []),
+    "xs_raycast_set_completion_event": (None, [_vp]),
     "xs_raycast_compose_entry_bytes": (_sz, []),
     "xs_raycast_compose_pack": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp]),
     "xs_raycast_compose_scatter": (C.c_int, [_vp, C.c_long, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
@@ -478,6 +481,15 @@ def raycast_compose_mask(own_keys, min_keys, vmap, nmap, map_step, rows, cols, s
 
 def raycast_compose_finish(min_keys, vmap, nmap, map_step, rows, cols, hits=None, stream=None):
     check(_lib.xs_raycast_compose_finish(_ptr(min_keys), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
+
+
+def raycast_set_pyramid(vmap1, nmap1, step1, vmap2, nmap2, step2):
+    """The model-map pyramid the next raycast call (workspace + sign map) builds inside its kernel; (None, ...) clears."""
+    _lib.xs_raycast_set_pyramid(_ptr(vmap1), _ptr(nmap1), step1, _ptr(vmap2), _ptr(nmap2), step2)
+
+
+def raycast_pyramid_built():
+    return bool(_lib.xs_raycast_pyramid_built())
 
 
 def raycast_compose_entry_bytes():

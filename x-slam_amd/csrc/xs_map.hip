@@ -363,58 +363,7 @@ static int resize_map(bool normalize, const float *in, size_t istep, int srows, 
 // pixel: it forms the four level-1 pixels under it (each from its own 2x2 of level 0, exactly as
 // k_resize does), stores them, and averages them again from registers — the values it would read back.
 // blockIdx.z picks the map (0: vertices, 1: normals, renormalised at both levels).
-struct PyramidArgs {
-    const cfloat *in[2]; cfloat *mid[2]; cfloat *out[2];
-    size_t istep, mstep, ostep;
-    int rows0, cols0;
-};
-template <bool NORMALIZE>
-__device__ __forceinline__ void resize_two_levels(const PyramidArgs &a, int m, int x2, int y2) {
-    const int rows1 = a.rows0 / 2, cols1 = a.cols0 / 2, rows2 = rows1 / 2, cols2 = cols1 / 2;
-    cfloat3 l1[4];
-    bool ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int x = 2 * x2 + (q & 1), y = 2 * y2 + (q >> 1);
-        ok[q] = false;
-        if (x >= cols1 || y >= rows1) continue;
-        const int xs_ = x * 2, ys = y * 2;
-        const cfloat *in = a.in[m];
-        const cfloat x00 = row_ptr(in, a.istep, ys)[xs_], x01 = row_ptr(in, a.istep, ys)[xs_ + 1];
-        const cfloat x10 = row_ptr(in, a.istep, ys + 1)[xs_], x11 = row_ptr(in, a.istep, ys + 1)[xs_ + 1];
-        if (isnan(x00.re) || isnan(x01.re) || isnan(x10.re) || isnan(x11.re)) {
-            row_ptr(a.mid[m], a.mstep, y)[x] = cfloat(qnan_f(), 0.f);
-            continue;
-        }
-        cfloat3 n;
-        n.x = (x00 + x01 + x10 + x11) / 4.0f;
-        const cfloat y00 = row_ptr(in, a.istep, ys + a.rows0)[xs_], y01 = row_ptr(in, a.istep, ys + a.rows0)[xs_ + 1];
-        const cfloat y10 = row_ptr(in, a.istep, ys + a.rows0 + 1)[xs_], y11 = row_ptr(in, a.istep, ys + a.rows0 + 1)[xs_ + 1];
-        n.y = (y00 + y01 + y10 + y11) / 4.0f;
-        const cfloat z00 = row_ptr(in, a.istep, ys + 2 * a.rows0)[xs_], z01 = row_ptr(in, a.istep, ys + 2 * a.rows0)[xs_ + 1];
-        const cfloat z10 = row_ptr(in, a.istep, ys + 2 * a.rows0 + 1)[xs_], z11 = row_ptr(in, a.istep, ys + 2 * a.rows0 + 1)[xs_ + 1];
-        n.z = (z00 + z01 + z10 + z11) / 4.0f;
-        if (NORMALIZE) n = normalized(n);
-        row_ptr(a.mid[m], a.mstep, y)[x] = n.x;
-        row_ptr(a.mid[m], a.mstep, y + rows1)[x] = n.y;
-        row_ptr(a.mid[m], a.mstep, y + 2 * rows1)[x] = n.z;
-        l1[q] = n;
-        ok[q] = true;
-    }
-    if (x2 >= cols2 || y2 >= rows2) return;
-    if (!(ok[0] && ok[1] && ok[2] && ok[3])) {
-        row_ptr(a.out[m], a.ostep, y2)[x2] = cfloat(qnan_f(), 0.f);
-        return;
-    }
-    cfloat3 n;
-    n.x = (l1[0].x + l1[1].x + l1[2].x + l1[3].x) / 4.0f;
-    n.y = (l1[0].y + l1[1].y + l1[2].y + l1[3].y) / 4.0f;
-    n.z = (l1[0].z + l1[1].z + l1[2].z + l1[3].z) / 4.0f;
-    if (NORMALIZE) n = normalized(n);
-    row_ptr(a.out[m], a.ostep, y2)[x2] = n.x;
-    row_ptr(a.out[m], a.ostep, y2 + rows2)[x2] = n.y;
-    row_ptr(a.out[m], a.ostep, y2 + 2 * rows2)[x2] = n.z;
-}
+#include "xs_pyramid.h"   // PyramidArgs, resize_two_levels: shared with the raycast kernel, which can build the pyramid of its own tile
 __global__ void __launch_bounds__(256) k_resize_pyramid(const PyramidArgs a) {
     const int x2 = threadIdx.x + blockIdx.x * blockDim.x;
     const int y2 = threadIdx.y + blockIdx.y * blockDim.y;

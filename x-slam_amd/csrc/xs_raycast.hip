@@ -9,8 +9,10 @@
 // value volume alone and in real arithmetic — the same float operations the reference's
 // real(ray_start + ray_dir * t) performs; the gradient volume is read only at the crossing,
 // where the 2 + 6 trilinear samples run in complex arithmetic.
+#include <hip/hip_ext.h>
 #include "xs_device.h"
 #include "xs_signmap.h"
+#include "xs_pyramid.h"
 #include <type_traits>
 #include "../../include/xslam_amd.h"
 
@@ -36,6 +38,7 @@ struct RaycastArgs {
     int *steps;    // optional (measurement): per pixel, the march iterations the reference's loop (RayCaster.cu:222-247) runs for this ray
     SignMap sm;    // sm.dil != null (the march kernels): evaluate only the iterations the sign map leaves (xs_signmap.h)
     float sm_dt; int sm_rounds;   // sign map: spacing of the per-wave samples along the tile's centre ray; 64 * sm_rounds of them
+    PyramidArgs pyr;              // pyr.mid[0] != null (the fused one-launch form): every workgroup also builds levels 1 and 2 of both maps under its own tile
 };
 
 namespace {
@@ -653,6 +656,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
         }
         if (SLAB) a.keys[y * a.cols + x] = key;  // (MODE 5 rewrites the key it read: even where the crossing gave a vertex)
     }
+    if (MODE == 0 && a.pyr.mid[0]) {
+        // The model-map pyramid (resizeVMap / resizeNMap twice, KinectFusionReconstruction.cpp:272-277) of this workgroup's own tile: a
+        // level-2 pixel needs the 4 x 4 level-0 pixels under it, and the tile's origin and size are multiples of four — so the two
+        // halvings need nothing another workgroup writes, and the frame's tail loses a launch (~16 us: dispatch + a kernel that reads the
+        // maps back from memory).  The tile's vertices / normals went out with plain stores: once they have completed (release at
+        // workgroup scope + barrier) the lanes of wave 0 read them back through this CU's L1 / L2.  One lane per level-2 pixel and map,
+        // through the pyramid kernel's own function: the same values.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // level 1: the tile's 64 pixels of each map, one per lane of waves 0 and 1 (wave 0: vertices, wave 1: normals); their values
+        // pass to level 2 through LDS: the 16 pixels of each map, one per lane of the first half of wave 0
+        __shared__ cfloat3 s_l1[2][64];
+        __shared__ unsigned char s_ok1[2][64];
+        const int rows1 = a.pyr.rows0 / 2, cols1 = a.pyr.cols0 / 2;
+        const int n1x = wx;                                        // level-1 pixels per tile: (2 wx / 2) x (2 wy / 2) = wx x wy = 64
+        const int x1o = (tile % tiles_x) * wx, y1o = (tile / tiles_x) * wy;   // the tile's first level-1 pixel
+        if (tile_ok && threadIdx.x < 128) {
+            const int m = (int)threadIdx.x >> 6, q = (int)threadIdx.x & 63;
+            const int x1 = x1o + q % n1x, y1 = y1o + q / n1x;
+            cfloat3 n;
+            bool ok = false;
+            if (x1 < cols1 && y1 < rows1) ok = m == 0 ? pyramid_level1_pixel<false>(a.pyr, 0, x1, y1, n) : pyramid_level1_pixel<true>(a.pyr, 1, x1, y1, n);
+            if (ok) s_l1[m][q] = n;
+            s_ok1[m][q] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (tile_ok && threadIdx.x < 32) {
+            const int m = (int)threadIdx.x >> 4, r = (int)threadIdx.x & 15;
+            const int n2x = n1x >> 1;
+            const int lx = r % n2x, ly = r / n2x;                  // level-2 pixel inside the tile
+            const int x2 = (x1o >> 1) + lx, y2 = (y1o >> 1) + ly;
+            if (x2 < cols1 / 2 && y2 < rows1 / 2) {
+                cfloat3 l1[4];
+                bool ok[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int q = (2 * ly + (c >> 1)) * n1x + 2 * lx + (c & 1);
+                    ok[c] = s_ok1[m][q] != 0;
+                    if (ok[c]) l1[c] = s_l1[m][q];
+                }
+                if (m == 0) pyramid_level2_pixel<false>(a.pyr, 0, x2, y2, l1, ok);
+                else pyramid_level2_pixel<true>(a.pyr, 1, x2, y2, l1, ok);
+            }
+        }
+    }
     if (a.hits) {
         // one atomic per workgroup: same-address atomics cost ~12 ns each at the memory side, and one
         // per wave (4800 of them) would by itself take longer than the kernel
@@ -730,10 +779,26 @@ static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y =
  * vertex.  workspace: optional rows*cols floats; with it the ray is split into a march kernel
  * and a crossing kernel (same arithmetic, higher occupancy).  No synchronisation (neither does
  * the reference, :367). */
+// The model-map pyramid handed to the next xs_raycast call of this thread (levels 1 and 2 of the vertex and of the normal map, as
+// xs_resize_pyramid takes them): the one-launch form of the raycast (workspace + sign map) then builds it inside the raycast kernel, and
+// xs_raycast_pyramid_built() says whether that call did (else the caller launches xs_resize_pyramid as before).  A completion event rides
+// on that launch like xs_resize_pyramid_set_completion_event's on the pyramid kernel.
+static thread_local PyramidArgs g_ray_pyr = {};
+static thread_local bool g_ray_pyr_set = false, g_ray_pyr_built = false;
+static thread_local hipEvent_t g_ray_done = nullptr;
+extern "C" void xs_raycast_set_pyramid(float *vmap1, float *nmap1, size_t step1, float *vmap2, float *nmap2, size_t step2) {
+    g_ray_pyr_set = vmap1 && nmap1 && vmap2 && nmap2;
+    g_ray_pyr.mid[0] = (cfloat *)vmap1; g_ray_pyr.mid[1] = (cfloat *)nmap1; g_ray_pyr.out[0] = (cfloat *)vmap2; g_ray_pyr.out[1] = (cfloat *)nmap2;
+    g_ray_pyr.mstep = step1; g_ray_pyr.ostep = step2;
+}
+extern "C" int xs_raycast_pyramid_built(void) { return g_ray_pyr_built ? 1 : 0; }
+extern "C" void xs_raycast_set_completion_event(void *event) { g_ray_done = (hipEvent_t)event; }
+
 extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                           float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                           float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
                           void *stream) {
+    g_ray_pyr_built = false;
     if (!intr4 || !Rc2v18 || !tc2v6 || !Rv2w18 || !tv2w6 || !res || !value || !grad || !vmap || !nmap)
         return xs_set_error(hipErrorInvalidValue, "xs_raycast: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
@@ -750,6 +815,7 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
     a.hits = hits_dev; a.cross_t = workspace; a.steps = g_ray_steps;
     a.sm = SignMap{};
+    a.pyr = PyramidArgs{};
     if (g_ray_signmap && workspace) {
         // the map's time table was written for one truncation distance (xs_signmap_reset): any other would resume at wrong times
         if (g_ray_signmap_tranc * 0.8f != a.time_step || g_ray_signmap_shift < 2 || g_ray_signmap_shift > 6)
@@ -774,8 +840,15 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
             // with the sign map the march is a few batches long: it and the crossing are one launch (five waves per SIMD hold the
             // frame's 4 800 waves either way) — no second dispatch, no crossing-time plane written and read back
             a.hits = hits_dev;
-            if (off32) hipLaunchKernelGGL(((a.dv.ok & 2u) ? k_raycast<0, true, true, true> : k_raycast<0, true, false, true>), grid, block, 0, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((k_raycast<0, false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+            static const bool env_no_pyr = getenv("XS_RAY_NO_PYRAMID") != nullptr;   // A/B aid: the pyramid stays a launch of its own
+            if (g_ray_pyr_set && !env_no_pyr) {
+                a.pyr = g_ray_pyr;
+                a.pyr.in[0] = a.vmap; a.pyr.in[1] = a.nmap; a.pyr.istep = map_step; a.pyr.rows0 = rows; a.pyr.cols0 = cols;
+                g_ray_pyr_built = true;
+            }
+            void (*kern)(const RaycastArgs) = off32 ? ((a.dv.ok & 2u) ? k_raycast<0, true, true, true> : k_raycast<0, true, false, true>) : k_raycast<0, false, false, true>;
+            if (g_ray_done) hipExtLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, nullptr, g_ray_done, 0, a);
+            else hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, a);
             XS_CHECK(hipGetLastError());
             return 0;
         }
@@ -824,6 +897,7 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.zs0 = zs0; a.zs1 = zs1; a.z0 = z0; a.z1 = z1; a.keys = keys_dev;
     a.hits = nullptr; a.cross_t = nullptr; a.steps = nullptr;
     a.sm = SignMap{};
+    a.pyr = PyramidArgs{};
     a.sm_dt = 0.0f; a.sm_rounds = 0;
     if (g_ray_signmap) {
         // this rank's sign map (marked by its own integrate calls: owned slab + halo): the march evaluates the iterations it leaves

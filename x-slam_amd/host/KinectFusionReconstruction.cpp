@@ -130,6 +130,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_host_fold = config.as<bool>("icp_host_fold", false);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
     shard_composite_gather = config.as<bool>("shard_composite_gather", true);
+    raycast_builds_pyramid = config.as<bool>("raycast_builds_pyramid", true);
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
     if (sign_map_on()) {
@@ -847,15 +848,23 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
 
 // reference :272-277: resizeVMap / resizeNMap per level.  With three levels both halvings of both maps
 // are one launch (xs_resize_pyramid: same values).
+// levels 1 and 2 of the model maps allocated, and all three levels' vertex / normal maps of equal pitch (what the one-launch pyramid — its
+// own kernel or the raycast's epilogue — wants): false = the per-level launches
+bool KinectFusionReconstruction::PreparePyramidLevels() {
+    if (num_levels != 3) return false;
+    const int rows0 = vmaps_g_prev_d[0].rows() / 3, cols0 = vmaps_g_prev_d[0].cols();
+    for (int i = 1; i < 3; ++i) {
+        vmaps_g_prev_d[i].create((rows0 >> i) * 3, cols0 >> i);
+        nmaps_g_prev_d[i].create((rows0 >> i) * 3, cols0 >> i);
+    }
+    return vmaps_g_prev_d[0].step() == nmaps_g_prev_d[0].step() && vmaps_g_prev_d[1].step() == nmaps_g_prev_d[1].step() &&
+           vmaps_g_prev_d[2].step() == nmaps_g_prev_d[2].step();
+}
 void KinectFusionReconstruction::ModelMapPyramid() {
+    if (pyramid_in_raycast_) { pyramid_in_raycast_ = false; return; }   // built by the raycast launch (CalculatePointCloud)
     if (num_levels == 3) {
         const int rows0 = vmaps_g_prev_d[0].rows() / 3, cols0 = vmaps_g_prev_d[0].cols();
-        for (int i = 1; i < 3; ++i) {
-            vmaps_g_prev_d[i].create((rows0 >> i) * 3, cols0 >> i);
-            nmaps_g_prev_d[i].create((rows0 >> i) * 3, cols0 >> i);
-        }
-        if (vmaps_g_prev_d[0].step() == nmaps_g_prev_d[0].step() && vmaps_g_prev_d[1].step() == nmaps_g_prev_d[1].step() &&
-            vmaps_g_prev_d[2].step() == nmaps_g_prev_d[2].step()) {
+        if (PreparePyramidLevels()) {
             // (its completion = the end of the frame's tail: what the announced next frame's map preparation waits for, HintNextFrame)
             xs_resize_pyramid_set_completion_event(tail_done_);
             check_rc(xs_resize_pyramid(&vmaps_g_prev_d[0].ptr()->re, &nmaps_g_prev_d[0].ptr()->re, vmaps_g_prev_d[0].step(), rows0, cols0,
@@ -1063,8 +1072,20 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     if (sign_map_stale_) { RebuildSignMap(); sign_map_stale_ = false; }   // (xs_kf_volume_ptr handed the value array out since the last raycast)
     if (shard_count == 1 && !force_shard_composite) {
         xs_raycast_set_signmap(sign_map_ptr(), raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist());
+        // the model-map pyramid rides in the raycast launch where it can (three levels, the level-0 model maps, one launch: the sign map's
+        // form): ModelMapPyramid then has nothing to launch, and the tail's completion event rides on the raycast
+        pyramid_in_raycast_ = false;
+        const bool own_maps = &xyz_g_d == &vmaps_g_prev_d[0] && &normal_g_d == &nmaps_g_prev_d[0];
+        if (raycast_builds_pyramid && own_maps && PreparePyramidLevels()) {
+            xs_raycast_set_pyramid(&vmaps_g_prev_d[1].ptr()->re, &nmaps_g_prev_d[1].ptr()->re, vmaps_g_prev_d[1].step(),
+                                   &vmaps_g_prev_d[2].ptr()->re, &nmaps_g_prev_d[2].ptr()->re, vmaps_g_prev_d[2].step());
+            xs_raycast_set_completion_event(tail_done_);
+        }
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
                 voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, hits_counter_, ray_ws_.ptr());
+        if (xs_raycast_pyramid_built()) { pyramid_in_raycast_ = true; tail_recorded_ = true; }
+        xs_raycast_set_pyramid(nullptr, nullptr, 0, nullptr, nullptr, 0);
+        xs_raycast_set_completion_event(nullptr);
         xs_raycast_set_signmap(nullptr, 0, 0.0f);
         return 0;
     }

@@ -245,6 +245,10 @@ private:
     std::vector<DeviceArray2D<float>> vreal_next_d, nreal_next_d;
     DeviceArray2D<float> depthRawScaled_next_d;
     DeviceArray<float> depth_max_next_;
+    // the model-map pyramid inside the raycast launch (YAML raycast_builds_pyramid, default true; single GPU, three levels, sign map on)
+    bool raycast_builds_pyramid = true;
+    bool pyramid_in_raycast_ = false;   // this frame's raycast launch built levels 1 and 2: ModelMapPyramid has nothing to do
+    bool PreparePyramidLevels();
     // shard mode, raycast composite by owner-compacted exchange (YAML shard_composite_gather, default true; false = the int32 sum of the maps)
     bool shard_composite_gather = true;
     DeviceArray<unsigned char> gather_buf_, pack_buf_;   // the ranks' packed owned pixels (52 bytes each), all of them / this rank's
