@@ -100,6 +100,7 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
 #define XS_INTEGRATE_POSE_POSTED 16u     /* the kernel takes its pose from a mailbox (xs_integrate_set_pose_mailbox / xs_integrate_post_pose): see below */
 #define XS_INTEGRATE_NO_TILES 32u        /* every brick takes the exact per-voxel walk: no free-space / nothing-to-write classification from the depth tiles (A/B and tests; same volume either way) */
 #define XS_INTEGRATE_COUNT_CLASSES 64u   /* the kernel counts the wave-sized boxes it classified: 32-bit words 48 / 49 / 50 of the workspace = free / nothing to write / exact walk (cleared with the header; tests and bench figures) */
+#define XS_INTEGRATE_RECLASSIFY_BOXES 128u /* with XS_INTEGRATE_LIST_IS_READY: the brick list holds for this pose but the box classes xs_integrate_classify left do not (xs_integrate_list_covers returned 1, not 3): classify the boxes again, with this pose */
 #define XS_INTEGRATE_LIST_IS_READY 4u   /* xs_integrate_classify has produced the brick list on this stream (see there) */
 int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
@@ -114,7 +115,10 @@ int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, v
  * xs_integrate_scaled_ex with XS_INTEGRATE_LIST_IS_READY (| XS_INTEGRATE_HEADER_IS_CLEAR) on the same stream / workspace / slab /
  * image size, else clear the header again (xs_integrate_workspace_clear) and call it without.  flags of xs_integrate_classify:
  * XS_INTEGRATE_HEADER_IS_CLEAR as above.  Results are those of the plain call, bit for bit (the list is a superset; every voxel
- * still takes the exact tests with the final pose). */
+ * still takes the exact tests with the final pose).
+ * With a depth-tile table named (xs_integrate_set_depth_tiles) xs_integrate_classify also decides the boxes' classes (free space /
+ * nothing to write / per-voxel walk), padded for every pose within the slack's allowances; xs_integrate_list_covers returns 0 (the
+ * list does not hold), 1 (the list holds, the classes do not: add XS_INTEGRATE_RECLASSIFY_BOXES to the call's flags) or 3 (both hold). */
 /* The integrate kernel enqueued before its pose exists (flag XS_INTEGRATE_POSE_POSTED, with XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR):
  * xs_integrate_set_pose_mailbox(mailbox, seq, slack_scale, pose_dev) names — for the NEXT xs_integrate_scaled_ex call of this thread — the mailbox
  * (xs_icp_mailbox_alloc: one of its own, not the ICP loop's) that a one-wave gate kernel in front of the integrate kernel polls, the sequence number

@@ -566,6 +566,71 @@ def test_brick_classification_is_invisible(dev, oracle, n, threshold):
     compare(tuple(exact), (cv, cw, cg, cc))
 
 
+@pytest.mark.parametrize("threshold", [0.0, 0.02])
+def test_box_classes_decided_ahead_for_a_nearby_pose(dev, threshold):
+    """xs_integrate_classify with a depth-tile table named decides the boxes' classes too, padded for every pose within the slack's
+    allowances (sideways centimetres, a few millimetres along the viewing axis); xs_integrate_list_covers tells the three cases apart:
+    3 — list and classes hold (a last-ICP-update-sized difference, and a 3 cm sideways slide like scene S1's): the call with
+    LIST_IS_READY uses both; 1 — the list holds, the classes do not (12 mm along the viewing axis): RECLASSIFY_BOXES; 0 — neither.
+    Every accepted combination gives the volume and count of the plain call, bit for bit, with free-space boxes taken."""
+    torch, capi = dev
+    n = 256
+    prm = synth.s1_params(n, threshold=threshold)
+    res = [n, n, n]
+    Hh, Ww = synth.HEIGHT, synth.WIDTH
+    k4, vs, trunc = intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm)
+    scaled = torch.empty((Hh, Ww), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    tiles = torch.zeros(capi.depth_tiles_bytes(Hh, Ww) // 4, dtype=torch.float32, device="cuda")
+
+    def fresh():
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        return v, w, g
+
+    def moved(T, dt, ang=0.0):
+        R = np.array(T["Rv2c"], np.float32).reshape(3, 3, 2).copy(); t = np.array(T["tv2c"], np.float32).reshape(3, 2).copy()
+        c_, s_ = np.cos(ang), np.sin(ang)
+        Ry = np.array([[c_, 0, s_], [0, 1, 0], [-s_, 0, c_]], np.float32)
+        R[..., 0] = Ry @ R[..., 0]; t[:, 0] = Ry @ t[:, 0] + np.asarray(dt, np.float32)
+        return R, t
+    cases = [("update", [3e-4, -2e-4, 1e-4], 2e-5, 3), ("slide", [0.03, -0.02, 0.001], 0.0, 3), ("along the axis", [0.0, 0.0, 0.012], 0.0, 1), ("far", [0.2, 0.0, 0.0], 0.0, 0)]
+    vols = {name: fresh() for name, *_ in cases if _[-1]}
+    plain = fresh()
+    cp = torch.zeros(1, dtype=torch.int64, device="cuda")
+    free_taken = 0
+    for k in (0, 4, 8):
+        depth = torch.from_numpy(synth.s1_frame(k).astype(np.int16)).cuda()
+        dmax.zero_()
+        capi.scale_depth_tiles(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax, tiles)
+        T = s1_transforms(k, prm)
+        ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+        cp.zero_()
+        capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, *plain, n * 4, 32, threshold=threshold, updated=cp,
+                                 depth_max=dmax, workspace=ws)      # every voxel through the per-voxel walk
+        for name, dt, ang, want in cases:
+            Rl, tl = moved(T, dt, ang)       # the pose the classification sees
+            covers = capi.integrate_list_covers(Hh, Ww, k4, res, vs, Rl, tl, 2.0, T["Rv2c"], T["tv2c"])
+            assert covers == want, (name, covers)
+            if not covers:
+                continue
+            c = torch.zeros(1, dtype=torch.int64, device="cuda")
+            capi.integrate_set_depth_tiles(tiles)
+            try:
+                capi.integrate_classify(Hh, Ww, k4, res, vs, Rl, tl, trunc, ws, slack_scale=2.0, flags=64, depth_max=dmax)
+                capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, *vols[name], n * 4,
+                                         1 | 4 | 64 | (0 if covers & 2 else 128), threshold=threshold, updated=c, depth_max=dmax, workspace=ws)
+            finally:
+                capi.integrate_set_depth_tiles(None)
+            torch.cuda.synchronize()
+            free_taken += class_counts(ws)[0]
+            assert int(c.item()) == int(cp.item()) > 1000, name
+            for x, y in zip(plain, vols[name]):
+                assert torch.equal(x, y), (name, k)
+    assert free_taken > 100
+
+
 def test_brick_classification_adversarial_grazing_surfaces(dev):
     """Surfaces that graze brick faces and tile borders: a staircase of planes whose depths sit within a few voxels of every brick
     boundary along z, a one-pixel-wide pillar and a one-pixel hole inside otherwise free tiles, and the camera rotated so that the

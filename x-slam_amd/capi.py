@@ -288,7 +288,7 @@ def integrate_list_covers(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_lis
     k = _fa(intr, 4)
     a, b, c, d = _fa(Rv2c_list, 18), _fa(tv2c_list, 6), _fa(Rv2c, 18), _fa(tv2c, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
-    return bool(_lib.xs_integrate_list_covers(rows, cols, P(k), r.ctypes.data_as(_i32p), voxel_size, P(a), P(b), slack_scale, P(c), P(d)))
+    return int(_lib.xs_integrate_list_covers(rows, cols, P(k), r.ctypes.data_as(_i32p), voxel_size, P(a), P(b), slack_scale, P(c), P(d)))
 
 
 def integrate_set_pose_mailbox(mailbox, mailbox_seq, slack_scale=2.0, pose_dev=None):

@@ -1120,16 +1120,18 @@ extern "C" int xs_integrate_fold_counts(void *workspace, unsigned long long *upd
     XS_CHECK(hipGetLastError());
     return 0;
 }
-// What a pose covered by a list classified with slack_scale may differ by from the list's pose, in camera-frame metres anywhere in the
-// volume: a tenth of the frustum planes' extra slack (2e-3 of the coordinate magnitudes per unit of slack_scale; 2.2 mm per axis for
-// the benchmark volume at slack 2 — a last ICP update is well inside, and the classes' pads stay small: ~3 px at 1 m, 2 mm of depth).
-// xs_integrate_list_covers checks a pose against exactly these.
+// What a pose whose box classes a list classified with slack_scale still holds for may differ by from the list's pose, in camera-frame
+// metres anywhere in the volume.  Sideways (X, Y) as much as the frustum planes' extra slack lets a pose move (2e-3 of the coordinate
+// magnitudes per unit of slack_scale, doubled: 4.4 cm for the benchmark volume at slack 2 — the last ICP update of a scene that slides,
+// like S1 along its wall, is centimetres): that only widens a box's pixel range (~8 px at 2.5 m).  Along the viewing axis (C) a third of
+// it (6.6 mm): that one thickens the band round every surface in which boxes take the per-voxel walk.  xs_integrate_list_covers
+// checks a pose against exactly these (bit 1 of its result).
 static BoxSlack box_slack(const IntegrateArgs &a, float slack_scale) {
     const float vs = a.voxel_size, ext = (float)std::max(a.X, std::max(a.Y, a.Z));
     auto mag = [&](const cfloat3 &row, float t) { return fabsf(t) + (fabsf(row.x.re) + fabsf(row.y.re) + fabsf(row.z.re)) * vs * ext; };
-    const float k = 0.1f * 2e-3f * (slack_scale - 1.0f);
+    const float k = 2e-3f * (slack_scale - 1.0f);
     BoxSlack sl;
-    sl.dX = k * mag(a.R.data[0], a.t.x.re); sl.dY = k * mag(a.R.data[1], a.t.y.re); sl.dC = k * mag(a.R.data[2], a.t.z.re);
+    sl.dX = 2.0f * k * mag(a.R.data[0], a.t.x.re); sl.dY = 2.0f * k * mag(a.R.data[1], a.t.y.re); sl.dC = 0.3f * k * mag(a.R.data[2], a.t.z.re);
     return sl;
 }
 // largest camera-frame coordinate difference between two poses over the volume's voxels, per axis
@@ -1224,7 +1226,7 @@ extern "C" int xs_integrate_list_covers(int rows, int cols, const float *intr4, 
         const double room = 1.5 * ((double)slack_scale * l.fr.slack[p] - f.fr.slack[p]);
         if (!(d <= 0.9 * room)) return 0;   // (a tenth of the room left for the kernel's float evaluation of the forms)
     }
-    return box_slack_covers(l, f, res, slack_scale) ? 1 : 0;   // the boxes' classes hold for the pose too
+    return box_slack_covers(l, f, res, slack_scale) ? 3 : 1;   // bit 1: the boxes' classes hold for the pose too
 }
 /* Host only: the stricter cover test a POSTED integrate launch needs — it keeps the list pose's widened planes for its column clip too, where
  * a voxel is kept when alpha + b . index >= -slack (the brick test of xs_integrate_list_covers allows 1.5 slack): 1 if every half-space of
@@ -1241,7 +1243,7 @@ extern "C" int xs_integrate_pose_covered(int rows, int cols, const float *intr4,
         const double room = (double)slack_scale * l.fr.slack[p] - f.fr.slack[p];
         if (!(d <= 0.8 * room)) return 0;   // (a fifth of the room left for the float evaluation of the forms and of the roots the clip solves them for)
     }
-    return box_slack_covers(l, f, res, slack_scale) ? 1 : 0;
+    return box_slack_covers(l, f, res, slack_scale) ? 1 : 0;   // (a posted launch cannot classify again: it needs both)
 }
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
@@ -1321,7 +1323,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // the boxes' classes (free space / nothing to write / exact walk): those xs_integrate_classify left for this list, or classified
         // here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here, in the workspace
         static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;   // A/B aid, as the flag
-        const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace;
+        const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
         g_classes_of = nullptr;
         if (off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES)) {
             if (classes_ahead) {

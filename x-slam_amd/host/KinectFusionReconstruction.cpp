@@ -810,10 +810,10 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             unsigned list_flag = 0;
             if (i == 0 && list_ready_) {
                 list_ready_ = false;
-                if (xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
-                                             integrate_classify_slack,
-                                             &device_Rv2c.data[0].x.re, &device_tv2c.x.re))
-                    list_flag = XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR;
+                const int covers = xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_,
+                                                            list_tv2c_, integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re);
+                if (covers)   // (bit 1 clear: the list holds but the boxes' classes were padded for a nearer pose — they are decided again, the list stays)
+                    list_flag = XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR | ((covers & 2) ? 0u : XS_INTEGRATE_RECLASSIFY_BOXES);
                 else   // the last update moved the frustum further than the widened list allows for (never seen): start over
                     check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
             }
