@@ -631,6 +631,51 @@ def test_box_classes_decided_ahead_for_a_nearby_pose(dev, threshold):
     assert free_taken > 100
 
 
+@pytest.mark.parametrize("shape", [(960, 1280), (203, 333)])
+def test_brick_classification_other_image_sizes(dev, shape):
+    """A 1280 x 960 sensor (four times the tiles; boxes near the camera go through the super tiles) and a ragged 333 x 203 one (partial
+    tiles and super tiles at the right and bottom edges): classified against the per-voxel walk everywhere, bit for bit."""
+    torch, capi = dev
+    hh, ww = shape
+    n = 192
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    sx, sy = ww / synth.WIDTH, hh / synth.HEIGHT
+    cam = dict(width=ww, height=hh, fx=synth.FX * sx, fy=synth.FY * sy, cx=synth.CX * sx, cy=synth.CY * sy)
+    k4 = np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float32)
+    vs, trunc = prm["tsdf_voxel_size"], tranc_dist(prm)
+    rng = np.random.default_rng(2)
+    scaled = torch.empty((hh, ww), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    outs = []
+    total = np.zeros(3, np.int64)
+    for flags in (32, 0):
+        v = torch.zeros((n * n, n), dtype=torch.float32, device="cuda"); w = torch.zeros((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.zeros((n * n, n), dtype=torch.float32, device="cuda")
+        counts = []
+        for k in (0, 3, 6):
+            d = synth.s1_frame(k, **cam)
+            assert d.shape == (hh, ww)
+            d[hh // 3:hh // 3 + 9, ww // 4:ww // 4 + 30] = 0          # a hole
+            depth = torch.from_numpy(d.astype(np.int16)).cuda()
+            dmax.zero_()
+            capi.scale_depth_max(depth, ww * 2, hh, ww, scaled, ww * 4, dmax)
+            T = s1_transforms(k, prm)
+            ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+            c = torch.zeros(1, dtype=torch.int64, device="cuda")
+            capi.integrate_scaled_ex(scaled, ww * 4, hh, ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, v, w, g, n * 4, flags | 64, updated=c,
+                                     depth_max=dmax, workspace=ws)
+            torch.cuda.synchronize()
+            counts.append(int(c.item()))
+            if flags == 0:
+                total += class_counts(ws)
+        outs.append(([x.cpu().numpy().view(np.int32) for x in (v, w, g)], counts))
+    for x, y in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(x, y)
+    assert outs[0][1] == outs[1][1] and outs[0][1][0] > 1000
+    assert total[0] > 20 and total[2] > 20, total
+
+
 def test_brick_classification_adversarial_grazing_surfaces(dev):
     """Surfaces that graze brick faces and tile borders: a staircase of planes whose depths sit within a few voxels of every brick
     boundary along z, a one-pixel-wide pillar and a one-pixel hole inside otherwise free tiles, and the camera rotated so that the
