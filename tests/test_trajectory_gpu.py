@@ -3,7 +3,7 @@ and the CPU oracle pipeline process the same 30 frames of scene S1 (SURVEY's tra
 degree of freedom constrained) at 256^3 and 512^3, side by side; every frame's pose, pose derivative, voxels written,
 rays hit and ICP inlier counts are compared, then the fused volumes on 400 000 seeded voxels.
 
-Stated envelope (measured figures: DESIGN.md "Parity status"; the per-frame log goes to gpurun_out/trajectory_parity.json).
+Stated envelope (measured figures: DESIGN.md "Parity status" and docs/DESIGN_rounds1-3.md; the per-frame log goes to gpurun_out/trajectory_parity.json).
 Scene S3 constrains all six degrees of freedom.  There the two implementations produce IDENTICAL BITS for the first 15
 frames at both sizes (every pose entry, real and imaginary), then differ in the last digits once a bilateral-filter pixel
 (expf ulp) or a flipped discrete decision enters:
@@ -12,7 +12,7 @@ frames at both sizes (every pose entry, real and imaginary), then differ in the 
        fused volume after 30 frames: weights equal on all sampled voxels but FLIPS, value within 1e-3 there.
 Scene S1 (SURVEY's wall + sphere; the bench's scene) leaves sliding along the wall to the sphere alone: its 6x6 system is
 nearly singular, and a last-digit difference entering at frame 3-5 is amplified ~100x per frame until it saturates at the
-size of the scene's free motion (millimetres; DESIGN.md section 5 — the oracle run against itself with one depth pixel
+size of the scene's free motion (millimetres; DESIGN.md section 6 — the oracle run against itself with one depth pixel
 changed by 1 mm departs just as far: measured here as "sensitivity").  So for S1:
   frames 0-3    pose |d| <= 1e-6, derivative within 1e-4 — identical inputs, identical bits expected and measured
   frames 4-29   both sides keep tracking; pose |d| <= 3e-2 (measured <= 1.8e-2) and no larger than 10x what the one-pixel
@@ -71,7 +71,7 @@ def test_thirty_frames_bench_scene_side_by_side_with_the_oracle(dev, oracle, n):
     assert np.all(np.array(r["dhits"]) <= np.maximum(3, 2e-3 * np.array(r["hits"]))), r["dhits"]
     assert min(r["dinliers"]) >= 0 and max(r["dinliers"]) <= 0.01 * 640 * 480
     # the pose derivative, every frame (round 3): in units of d pose / d seed.  On this scene the lateral seed dies within a few frames
-    # (deriv_scale falls to ~1e-3: nearest-pixel depth, DESIGN.md 5), so a relative figure means nothing after frame 3; what is asserted
+    # (deriv_scale falls to ~1e-3: nearest-pixel depth, DESIGN.md 6), so a relative figure means nothing after frame 3; what is asserted
     # is that the two pipelines' derivatives differ by no more than 10x what the one-pixel perturbation does to the GPU pipeline's own
     # derivative (the scene's conditioning), with a floor of 1e-4 of the seed's initial unit derivative
     dabs, sens_d = np.array(r["dderiv_abs"]), np.array(r["sensitivity_dderiv_abs"])

@@ -1130,8 +1130,10 @@ static BoxSlack box_slack(const IntegrateArgs &a, float slack_scale) {
     const float vs = a.voxel_size, ext = (float)std::max(a.X, std::max(a.Y, a.Z));
     auto mag = [&](const cfloat3 &row, float t) { return fabsf(t) + (fabsf(row.x.re) + fabsf(row.y.re) + fabsf(row.z.re)) * vs * ext; };
     const float k = 2e-3f * (slack_scale - 1.0f);
+    static const float lateral = getenv("XS_BOX_SLACK_LATERAL") ? (float)atof(getenv("XS_BOX_SLACK_LATERAL")) : 2.0f;   // tuning aid
+    static const float axial = getenv("XS_BOX_SLACK_AXIAL") ? (float)atof(getenv("XS_BOX_SLACK_AXIAL")) : 0.3f;
     BoxSlack sl;
-    sl.dX = 2.0f * k * mag(a.R.data[0], a.t.x.re); sl.dY = 2.0f * k * mag(a.R.data[1], a.t.y.re); sl.dC = 0.3f * k * mag(a.R.data[2], a.t.z.re);
+    sl.dX = lateral * k * mag(a.R.data[0], a.t.x.re); sl.dY = lateral * k * mag(a.R.data[1], a.t.y.re); sl.dC = axial * k * mag(a.R.data[2], a.t.z.re);
     return sl;
 }
 // largest camera-frame coordinate difference between two poses over the volume's voxels, per axis
