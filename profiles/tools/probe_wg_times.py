@@ -16,7 +16,7 @@ intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
 s = torch.cuda.current_stream()
 nb = 16 * 64 * 64
 list_bytes = (256 + nb * 4 * 4 + 255) // 256 * 256          # workspace_list_bytes: bricks of 2 planes -> 4x the 8-plane count
-class_bytes = (nb * 4 * 4 + 255) // 256 * 256
+class_bytes = (nb * 4 * 4 * 4 + 255) // 256 * 256      # a 32-bit word per box, four boxes per (2-plane) brick
 off = list_bytes + class_bytes + (1 << 18)
 for k in range(12):
     depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
@@ -30,8 +30,11 @@ t0 = rec[..., 0].min()
 b = (rec[..., 0] - t0) * 0.01; e = (rec[..., 1] - t0) * 0.01
 print(f"bricks {count}; workgroups 8192; kernel span {e.max():.2f} us; last workgroup begins at {b.max():.2f} us")
 work = rec[:count]
+nfree, nempty = work[..., 2] & 0xff, (work[..., 2] >> 8) & 0xff
+walked = 8 - nfree - nempty
+print("planes walked per box:", {int(k): int((walked == k).sum()) for k in range(9)})
 for cls, name in ((1, "free"), (2, "nothing to write"), (0, "per-voxel walk")):
-    m = work[..., 2] == cls
+    m = (nfree == 8) if cls == 1 else (nempty == 8) if cls == 2 else (walked > 0)
     if m.any():
         d = (work[..., 1] - work[..., 0])[m] * 0.01
         print(f"{name:18s} waves {m.sum():5d}  begin {b[:count][m].mean():6.2f} us (max {b[:count][m].max():6.2f})  duration mean {d.mean():6.2f}  p50 {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}  end max {e[:count][m].max():6.2f}")
@@ -45,9 +48,8 @@ order = np.argsort(-dur.max(axis=1))[:16]
 print("slowest workgroups: duration per wave (us), classes, lane-0 voxels written, brick (bx, by, bz)")
 for i in order:
     b_ = int(lst[i])
-    print(f"  wg {i:5d}  {np.round(dur[i], 1).tolist()}  cls {work[i, :, 2].tolist()}  n0 {work[i, :, 3].tolist()}  brick {(b_ & 1023, (b_ >> 10) & 1023, b_ >> 20)}  begin {b[i].min():.2f}")
-m = work[..., 2] == 0
-for k in range(9):
-    sel = m & (work[..., 3] == k)
+    print(f"  wg {i:5d}  {np.round(dur[i], 1).tolist()}  free/empty planes {[(int(a_), int(b_)) for a_, b_ in zip(nfree[i], nempty[i])]}  n0 {work[i, :, 3].tolist()}  brick {(b_ & 1023, (b_ >> 10) & 1023, b_ >> 20)}  begin {b[i].min():.2f}")
+for k in range(1, 9):
+    sel = walked == k
     if sel.any():
-        print(f"walk waves whose lane 0 wrote {k} voxels: {sel.sum():5d}  mean {dur[sel].mean():6.2f} us  max {dur[sel].max():6.2f}")
+        print(f"waves that walk {k} planes: {sel.sum():5d}  mean {dur[sel].mean():6.2f} us  max {dur[sel].max():6.2f}")

@@ -214,7 +214,7 @@ struct IntegrateArgs {
     unsigned *pose_dev;                              // ... and where it leaves {cmd, 24 floats} for k_integrate_bricks<., ., true>
     unsigned char *signmap;       // xs_signmap.h buffer (whole-volume launches) or null: bricks that receive a negative value are marked
     DepthTiles dt;                // per-tile depth range of the frame (k_scale_depth), for k_classify_boxes
-    unsigned char *box_class;     // [list entry][BOXES_PER_BRICK] BOX_* (k_classify_boxes) or null: every box takes the exact walk
+    unsigned *box_class;          // [list entry][BOXES_PER_BRICK] box_word (k_classify_boxes) or null: every box takes the exact walk
     size_t probe_offset;          // XS_PROBE_WG_TIMES only: bytes from box_class to the record area
 };
 enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };   // KF_FAR_FIRST: the list is taken from its end (see k_integrate_bricks)  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
@@ -578,10 +578,20 @@ template <bool MAX> __device__ __forceinline__ float fold64(float v) {  // over 
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return pick<MAX>(pick<MAX>(r0, r1), pick<MAX>(r2, r3));
 }
+// A box's verdict, plane by plane: along the box's z the camera depth c is affine, the depth range of the pixels the box can see is one
+// pair (lo, hi) for the whole box — so the planes in front of everything (FREE) are the ones at the near end, the planes behind
+// everything (EMPTY) the ones at the far end, and what lies between takes the per-voxel walk: two counts and the direction.
+//   word = free planes | empty planes << 8 | (c falls with z) << 16
+// A surface across the planes puts its truncation band (six or seven planes wide) into one or two bricks' boxes: only those planes are walked.
+__device__ __forceinline__ unsigned box_word(int n_free, int n_empty, int falls) { return (unsigned)n_free | ((unsigned)n_empty << 8) | ((unsigned)falls << 16); }
+__device__ __forceinline__ float dpp_fold4min(float v) { v = fminf(v, dpp_xor1(v)); return fminf(v, dpp_xor2(v)); }
+__device__ __forceinline__ float dpp_fold4max(float v) { v = fmaxf(v, dpp_xor1(v)); return fmaxf(v, dpp_xor2(v)); }
 // box = voxel indices [x0, x1) x [y0, y1) x [z0, z1), not empty.  Eight lanes per box (a wave classifies eight boxes at once): lane
-// c of the group evaluates corner c, three cross-lane steps fold the group, and the group's lanes share the tile reads; every lane of a
-// group returns the group's class.
-__device__ __forceinline__ int classify_box(const IntegrateArgs &a, const BoxSlack &sl, int x0, int x1, int y0, int y1, int z0, int z1, int corner) {
+// c of the group evaluates corner c, cross-lane steps fold the group, the group's lanes share the tile reads and then take a plane
+// each; every lane of a group returns the group's word.
+__device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const BoxSlack &sl, int x0, int x1, int y0, int y1, int z0, int z1, int corner) {
+    const int nz = z1 - z0;
+    const unsigned all_walk = box_word(0, 0, 0), all_empty = box_word(0, nz, 0);
     // voxel centres, in the exact path's own units: (index + 0.5) * voxel_size
     const float vx = (((corner & 1) ? x1 - 1 : x0) + 0.5f) * a.voxel_size;
     const float vy = (((corner & 2) ? y1 - 1 : y0) + 0.5f) * a.voxel_size;
@@ -590,7 +600,7 @@ __device__ __forceinline__ int classify_box(const IntegrateArgs &a, const BoxSla
     const float Y = ((a.R.data[1].x.re * vx + a.R.data[1].y.re * vy) + a.R.data[1].z.re * vz) + a.t.y.re;
     const float c = ((a.R.data[2].x.re * vx + a.R.data[2].y.re * vy) + a.R.data[2].z.re * vz) + a.t.z.re;
     const float cmin = fold8<false>(c) - sl.dC, cmax = fold8<true>(c) + sl.dC;
-    if (!(cmin > 1e-3f)) return BOX_MIXED;           // the camera plane cuts the box (or nearly): no hull argument
+    if (!(cmin > 1e-3f)) return all_walk;            // the camera plane cuts the box (or nearly): no hull argument
     const float rc = __builtin_amdgcn_rcpf(c);
     const float un = X * rc, vn = Y * rc;            // normalised image coordinates of the corner
     const float u = a.intr.fx * un + a.intr.cx, v = a.intr.fy * vn + a.intr.cy;
@@ -599,18 +609,18 @@ __device__ __forceinline__ int classify_box(const IntegrateArgs &a, const BoxSla
     const float pad_u = 1.5f + fabsf(a.intr.fx) * (sl.dX + fold8<true>(fabsf(un)) * sl.dC) * rcm * 1.01f;
     const float pad_v = 1.5f + fabsf(a.intr.fy) * (sl.dY + fold8<true>(fabsf(vn)) * sl.dC) * rcm * 1.01f;
     const float ulo = fold8<false>(u) - pad_u, uhi = fold8<true>(u) + pad_u, vlo = fold8<false>(v) - pad_v, vhi = fold8<true>(v) + pad_v;
-    if (!(ulo > -1e6f && uhi < 1e6f && vlo > -1e6f && vhi < 1e6f)) return BOX_MIXED;   // (NaN / overflow: take the exact walk)
+    if (!(ulo > -1e6f && uhi < 1e6f && vlo > -1e6f && vhi < 1e6f)) return all_walk;   // (NaN / overflow: take the exact walk)
     const int px0 = __float2int_rd(ulo), px1 = __float2int_ru(uhi), py0 = __float2int_rd(vlo), py1 = __float2int_ru(vhi);
     const bool inside = px0 >= 2 && py0 >= 2 && px1 <= a.dcols - 2 && py1 <= a.drows - 2;
     // the part of the pixel range that lies in the image (what is outside is never written)
     const int qx0 = max(px0, 0), qx1 = min(px1, a.dcols - 1), qy0 = max(py0, 0), qy1 = min(py1, a.drows - 1);
-    if (qx0 > qx1 || qy0 > qy1) return BOX_EMPTY;
+    if (qx0 > qx1 || qy0 > qy1) return all_empty;
     // the depth range over the pixel range: from the tiles, or — a box near the camera covers hundreds of them — from the super tiles
     int tx0 = qx0 / DEPTH_TILE, tx1 = qx1 / DEPTH_TILE, ty0 = qy0 / DEPTH_TILE, ty1 = qy1 / DEPTH_TILE, pitch = a.dt.tiles_x;
     const DepthTile *table = a.dt.tiles;
     if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > BOX_MAX_TILES) {
         tx0 = qx0 / SUPER_W; tx1 = qx1 / SUPER_W; ty0 = qy0 / SUPER_H; ty1 = qy1 / SUPER_H; pitch = a.dt.supers_x; table = a.dt.supers;
-        if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4 * BOX_MAX_TILES) return BOX_MIXED;
+        if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4 * BOX_MAX_TILES) return all_walk;
     }
     float lo = __builtin_inff(), hi = 0.f;
     for (int ty = ty0; ty <= ty1; ++ty)
@@ -620,9 +630,31 @@ __device__ __forceinline__ int classify_box(const IntegrateArgs &a, const BoxSla
         }
     lo = fold8<false>(lo); hi = fold8<true>(hi);
     const float band = (a.tranc_dist * 1.001f + 1e-5f) + 2e-4f;   // the walk's own band (update_voxel) + margin
-    if (cmin - hi > band) return BOX_EMPTY;          // behind everything the box can see (hi = 0: nothing valid there)
-    if (inside && lo - cmax > band) return BOX_FREE;  // (lo = 0 where a pixel is invalid)
-    return BOX_MIXED;
+    if (cmin - hi > band) return all_empty;                 // behind everything the box can see (hi = 0: nothing valid there)
+    if (inside && lo - cmax > band) return box_word(nz, 0, 0);   // in front of everything it can see (lo = 0 where a pixel is invalid)
+    if (nz > 8) return all_walk;                            // (more planes per brick than lanes per box: a tuning configuration)
+    // Plane by plane.  The four corners of the box's first plane are lanes 0 - 3 (corner bit 2 clear), of its last plane lanes 4 - 7; c moves
+    // by dzc per plane at every (x, y).  Lane j takes plane j with the c range of the first plane's corners shifted j planes along.
+    const float q_lo = dpp_fold4min(c), q_hi = dpp_fold4max(c);                 // per quad: this plane's corners
+    const float o_lo = dpp_half_mirror(q_lo), o_hi = dpp_half_mirror(q_hi);     // the other quad's
+    const float c0_lo = (corner & 4) ? o_lo : q_lo, c0_hi = (corner & 4) ? o_hi : q_hi;   // first plane
+    const float dzc = a.R.data[2].z.re * a.voxel_size;
+    const float pl_lo = (c0_lo + (float)corner * dzc) - sl.dC - 1e-5f, pl_hi = (c0_hi + (float)corner * dzc) + sl.dC + 1e-5f;   // plane `corner`'s c range
+    const bool p_ok = corner < nz;
+    const bool p_free = p_ok && inside && lo - pl_hi > band, p_empty = p_ok && pl_lo - hi > band;
+    const int shift = (int)(threadIdx.x & 63u) & ~7;          // the group's first lane in the wave
+    const unsigned fm = (unsigned)(__builtin_amdgcn_ballot_w64(p_free) >> shift) & 0xffu, em = (unsigned)(__builtin_amdgcn_ballot_w64(p_empty) >> shift) & 0xffu;
+    const int falls = dzc < 0.f ? 1 : 0;
+    int n_free, n_empty;
+    if (!falls) {   // c grows with z: free planes from the first plane on, empty ones from the last plane back
+        n_free = __builtin_ctz(~fm | 0x100u);
+        n_empty = __builtin_clz((~em & ((1u << nz) - 1u)) << (32 - nz) | (1u << (31 - nz)));
+    } else {
+        n_free = __builtin_clz((~fm & ((1u << nz) - 1u)) << (32 - nz) | (1u << (31 - nz)));
+        n_empty = __builtin_ctz(~em | 0x100u);
+    }
+    n_free = min(n_free, nz); n_empty = min(n_empty, nz - n_free);
+    return box_word(n_free, n_empty, falls);
 }
 // FREE box: voxels (x, y, zb .. ze - 1) of this lane's column (which lies in the volume).  A rolling pipeline over groups of FREE_CHUNK
 // planes: the next group's state is requested before the current group is updated and stored, so the wave always has reads in flight
@@ -758,14 +790,19 @@ __global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, c
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int wx0 = bx * BRICK_X + (box * 64) % BRICK_X, wy0 = by * BRICK_Y + (box * 64) / BRICK_X;
         const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
-        int cls = BOX_EMPTY;   // a wave without a column of the brick in the volume
-        if (wx0 < a.X && wy0 < a.Y) cls = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
-#if defined(XS_PROBE_ALL_FREE)   // measurement only (wrong volume): every walked box streams like free space — the free path's ceiling
-        if (cls == BOX_MIXED) cls = BOX_FREE;
+        const int nz = ze0 - zb0;
+        unsigned word = box_word(0, nz, 0);   // a wave without a column of the brick in the volume: nothing to write
+        if (wx0 < a.X && wy0 < a.Y) word = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
+#if defined(XS_PROBE_ALL_FREE)   // measurement only (wrong volume): every walked plane streams like free space — the free path's ceiling
+        if ((int)(word & 0xff) + (int)((word >> 8) & 0xff) < nz) word = box_word(nz, 0, 0);
 #endif
         if (corner == 0) {
-            a.box_class[e * BOXES_PER_BRICK + box] = (unsigned char)cls;
-            if (a.kflags & KF_COUNT_CLASSES) atomicAdd(a.brick_count + CLASS_COUNT_WORD + (cls == BOX_FREE ? 0 : cls == BOX_EMPTY ? 1 : 2), 1u);
+            a.box_class[e * BOXES_PER_BRICK + box] = word;
+            if (a.kflags & KF_COUNT_CLASSES) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
+                const int nf = (int)(word & 0xff), ne = (int)((word >> 8) & 0xff);
+                atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
+                atomicAdd(a.brick_count + CLASS_COUNT_WORD + 3, (unsigned)(nz - nf - ne));
+            }
         }
     }
 }
@@ -853,26 +890,29 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
         const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
         const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
+        int walk_lo = a.z0, walk_hi = a.z1;   // the planes this wave walks voxel by voxel (all of the brick's unless the box's word says otherwise)
         if constexpr (OFF32) {
-            if (a.box_class) {   // what k_classify_boxes found for this wave's part of the brick
-                const int cls = __builtin_amdgcn_readfirstlane(cls_now);
-                if (cls == BOX_EMPTY) continue;
-                if (cls == BOX_FREE) {
-                    if (x < a.X && y < a.Y) {
-                        const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
-                        const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-                        n_upd += integrate_free_column<SIGN>(a, reinterpret_cast<char *>(a.value) + ubase, reinterpret_cast<char *>(a.weight) + ubase,
-                                                             reinterpret_cast<char *>(a.grad) + ubase, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u,
-                                                             (unsigned)a.Y * (unsigned)a.vstep, x, y, zb0, ze0);
-                    }
-                    continue;
+            if (a.box_class) {   // what k_classify_boxes found for this wave's part of the brick: free planes at one end, empty ones at the other
+                const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane(cls_now);
+                const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
+                const int nf = (int)(word & 0xffu), ne = (int)((word >> 8) & 0xffu);
+                const bool falls = ((word >> 16) & 1u) != 0u;
+                const int f0 = falls ? ze0 - nf : zb0, f1 = falls ? ze0 : zb0 + nf;       // free planes [f0, f1)
+                walk_lo = falls ? zb0 + ne : zb0 + nf; walk_hi = falls ? ze0 - nf : ze0 - ne;
+                if (nf > 0 && x < a.X && y < a.Y) {
+                    const size_t ubase = ((size_t)(f0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
+                    n_upd += integrate_free_column<SIGN>(a, reinterpret_cast<char *>(a.value) + ubase, reinterpret_cast<char *>(a.weight) + ubase,
+                                                         reinterpret_cast<char *>(a.grad) + ubase, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u,
+                                                         (unsigned)a.Y * (unsigned)a.vstep, x, y, f0, f1);
                 }
+                if (walk_lo >= walk_hi) continue;
             }
         }
         if (x < a.X && y < a.Y) {
             const int zb0 = a.z0 + bz * a.brick_z;
             int zb = zb0, ze = min(zb + a.brick_z, a.z1);
             clip_column(s_cp, far, x, y, zb, ze);
+            zb = max(zb, walk_lo); ze = min(ze, walk_hi);
             if (zb < ze) {
                 if constexpr (OFF32) {
                     const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
@@ -884,7 +924,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     }
 #if defined(XS_PROBE_WG_TIMES)
     if (a.box_class && threadIdx.x == 0) {
-        unsigned *rec = reinterpret_cast<unsigned *>(a.box_class + a.probe_offset) + 4u * (blockIdx.x * 4 + threadIdx.y);
+        unsigned *rec = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(a.box_class) + a.probe_offset) + 4u * (blockIdx.x * 4 + threadIdx.y);
         rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[entry(blockIdx.x) * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = n_upd;
     }
 #endif
@@ -1093,10 +1133,10 @@ extern "C" void xs_integrate_set_signmap(void *signmap) { g_signmap = static_cas
 static thread_local const DepthTile *g_depth_tiles = nullptr;
 extern "C" void xs_integrate_set_depth_tiles(const void *tiles) { g_depth_tiles = static_cast<const DepthTile *>(tiles); }
 enum { TILE_ROOM_BYTES = 1 << 20 };   // the workspace's own tile table: images of up to 131 072 tiles (e.g. 4096 x 2048 pixels); larger ones take the exact walk everywhere
-// workspace: 256-byte header | brick list (int per brick) | box classes (BOXES_PER_BRICK bytes per list entry) | the call's own depth tiles
+// workspace: 256-byte header | brick list (int per brick) | box classes (BOXES_PER_BRICK words per list entry) | the call's own depth tiles
 static size_t workspace_bricks(const int *res, int nz) { return (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2); }   // room for 2-plane bricks
 static size_t workspace_list_bytes(const int *res, int nz) { return (256 + workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255; }
-static size_t workspace_class_bytes(const int *res, int nz) { return (workspace_bricks(res, nz) * BOXES_PER_BRICK + 255) & ~(size_t)255; }
+static size_t workspace_class_bytes(const int *res, int nz) { return (workspace_bricks(res, nz) * BOXES_PER_BRICK * sizeof(unsigned) + 255) & ~(size_t)255; }
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
     return workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz) + TILE_ROOM_BYTES;
@@ -1154,7 +1194,7 @@ static bool box_slack_covers(const IntegrateArgs &l, const IntegrateArgs &f, con
 static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st) {
     if (!tiles) return false;
     a.dt = depth_tiles_view(tiles, a.drows, a.dcols);
-    a.box_class = reinterpret_cast<unsigned char *>((char *)workspace + workspace_list_bytes(res, nz));
+    a.box_class = reinterpret_cast<unsigned *>((char *)workspace + workspace_list_bytes(res, nz));
     a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
     hipLaunchKernelGGL(k_classify_boxes, dim3(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048), dim3(256), 0, st, a, sl);
@@ -1329,7 +1369,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         g_classes_of = nullptr;
         if (off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES)) {
             if (classes_ahead) {
-                a.box_class = reinterpret_cast<unsigned char *>((char *)workspace + workspace_list_bytes(res, nz));
+                a.box_class = reinterpret_cast<unsigned *>((char *)workspace + workspace_list_bytes(res, nz));
                 a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
             }
             else if (!posted) {   // (a posted launch has no pose yet to classify with)
