@@ -42,14 +42,32 @@ idle = rec[count:]
 print(f"workgroups without a brick: {len(idle)}  begin mean {((idle[..., 0] - t0) * 0.01).mean():.2f}  last end {((idle[..., 1] - t0) * 0.01).max():.2f} us")
 hist, edges = np.histogram(e[:count].max(axis=1), bins=12)
 print("end-time histogram of working workgroups (us):", [(round(float(a), 1), int(c)) for a, c in zip(edges[:-1], hist)])
-lst = ws[256:256 + count * 4].view(torch.int32).cpu().numpy()
+order_off = list_bytes + class_bytes + (1 << 20)      # the list in the order the kernel takes it (k_classify_boxes)
+lst = ws[order_off:order_off + count * 4].view(torch.int32).cpu().numpy()
 dur = (work[..., 1] - work[..., 0]) * 0.01
 order = np.argsort(-dur.max(axis=1))[:16]
 print("slowest workgroups: duration per wave (us), classes, lane-0 voxels written, brick (bx, by, bz)")
 for i in order:
     b_ = int(lst[i])
-    print(f"  wg {i:5d}  {np.round(dur[i], 1).tolist()}  free/empty planes {[(int(a_), int(b_)) for a_, b_ in zip(nfree[i], nempty[i])]}  n0 {work[i, :, 3].tolist()}  brick {(b_ & 1023, (b_ >> 10) & 1023, b_ >> 20)}  begin {b[i].min():.2f}")
+    print(f"  wg {i:5d}  {np.round(dur[i], 1).tolist()}  free/empty planes {[(int(a_), int(b_)) for a_, b_ in zip(nfree[i], nempty[i])]}  n0 {(work[i, :, 3] & 0xff).tolist()}  brick {(b_ & 1023, (b_ >> 10) & 1023, b_ >> 20)}  begin {b[i].min():.2f}")
 for k in range(1, 9):
     sel = walked == k
     if sel.any():
         print(f"waves that walk {k} planes: {sel.sum():5d}  mean {dur[sel].mean():6.2f} us  max {dur[sel].max():6.2f}")
+
+# where the work ran: a CU is (XCC, SE, SH, CU) of the hardware id each wave recorded
+hw = work[..., 3]
+cu_key = ((hw >> 8) & 0xf) * 4096 + ((hw >> 29) & 7) * 512 + ((hw >> 28) & 1) * 256 + ((hw >> 24) & 0xf)
+cus = {}
+for i in range(count):
+    for w in range(4):
+        c = cus.setdefault(int(cu_key[i, w]), [0, 0, 0.0, 0.0])
+        c[0] += 1; c[1] += int(walked[i, w]); c[2] = max(c[2], float(e[i, w])); c[3] += float(dur[i, w]) if walked[i, w] > 0 else 0.0
+rows = sorted(cus.values(), key=lambda c: -c[2])
+print(f"CUs seen {len(cus)}; planes walked per CU: mean {np.mean([c[1] for c in rows]):.1f}  min {min(c[1] for c in rows)}  max {max(c[1] for c in rows)}")
+print("last CUs to finish: (waves, planes walked, end us)", [(c[0], c[1], round(c[2], 1)) for c in rows[:12]])
+print("first CUs to finish:", [(c[0], c[1], round(c[2], 1)) for c in rows[-12:]])
+pw = np.array([c[1] for c in rows], float); en = np.array([c[2] for c in rows])
+print(f"correlation(planes walked on the CU, the CU's end time) = {np.corrcoef(pw, en)[0, 1]:.2f};  end = {np.polyfit(pw, en, 1)[0]:.3f} us per plane + {np.polyfit(pw, en, 1)[1]:.2f}")
+wg_cu = cu_key[:, 0]
+print("workgroup -> CU: wg 0..15:", [hex(int(v)) for v in wg_cu[:16]], " same CU for wg i and i + 256:", float((wg_cu[:count - 256] == wg_cu[256:count]).mean()))

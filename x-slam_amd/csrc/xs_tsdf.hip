@@ -300,8 +300,11 @@ struct DepthBuffer {
 };
 enum { BUFFER_RSRC_FLAGS = 0x00020000 };   // gfx9 raw buffer, dword 3: 32-bit data format
 // phase 1 (TsdfFusion.cu:110-143): project the voxel, fetch its depth.  false = not written.
-template <bool BILINEAR, class Depth>
-__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, int z, VoxelProj &o, const Depth &dimg) {
+// In two halves so that a caller can put other work between the address and the use of the depth (integrate_span_grouped):
+// voxel_pixel — camera-frame point, image coordinates, the pixel (TsdfFusion.cu:110-127); pixel_depth — the depth sample(s) as loaded
+// words; voxel_depth — Dp from those words (:128-143).  project_voxel is the three in a row.
+struct VoxelPixel { int coo_x, coo_y, near_x, near_y; };
+__device__ __forceinline__ bool voxel_pixel(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, int z, VoxelProj &o, VoxelPixel &px_) {
     const float vgz = (z + 0.5f) * a.voxel_size;
     o.v_c.x = (k.base[0] + ps.R.data[0].z * vgz) + ps.t.x;
     o.v_c.y = (k.base[1] + ps.R.data[1].z * vgz) + ps.t.y;
@@ -317,21 +320,40 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Pose
     const cfloat inv_z = 1.0f / o.v_c.z;
     o.image_x = px * inv_z + k.cx;
     o.image_y = py * inv_z + k.cy;
-    const int coo_x = __float2int_rd(o.image_x.re - 0.5f);
-    const int coo_y = __float2int_rd(o.image_y.re - 0.5f);
-    if (!(coo_x > 1 && coo_y > 1 && coo_x < a.dcols - 1 && coo_y < a.drows - 1)) return false;
-    const int near_x = __float2int_rn(o.image_x.re), near_y = __float2int_rn(o.image_y.re);
-    cfloat Dp;
-    if (BILINEAR) {
+    px_.coo_x = __float2int_rd(o.image_x.re - 0.5f);
+    px_.coo_y = __float2int_rd(o.image_y.re - 0.5f);
+    if (!(px_.coo_x > 1 && px_.coo_y > 1 && px_.coo_x < a.dcols - 1 && px_.coo_y < a.drows - 1)) return false;
+    px_.near_x = __float2int_rn(o.image_x.re); px_.near_y = __float2int_rn(o.image_y.re);
+    return true;
+}
+template <bool BILINEAR> struct DepthWords;
+template <> struct DepthWords<false> { float n; };
+template <> struct DepthWords<true> { float d00, d10, d01, d11; };
+template <bool BILINEAR, class Depth>
+__device__ __forceinline__ void pixel_depth(const VoxelPixel &q, const Depth &dimg, DepthWords<BILINEAR> &w) {
+    if constexpr (BILINEAR) {
         // the four corners as two 8-byte loads (the pair (coo_x, coo_x + 1) is contiguous; 4-byte alignment is all a
         // global load needs); the nearest pixel is always one of them — coo = floor(image - 0.5), so rn(image) is coo or
         // coo + 1 on each axis (ties included) — and is picked from the registers instead of being gathered a fifth time:
         // two address-unit trips per voxel where there were five
-        float d00, d10, d01, d11;
-        dimg.two(coo_y, coo_x, d00, d10);
-        dimg.two(coo_y + 1, coo_x, d01, d11);
-        const float n0 = near_x == coo_x ? d00 : d10, n1 = near_x == coo_x ? d01 : d11;
-        Dp = cfloat(near_y == coo_y ? n0 : n1, 0.0f);
+        dimg.two(q.coo_y, q.coo_x, w.d00, w.d10);
+        dimg.two(q.coo_y + 1, q.coo_x, w.d01, w.d11);
+    } else {
+#if defined(XS_PROBE_NODEPTH)   // measurement only: no depth gather either
+        float d = 4.5f + 1e-9f * q.near_x * q.near_y; asm volatile("" : "+v"(d)); w.n = d;
+#else
+        w.n = dimg.one(q.near_y, q.near_x);
+#endif
+    }
+}
+template <bool BILINEAR>
+__device__ __forceinline__ bool voxel_depth(const IntegrateArgs &a, const VoxelPixel &q, const DepthWords<BILINEAR> &w, VoxelProj &o) {
+    cfloat Dp;
+    if constexpr (BILINEAR) {
+        const float d00 = w.d00, d10 = w.d10, d01 = w.d01, d11 = w.d11;
+        const int coo_x = q.coo_x, coo_y = q.coo_y;
+        const float n0 = q.near_x == coo_x ? d00 : d10, n1 = q.near_x == coo_x ? d01 : d11;
+        Dp = cfloat(q.near_y == coo_y ? n0 : n1, 0.0f);
         const float gmax = fmaxf(d00, fmaxf(d01, fmaxf(d10, d11)));
         const float gmin = fminf(d00, fminf(d01, fminf(d10, d11)));
         if (gmax - gmin < a.threshold && d00 != 0.0f && d01 != 0.0f && d10 != 0.0f && d11 != 0.0f) {
@@ -340,14 +362,17 @@ __device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const Pose
             const cfloat fb = o.image_y - cfloat(coo_y + 0.5f, 0.0f);
             Dp = d00 * (one - fa) * (one - fb) + d10 * fa * (one - fb) + d01 * (one - fa) * fb + d11 * fa * fb;
         }
-    }
-#if defined(XS_PROBE_NODEPTH)   // measurement only: no depth gather either
-    else { float d = 4.5f + 1e-9f * near_x * near_y; asm volatile("" : "+v"(d)); Dp = cfloat(d, 0.0f); }
-#else
-    else Dp = cfloat(dimg.one(near_y, near_x), 0.0f);
-#endif
+    } else Dp = cfloat(w.n, 0.0f);
     o.Dp = Dp;
     return Dp.re > 0;  // the update needs Re Dp > 0 (TsdfFusion.cu:150)
+}
+template <bool BILINEAR, class Depth>
+__device__ __forceinline__ bool project_voxel(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, int z, VoxelProj &o, const Depth &dimg) {
+    VoxelPixel q;
+    if (!voxel_pixel(a, ps, k, z, o, q)) return false;
+    DepthWords<BILINEAR> w;
+    pixel_depth<BILINEAR>(q, dimg, w);
+    return voxel_depth<BILINEAR>(a, q, w, o);
 }
 // phase 2 (TsdfFusion.cu:144-167): signed distance, truncation, running mean.
 __device__ __forceinline__ bool update_voxel(const IntegrateArgs &a, const VoxelCtx &k, const VoxelProj &p, float pre_v, float pre_g,
@@ -540,6 +565,77 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
     if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
     return n_upd;
 }
+
+
+// The OFF32 walk, G planes at a time (XS_WALK_GROUP = G > 0).  The plain walk's trip is a chain — state loads, projection, depth gather,
+// update, stores — and a wave's vector-memory operations complete in issue order, so every plane exposes a gather behind a memory latency
+// behind the previous plane's store acknowledgements: ~1.5 us per plane on the benchmark scene, 12 us for a brick, which is the launch
+// (all of its bricks are resident at once: profiles/r04_integrate_wg_times.txt).  Here a group's state loads go out first, then the G
+// pixels are found and their depth requested, and only then is anything waited for: one exposed latency per group.  Nothing but the
+// depth words and a mask is carried from the first half to the second — the projection is evaluated again there (same operations on the
+// same operands: same bits; the empty asm keeps the compiler from carrying the first evaluation's ~14 registers per plane across).
+template <bool BILINEAR, bool SIGN, int G>
+__device__ __forceinline__ unsigned integrate_span_grouped(const IntegrateArgs &a, const PoseRT &ps, int x, int y, int zb, int ze, size_t ubase, int zb0, unsigned lane_off) {
+    unsigned n_upd = 0;
+    const float vgx = (x + 0.5f) * a.voxel_size;
+    const float vgy = (y + 0.5f) * a.voxel_size;
+    VoxelCtx k;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) k.base[r] = ps.R.data[r].x * vgx + ps.R.data[r].y * vgy;
+    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
+    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
+    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    float vmin = 0.0f;
+    char *bv = reinterpret_cast<char *>(a.value) + ubase, *bw = reinterpret_cast<char *>(a.weight) + ubase, *bg = reinterpret_cast<char *>(a.grad) + ubase;
+    const unsigned plane = (unsigned)a.Y * (unsigned)a.vstep;
+    unsigned off = lane_off + (unsigned)(zb - zb0) * plane;
+    const DepthGlobal dimg{a.depth, a.dstep};
+#pragma unroll 1
+    for (int z = zb; z < ze; z += G, off += G * plane) {
+        float v0[G], g0[G]; int w0[G];
+        DepthWords<BILINEAR> dw[G];
+        unsigned seen = 0;
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            if (z + j < ze) {
+                v0[j] = *reinterpret_cast<const float *>(bv + (off + j * plane));
+                g0[j] = *reinterpret_cast<const float *>(bg + (off + j * plane));
+                w0[j] = *reinterpret_cast<const int *>(bw + (off + j * plane));
+            }
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            if (z + j < ze) {
+                VoxelProj p; VoxelPixel q;
+                if (voxel_pixel(a, ps, k, z + j, p, q)) { pixel_depth<BILINEAR>(q, dimg, dw[j]); seen |= 1u << j; }
+            }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (seen & (1u << j)) {
+                int zz = z + j;
+                asm volatile("" : "+v"(zz));
+                VoxelProj p; VoxelPixel q;
+                cfloat tsdf;
+                if (voxel_pixel(a, ps, k, zz, p, q) && voxel_depth<BILINEAR>(a, q, dw[j], p) && voxel_tsdf(a, k, p, tsdf)) {
+                    float ov, og; int ow;
+                    running_mean(a.max_weight, tsdf, v0[j], g0[j], w0[j], ov, og, ow);
+                    if ((__float_as_uint(ov) ^ __float_as_uint(v0[j])) | always) *reinterpret_cast<float *>(bv + (off + j * plane)) = ov;
+                    if ((unsigned)(ow ^ w0[j]) | always) *reinterpret_cast<int *>(bw + (off + j * plane)) = ow;
+                    if ((__float_as_uint(og) ^ __float_as_uint(g0[j])) | always) *reinterpret_cast<float *>(bg + (off + j * plane)) = og;
+                    if (SIGN) vmin = fminf(vmin, ov);
+                    ++n_upd;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) asm volatile("" ::"v"(v0[j]), "v"(g0[j]), "v"(w0[j]));   // (see integrate_span: loads of planes that left early)
+    }
+    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
+    return n_upd;
+}
+#ifndef XS_WALK_GROUP
+#define XS_WALK_GROUP 0
+#endif
 
 
 // ---- what a brick is, before any of its voxels is touched ----------------------------------------------------------------------
@@ -780,29 +876,73 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
 }
 
 // The class of every box of every listed brick (see classify_box): eight lanes per box, 32 boxes = 8 bricks per workgroup and trip.
-__global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl) {
+//
+// The kernel also decides the ORDER in which k_integrate_bricks takes the bricks: it writes a second list (ord.list) and the classes by
+// the entries of that list.  A launch with no more bricks than resident workgroups (the benchmark scene: 1 860 bricks, 1 536 workgroups
+// resident at once, the rest as soon as a slot is free) gives every brick its own workgroup and the dispatcher deals consecutive workgroups
+// round the CUs, so entries e, e + 256, e + 512 ... share a CU.  Half of the bricks are walked voxel by voxel — instruction issue, ~0.4 us of
+// SIMD time per plane — and in plane order a CU's share of those ranges from 8 to 192 planes (mean 114): the launch lasts as long as the
+// fullest CU (23 us where the emptiest is done after 10: profiles/r04_integrate_wg_times.txt).  Bricks with planes to walk therefore go to
+// the front of the list, in arrival order, the others fill it from the back: every CU gets its 3 or 4 walked bricks, and the streaming
+// ones run beside them.  Two atomics per workgroup and trip (eight bricks); above ord.limit bricks the order is the plane order (taken
+// from the far end when the camera looks up the z axis: KF_FAR_FIRST) — such launches run several rounds of workgroups, which balances
+// them, and their atomics would serialise (~12 ns each on one address).
+// The counters (header words ORDER_WORD, + 1) are zero when the kernel starts: the header clear zeroes them, and the last workgroup to
+// leave (ticket: word + 2) puts them back, so that a second classification of the same list (XS_INTEGRATE_RECLASSIFY_BOXES) finds them so.
+struct BoxOrder { int *list; unsigned limit; unsigned far_first; };
+enum { ORDER_WORD = 52 };
+__global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl, const BoxOrder ord) {
     const unsigned count = *a.brick_count;
     const int tid = (int)threadIdx.x, corner = tid & 7, box = (tid >> 3) & (BOXES_PER_BRICK - 1), slot = tid >> 5;
+    __shared__ unsigned s_kind[8], s_pos[8];
+    const bool sorted = ord.list != nullptr && count <= ord.limit;
     for (unsigned e0 = blockIdx.x * 8u; e0 < count; e0 += gridDim.x * 8u) {
         const unsigned e = e0 + slot;
-        if (e >= count) continue;    // (whole groups of eight lanes: the cross-lane steps stay inside a group)
-        const int b = a.brick_list[e];
-        const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
-        const int wx0 = bx * BRICK_X + (box * 64) % BRICK_X, wy0 = by * BRICK_Y + (box * 64) / BRICK_X;
-        const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
-        const int nz = ze0 - zb0;
-        unsigned word = box_word(0, nz, 0);   // a wave without a column of the brick in the volume: nothing to write
-        if (wx0 < a.X && wy0 < a.Y) word = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
+        const bool live = e < count;    // (whole groups of 32 lanes: the cross-lane steps stay inside a group)
+        int b = 0, nz = 0;
+        unsigned word = 0;
+        if (live) {
+            b = a.brick_list[e];
+            const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
+            const int wx0 = bx * BRICK_X + (box * 64) % BRICK_X, wy0 = by * BRICK_Y + (box * 64) / BRICK_X;
+            const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
+            nz = ze0 - zb0;
+            word = box_word(0, nz, 0);   // a wave without a column of the brick in the volume: nothing to write
+            if (wx0 < a.X && wy0 < a.Y) word = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
 #if defined(XS_PROBE_ALL_FREE)   // measurement only (wrong volume): every walked plane streams like free space — the free path's ceiling
-        if ((int)(word & 0xff) + (int)((word >> 8) & 0xff) < nz) word = box_word(nz, 0, 0);
+            if ((int)(word & 0xff) + (int)((word >> 8) & 0xff) < nz) word = box_word(nz, 0, 0);
 #endif
-        if (corner == 0) {
-            a.box_class[e * BOXES_PER_BRICK + box] = word;
+        }
+        const int nf = (int)(word & 0xff), ne = (int)((word >> 8) & 0xff);
+        unsigned pos = ord.far_first ? count - 1u - e : e;
+        if (sorted) {   // (uniform over the workgroup)
+            int walked = nz - nf - ne;    // this box's; the same in its eight lanes
+            walked += __shfl_xor(walked, 8); walked += __shfl_xor(walked, 16);   // the brick's
+            if ((tid & 31) == 0) s_kind[slot] = !live ? 0u : walked > 0 ? 1u : 2u;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned n1 = 0, n2 = 0;
+                for (int k = 0; k < 8; ++k) { n1 += s_kind[k] == 1u; n2 += s_kind[k] == 2u; }
+                unsigned front = n1 ? atomicAdd(a.brick_count + ORDER_WORD, n1) : 0u, back = n2 ? atomicAdd(a.brick_count + ORDER_WORD + 1, n2) : 0u;
+                for (int k = 0; k < 8; ++k) s_pos[k] = s_kind[k] == 1u ? front++ : count - 1u - back++;
+            }
+            __syncthreads();
+            pos = s_pos[slot];
+        }
+        if (live && corner == 0) {
+            a.box_class[(size_t)pos * BOXES_PER_BRICK + box] = word;
+            if (box == 0 && ord.list) ord.list[pos] = b;
             if (a.kflags & KF_COUNT_CLASSES) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
-                const int nf = (int)(word & 0xff), ne = (int)((word >> 8) & 0xff);
                 atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
                 atomicAdd(a.brick_count + CLASS_COUNT_WORD + 3, (unsigned)(nz - nf - ne));
             }
+        }
+    }
+    if (sorted && blockIdx.x * 8u < count) {   // (the workgroups that had a trip)
+        const unsigned workers = min(gridDim.x, (count + 7u) / 8u);
+        __syncthreads();
+        if (tid == 0 && atomicAdd(a.brick_count + ORDER_WORD + 2, 1u) == workers - 1u) {
+            atomicExch(a.brick_count + ORDER_WORD, 0u); atomicExch(a.brick_count + ORDER_WORD + 1, 0u); atomicExch(a.brick_count + ORDER_WORD + 2, 0u);
         }
     }
 }
@@ -916,7 +1056,11 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
             if (zb < ze) {
                 if constexpr (OFF32) {
                     const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
+#if XS_WALK_GROUP
+                    n_upd += integrate_span_grouped<BILINEAR, SIGN, XS_WALK_GROUP>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
+#else
                     n_upd += integrate_span<BILINEAR, true, SIGN>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
+#endif
                 } else
                     n_upd += integrate_span<BILINEAR, false, SIGN>(a, ps, x, y, zb, ze);
             }
@@ -925,7 +1069,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
 #if defined(XS_PROBE_WG_TIMES)
     if (a.box_class && threadIdx.x == 0) {
         unsigned *rec = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(a.box_class) + a.probe_offset) + 4u * (blockIdx.x * 4 + threadIdx.y);
-        rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[entry(blockIdx.x) * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = n_upd;
+        rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[entry(blockIdx.x) * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = (n_upd & 0xffu) | ((__builtin_amdgcn_s_getreg(0xF814) & 0xfu) << 8) | (__builtin_amdgcn_s_getreg(0xF804) << 16);   // + XCC_ID, HW_ID (wave, SIMD, pipe, CU, SH, SE)
     }
 #endif
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
@@ -1137,9 +1281,11 @@ enum { TILE_ROOM_BYTES = 1 << 20 };   // the workspace's own tile table: images 
 static size_t workspace_bricks(const int *res, int nz) { return (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2); }   // room for 2-plane bricks
 static size_t workspace_list_bytes(const int *res, int nz) { return (256 + workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255; }
 static size_t workspace_class_bytes(const int *res, int nz) { return (workspace_bricks(res, nz) * BOXES_PER_BRICK * sizeof(unsigned) + 255) & ~(size_t)255; }
+// ... | the list in the order the integrate kernel takes it (k_classify_boxes), after the tile room
+static size_t workspace_order_offset(const int *res, int nz) { return workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz) + TILE_ROOM_BYTES; }
 extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
-    return workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz) + TILE_ROOM_BYTES;
+    return workspace_order_offset(res, nz) + ((workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255);
 }
 // the workspace whose box classes xs_integrate_classify has written on this thread's behalf (for the xs_integrate_scaled_ex call with
 // XS_INTEGRATE_LIST_IS_READY that follows), and the slack they were classified with
@@ -1190,6 +1336,11 @@ static bool box_slack_covers(const IntegrateArgs &l, const IntegrateArgs &f, con
     pose_delta(l, f, res, d);
     return d[0] <= 0.9 * sl.dX && d[1] <= 0.9 * sl.dY && d[2] <= 0.9 * sl.dC;   // (a tenth left for the float evaluation on the device)
 }
+// camera depth grows with z: the far bricks end the list, and the list is taken from that end (KF_FAR_FIRST)
+static bool far_end_first(const IntegrateArgs &a) {
+    static const char *env_order = getenv("XS_INTEGRATE_ORDER");   // A/B aid: "near" / "far" force the list direction
+    return env_order ? !strcmp(env_order, "far") : a.R.data[2].z.re > 0.0f;
+}
 // k_classify_boxes behind the brick classification, if a tile table is there and the class array fits; true = a.box_class is being written
 static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st) {
     if (!tiles) return false;
@@ -1197,7 +1348,12 @@ static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *w
     a.box_class = reinterpret_cast<unsigned *>((char *)workspace + workspace_list_bytes(res, nz));
     a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-    hipLaunchKernelGGL(k_classify_boxes, dim3(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048), dim3(256), 0, st, a, sl);
+    // the order the integrate kernel takes the bricks in (see k_classify_boxes); XS_INTEGRATE_SORT_LIMIT: A/B aid (0: plane order always)
+    static const int env_limit = getenv("XS_INTEGRATE_SORT_LIMIT") ? atoi(getenv("XS_INTEGRATE_SORT_LIMIT")) : 4096;
+    BoxOrder ord;
+    ord.list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz));
+    ord.limit = (unsigned)env_limit; ord.far_first = (a.kflags & KF_FAR_FIRST) ? 1u : 0u;
+    hipLaunchKernelGGL(k_classify_boxes, dim3(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048), dim3(256), 0, st, a, sl, ord);
     return true;
 }
 // the pose-dependent part of the arguments the classification needs (what xs_integrate_scaled_ex sets up for it)
@@ -1245,6 +1401,7 @@ extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, con
     const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
     if (!env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32) {
         if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
+        if (far_end_first(a)) a.kflags |= KF_FAR_FIRST;
         a.tranc_dist = tranc_dist;
         if (launch_box_classes(a, res, z1 - z0, workspace, g_depth_tiles, box_slack(a, slack_scale), st)) g_classes_of = workspace;
     }
@@ -1322,8 +1479,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     static const bool env_always = getenv("XS_INTEGRATE_ALWAYS_STORE") != nullptr;   // measurement aid, as the flag
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
-    static const char *env_order = getenv("XS_INTEGRATE_ORDER");   // A/B aid: "near" / "far" force the list direction
-    if (env_order ? !strcmp(env_order, "far") : a.R.data[2].z.re > 0.0f) a.kflags |= KF_FAR_FIRST;   // camera depth grows with z: the far bricks end the list
+    if (far_end_first(a)) a.kflags |= KF_FAR_FIRST;
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
     a.dt = depth_tiles_view(nullptr, rows, cols); a.box_class = nullptr;
@@ -1381,6 +1537,10 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
                 }
                 launch_box_classes(a, res, nz, workspace, tiles, BoxSlack{0.f, 0.f, 0.f}, st);
             }
+        }
+        if (a.box_class) {   // k_classify_boxes has also put the bricks in the order they are taken in
+            a.brick_list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz));
+            a.kflags &= ~(unsigned)KF_FAR_FIRST;
         }
         void (*kern)(const IntegrateArgs) =
             sign ? (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true, false, true> : k_integrate_bricks<true, false, false, true>)
