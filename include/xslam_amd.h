@@ -144,6 +144,10 @@ size_t xs_integrate_workspace_bytes(const int *res, int nz);
  * stream; either may be NULL (a stop event alone is a completion event another stream can wait on);
  * NULL, NULL disables.  Workspace path only. */
 void xs_integrate_set_timing_events(void *start_event, void *stop_event);
+/* Event hook (per host thread): hipEvent_t attached to the last dispatch of xs_integrate_classify — its completion, no marker packet —
+ * for a caller that classifies on one stream and integrates on another (the orchestrator: the classification runs beside the last ICP
+ * launch, on the auxiliary stream); NULL disables. */
+void xs_integrate_set_classify_event(void *done_event);
 
 /* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */
 size_t xs_tsdf_reduce_workspace_bytes(void);

@@ -29,11 +29,11 @@ for k in range(24):
     capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
     T = synth.s1_transforms(k, prm)
     counter.zero_()
-    capi.integrate_scaled_ex(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, 64, updated=counter, depth_max=dmax, workspace=ws, stream=s)
+    capi.integrate_scaled_ex(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, 0 if os.environ.get("XS_PROBE_NO_COUNT") else 64, updated=counter, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
     classes = [int(x) for x in ws[192:204].view(torch.int32).cpu().numpy()]
     dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0
     if k >= 4:
-        times.append(dt.value * 1e3); bricks.append(int(ws[:4].view(torch.int32).item())); Us.append(int(counter.item()))
+        times.append(dt.value * 1e3); bricks.append(sum(capi.integrate_listed(ws))); Us.append(int(counter.item()))
 b, U, t = np.median(bricks), np.median(Us), np.median(times)
 print(f"bricks listed {b:.0f}  voxels written {U:.0f}  kernel {t:.1f} us  ->  {24 * U / t / 1e6:.2f} TB/s algorithmic; boxes free / nothing / walk (last frame) {classes}")

@@ -24,7 +24,7 @@ def run(use_ws, use_max, reps=20):
     for _ in range(reps):
         capi.integrate_scaled(scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), value, weight, grad, n * 4, depth_max=dmax if use_max else None, workspace=ws if use_ws else None, stream=s)
     e1.record(s); torch.cuda.synchronize()
-    nb = int(ws[:4].view(torch.int32).item()) if use_ws else -1
+    nb = sum(capi.integrate_listed(ws)) if use_ws else -1
     return dict(ws=use_ws, far=use_max, U=U, bricks=nb, ms=e0.elapsed_time(e1) / reps)
 print('dmax', float(dmax.item()))
 cfgs = ((True, True),) if len(sys.argv) > 2 and sys.argv[2] == 'only' else ((False, False), (False, True), (True, False), (True, True))

@@ -24,7 +24,7 @@ for k in range(12):
     T = synth.s1_transforms(k, prm)
     capi.integrate_scaled(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
-count = int(ws[:4].view(torch.int32).item())
+nwalk, nother = capi.integrate_listed(ws); count = nwalk + nother
 rec = ws[off:off + 8192 * 4 * 16].view(torch.int32).cpu().numpy().astype(np.int64).reshape(8192, 4, 4) & 0xffffffff
 t0 = rec[..., 0].min()
 b = (rec[..., 0] - t0) * 0.01; e = (rec[..., 1] - t0) * 0.01
@@ -42,8 +42,8 @@ idle = rec[count:]
 print(f"workgroups without a brick: {len(idle)}  begin mean {((idle[..., 0] - t0) * 0.01).mean():.2f}  last end {((idle[..., 1] - t0) * 0.01).max():.2f} us")
 hist, edges = np.histogram(e[:count].max(axis=1), bins=12)
 print("end-time histogram of working workgroups (us):", [(round(float(a), 1), int(c)) for a, c in zip(edges[:-1], hist)])
-order_off = list_bytes + class_bytes + (1 << 20)      # the list in the order the kernel takes it (k_classify_boxes)
-lst = ws[order_off:order_off + count * 4].view(torch.int32).cpu().numpy()
+region = ws[256:256 + nb * 4 * 4].view(torch.int32).cpu().numpy()      # the list: walked bricks from the front of its region, the others from its back
+lst = np.array([region[e] if e < nwalk else region[len(region) - 1 - (e - nwalk)] for e in range(count)])
 dur = (work[..., 1] - work[..., 0]) * 0.01
 order = np.argsort(-dur.max(axis=1))[:16]
 print("slowest workgroups: duration per wave (us), classes, lane-0 voxels written, brick (bx, by, bz)")

@@ -631,6 +631,76 @@ def test_box_classes_decided_ahead_for_a_nearby_pose(dev, threshold):
     assert free_taken > 100
 
 
+def test_bricks_with_planes_to_walk_are_taken_first(dev):
+    """k_classify_boxes leaves the list a second time, in the order the integrate kernel takes it: two runs of a region — the bricks that
+    have a plane to walk voxel by voxel from the region's front, the others from its back, their counts in header words 52 / 53 — with
+    each brick's four class words filed under its place.  The same set of bricks as the frustum test lists, every front brick with planes
+    to walk, no back brick with any, the walked planes adding up to what the kernel counted.  Then a list classified ahead (slack 2)
+    whose classes are decided again (XS_INTEGRATE_RECLASSIFY_BOXES): the second pair starts from zero again, the same bricks of the
+    frustum have planes to walk."""
+    torch, capi = dev
+    n = 256
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    Hh, Ww = synth.HEIGHT, synth.WIDTH
+    k4, vs, trunc = intr_of(prm), prm["tsdf_voxel_size"], tranc_dist(prm)
+    scaled = torch.empty((Hh, Ww), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    tiles = torch.zeros(capi.depth_tiles_bytes(Hh, Ww) // 4, dtype=torch.float32, device="cuda")
+    v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+    g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+    capi.init_volume(v, w, g, n * 4, res)
+    list_off, cap, class_off, second_off = capi.integrate_list_layout(res)
+    assert second_off + (cap * 4 + 255) // 256 * 256 == capi.integrate_workspace_bytes(res)
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+
+    def listed(host):    # what k_classify_bricks listed: the front run of the first region
+        count, other = (int(x) for x in host[:8].view(np.int32))
+        assert other == 0 and count > 100
+        ids = host[list_off:list_off + 4 * count].view(np.int32)
+        assert len(np.unique(ids)) == count
+        return ids
+
+    def ordered(host):   # k_classify_boxes: the two runs of the second region and the planes walked per brick of each
+        nwalk, nother = (int(x) for x in host[208:216].view(np.int32))
+        region = host[second_off:second_off + cap * 4].view(np.int32)
+        words = host[class_off:class_off + cap * 16].view(np.uint32).reshape(cap, 4)
+        walked = lambda wd: (8 - (wd & 0xff).astype(np.int64) - ((wd >> 8) & 0xff).astype(np.int64)).sum(axis=1)
+        return region[:nwalk], region[cap - nother:][::-1], walked(words[:nwalk]), walked(words[cap - nother:])
+
+    for k in (0, 5):
+        depth = torch.from_numpy(synth.s1_frame(k).astype(np.int16)).cuda()
+        dmax.zero_()
+        capi.scale_depth_tiles(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax, tiles)
+        T = s1_transforms(k, prm)
+        capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, v, w, g, n * 4, 64, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        assert capi.integrate_listed(ws)[1] == 0
+        host = ws.cpu().numpy()
+        ids = listed(host)
+        front, back, w_front, w_back = ordered(host)
+        assert len(front) > 0 and len(back) > 0
+        assert np.array_equal(np.sort(np.concatenate([front, back])), np.sort(ids))
+        assert (w_front > 0).all() and (w_back == 0).all()
+        assert int(w_front.sum()) == int(host[204:208].view(np.int32)[0])        # header word 51: planes walked, counted as they were classified
+        # a wider list classified ahead, its classes decided again for the pose itself
+        capi.integrate_set_depth_tiles(tiles)
+        try:
+            capi.integrate_classify(Hh, Ww, k4, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, slack_scale=2.0, depth_max=dmax)
+            capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, v, w, g, n * 4, 1 | 4 | 128, depth_max=dmax, workspace=ws)
+        finally:
+            capi.integrate_set_depth_tiles(None)
+        torch.cuda.synchronize()
+        host = ws.cpu().numpy()
+        wide = listed(host)
+        f2, b2, w2f, w2b = ordered(host)
+        assert set(ids.tolist()) <= set(wide.tolist())
+        assert np.array_equal(np.sort(np.concatenate([f2, b2])), np.sort(wide))
+        assert (w2f > 0).all() and (w2b == 0).all()
+        # the same bricks of the frustum have planes to walk (+ bricks of the wider list the tiles cannot decide)
+        assert set(front.tolist()) <= set(f2.tolist()) and not (set(f2.tolist()) - set(front.tolist())) & set(ids.tolist())
+
+
 @pytest.mark.parametrize("shape", [(960, 1280), (203, 333)])
 def test_brick_classification_other_image_sizes(dev, shape):
     """A 1280 x 960 sensor (four times the tiles; boxes near the camera go through the super tiles) and a ragged 333 x 203 one (partial

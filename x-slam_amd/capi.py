@@ -52,6 +52,7 @@ _SIGS = {
     "xs_integrate_list_covers": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
     "xs_integrate_set_timing_events": (None, [_vp, _vp]),
+    "xs_integrate_set_classify_event": (None, [_vp]),
     "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "xs_scale_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "xs_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _vp]),
@@ -316,6 +317,24 @@ def integrate_fold_counts(workspace, updated, stream=None):
 def integrate_workspace_bytes(res, nz=None):
     r = _ia(res, 3)
     return _lib.xs_integrate_workspace_bytes(r.ctypes.data_as(_i32p), int(r[2]) if nz is None else nz)
+
+
+def integrate_listed(workspace):
+    """(bricks with planes to walk, other bricks) of the list the last classification left in an integrate workspace (a torch uint8
+    tensor): the two runs of the list (front / back of its region) — read back from the header, for tests and probes."""
+    import torch
+    pair = workspace[:8].view(torch.int32).cpu().numpy()
+    return int(pair[0]), int(pair[1])
+
+
+def integrate_list_layout(res, nz=None):
+    """Byte offsets inside an integrate workspace: (list region, entries it holds, class words, second list region)."""
+    r = _ia(res, 3)
+    nz = int(r[2]) if nz is None else nz
+    cap = -(-int(r[0]) // 32) * -(-int(r[1]) // 8) * -(-nz // 2)
+    list_bytes = (256 + cap * 4 + 255) // 256 * 256
+    class_bytes = (cap * 16 + 255) // 256 * 256
+    return 256, cap, list_bytes, list_bytes + class_bytes + (1 << 20)
 
 
 def tsdf_reduce_workspace_bytes():

@@ -207,7 +207,8 @@ struct IntegrateArgs {
     Intr intr; float voxel_size, threshold;
     unsigned long long *updated;  // optional device counter
     const float *depth_max;       // optional: largest valid depth of the frame (device)
-    int *brick_list; unsigned *brick_count;  // work list of the two-phase path
+    int *brick_list; unsigned *brick_count;  // work list of the two-phase path: the region the integrate kernel reads, the workspace header
+    unsigned list_cap, pair_word;            // entries a list region holds; header word of the ListPair that goes with brick_list (PAIR_*)
     int bricks_x, bricks_y, bricks_z, brick_z;  // brick_z: planes per brick (runtime; BRICK_Z by default)
     unsigned kflags;              // KF_*
     const unsigned *mailbox; unsigned mailbox_seq;   // posted pose: what k_pose_gate polls ...
@@ -718,12 +719,17 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
         tx0 = qx0 / SUPER_W; tx1 = qx1 / SUPER_W; ty0 = qy0 / SUPER_H; ty1 = qy1 / SUPER_H; pitch = a.dt.supers_x; table = a.dt.supers;
         if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4 * BOX_MAX_TILES) return all_walk;
     }
+    // (four rows of the range per trip, requested together — a row index past the range repeats its last row, which changes neither bound:
+    // a box of the benchmark scene sees 3 x 7 tiles with the slack's pads, i.e. one trip of one round of loads where row by row took three)
     float lo = __builtin_inff(), hi = 0.f;
-    for (int ty = ty0; ty <= ty1; ++ty)
+    for (int ty = ty0; ty <= ty1; ty += 4) {
+        const int r0 = ty * pitch, r1 = min(ty + 1, ty1) * pitch, r2 = min(ty + 2, ty1) * pitch, r3 = min(ty + 3, ty1) * pitch;
         for (int tx = tx0 + corner; tx <= tx1; tx += 8) {
-            const DepthTile t = table[ty * pitch + tx];
-            lo = fminf(lo, t.lo); hi = fmaxf(hi, t.hi);
+            const DepthTile t0 = table[r0 + tx], t1 = table[r1 + tx], t2 = table[r2 + tx], t3 = table[r3 + tx];
+            lo = fminf(lo, fminf(fminf(t0.lo, t1.lo), fminf(t2.lo, t3.lo)));
+            hi = fmaxf(hi, fmaxf(fmaxf(t0.hi, t1.hi), fmaxf(t2.hi, t3.hi)));
         }
+    }
     lo = fold8<false>(lo); hi = fold8<true>(hi);
     const float band = (a.tranc_dist * 1.001f + 1e-5f) + 2e-4f;   // the walk's own band (update_voxel) + margin
     if (cmin - hi > band) return all_empty;                 // behind everything the box can see (hi = 0: nothing valid there)
@@ -875,75 +881,106 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
     }
 }
 
-// The class of every box of every listed brick (see classify_box): eight lanes per box, 32 boxes = 8 bricks per workgroup and trip.
+// ---- the list and its order ---------------------------------------------------------------------------------------------------
+// A list is two runs in a region of list_cap entries: nwalk entries from the region's front and nother entries from its back, the two
+// counts in one 8-byte word of the workspace header (ListPair) — so that a kernel reserves room in both runs with ONE atomic, and no
+// entry's place depends on a total that is only known when every workgroup has reported.  Entry e of the list is region[e] for
+// e < nwalk, else region[list_cap - 1 - (e - nwalk)] (list_at).  k_classify_bricks alone fills only the front run, in plane order.
 //
-// The kernel also decides the ORDER in which k_integrate_bricks takes the bricks: it writes a second list (ord.list) and the classes by
-// the entries of that list.  A launch with no more bricks than resident workgroups (the benchmark scene: 1 860 bricks, 1 536 workgroups
-// resident at once, the rest as soon as a slot is free) gives every brick its own workgroup and the dispatcher deals consecutive workgroups
-// round the CUs, so entries e, e + 256, e + 512 ... share a CU.  Half of the bricks are walked voxel by voxel — instruction issue, ~0.4 us of
-// SIMD time per plane — and in plane order a CU's share of those ranges from 8 to 192 planes (mean 114): the launch lasts as long as the
-// fullest CU (23 us where the emptiest is done after 10: profiles/r04_integrate_wg_times.txt).  Bricks with planes to walk therefore go to
-// the front of the list, in arrival order, the others fill it from the back: every CU gets its 3 or 4 walked bricks, and the streaming
-// ones run beside them.  Two atomics per workgroup and trip (eight bricks); above ord.limit bricks the order is the plane order (taken
-// from the far end when the camera looks up the z axis: KF_FAR_FIRST) — such launches run several rounds of workgroups, which balances
-// them, and their atomics would serialise (~12 ns each on one address).
-// The counters (header words ORDER_WORD, + 1) are zero when the kernel starts: the header clear zeroes them, and the last workgroup to
-// leave (ticket: word + 2) puts them back, so that a second classification of the same list (XS_INTEGRATE_RECLASSIFY_BOXES) finds them so.
-struct BoxOrder { int *list; unsigned limit; unsigned far_first; };
-enum { ORDER_WORD = 52 };
-__global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl, const BoxOrder ord) {
-    const unsigned count = *a.brick_count;
-    const int tid = (int)threadIdx.x, corner = tid & 7, box = (tid >> 3) & (BOXES_PER_BRICK - 1), slot = tid >> 5;
-    __shared__ unsigned s_kind[8], s_pos[8];
-    const bool sorted = ord.list != nullptr && count <= ord.limit;
-    for (unsigned e0 = blockIdx.x * 8u; e0 < count; e0 += gridDim.x * 8u) {
-        const unsigned e = e0 + slot;
-        const bool live = e < count;    // (whole groups of 32 lanes: the cross-lane steps stay inside a group)
-        int b = 0, nz = 0;
-        unsigned word = 0;
-        if (live) {
-            b = a.brick_list[e];
-            const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
-            const int wx0 = bx * BRICK_X + (box * 64) % BRICK_X, wy0 = by * BRICK_Y + (box * 64) / BRICK_X;
-            const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
-            nz = ze0 - zb0;
-            word = box_word(0, nz, 0);   // a wave without a column of the brick in the volume: nothing to write
-            if (wx0 < a.X && wy0 < a.Y) word = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
+// With the boxes' classes known the front run holds the bricks that have planes to walk voxel by voxel and the back run the others, and
+// k_integrate_bricks takes the list front to back.  Why: a launch with no more bricks than resident workgroups (the benchmark scene:
+// 1 860 bricks, 1 536 workgroups resident at once, the rest as soon as a slot is free) gives every brick its own workgroup and the
+// dispatcher deals consecutive workgroups round the CUs, so entries e, e + 256, e + 512 ... share a CU.  Half of the bricks are walked —
+// instruction issue, ~0.4 us of SIMD time per plane — and in plane order a CU's share of those ranges from 8 to 192 planes (mean 114):
+// the launch lasts as long as the fullest CU (23 us where the emptiest is done after 10: profiles/r04_integrate_wg_times.txt).  With the
+// walked bricks in front every CU gets 3 or 4 of them and the streaming ones run beside (S1 kernel 26.7 -> 24.7 us).  Larger launches
+// run several rounds of workgroups, which balances them by itself; there the order puts the issue-bound walks in front and lets the
+// streaming fill in around them instead of leaving a tail of walks (S2 0.143 -> 0.130 ms, S1 at 1024^3 78.8 -> 75.3 us).
+enum { PAIR_PRIMARY = 0, PAIR_SECOND = 52 };   // header words of the two ListPairs: k_classify_bricks'; k_classify_boxes'
+__device__ __forceinline__ unsigned list_at(unsigned e, unsigned nwalk, unsigned cap) { return e < nwalk ? e : cap - 1u - (e - nwalk); }
+__device__ __forceinline__ unsigned long long list_reserve(unsigned *pair, unsigned n_walk, unsigned n_other) {   // -> the runs' lengths before
+    return atomicAdd(reinterpret_cast<unsigned long long *>(pair), (unsigned long long)n_walk | ((unsigned long long)n_other << 32));
+}
+// One brick's four boxes by the 32 lanes of a half-wave (8 lanes per box, see classify_box); the box's word in all of its eight lanes, bit
+// 31 set when the box has planes to walk.  KF_COUNT_CLASSES: counted in the header.
+__device__ __forceinline__ unsigned classify_brick_boxes(const IntegrateArgs &a, const BoxSlack &sl, int b, int box, int corner) {
+    const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
+    const int wx0 = bx * BRICK_X + (box * 64) % BRICK_X, wy0 = by * BRICK_Y + (box * 64) / BRICK_X;
+    const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
+    const int nz = ze0 - zb0;
+    unsigned word = box_word(0, nz, 0);   // a wave without a column of the brick in the volume: nothing to write
+    if (wx0 < a.X && wy0 < a.Y) word = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
 #if defined(XS_PROBE_ALL_FREE)   // measurement only (wrong volume): every walked plane streams like free space — the free path's ceiling
-            if ((int)(word & 0xff) + (int)((word >> 8) & 0xff) < nz) word = box_word(nz, 0, 0);
+    if ((int)(word & 0xff) + (int)((word >> 8) & 0xff) < nz) word = box_word(nz, 0, 0);
 #endif
+    const int nf = (int)(word & 0xff), ne = (int)((word >> 8) & 0xff);
+    if (corner == 0 && (a.kflags & KF_COUNT_CLASSES)) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
+        atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
+        atomicAdd(a.brick_count + CLASS_COUNT_WORD + 3, (unsigned)(nz - nf - ne));
+    }
+    return word | (nf + ne < nz ? 1u << 31 : 0u);
+}
+// What a workgroup does with the n bricks it holds in LDS (s_brick; their boxes' words in s_word, bit 31 = planes to walk): the first
+// wave ranks them inside the two runs, reserves room for both with one atomic, and all threads write the entries and the classes.
+// Call from every thread; s_pos: n words; s_base: 2 words.
+__device__ __forceinline__ void list_append(const IntegrateArgs &a, unsigned *pair, int *region, unsigned n, const int *s_brick, const unsigned *s_word,
+                                            unsigned *s_pos, unsigned *s_base) {
+    const unsigned tid = threadIdx.x;
+    if (tid < 64u) {
+        unsigned nw = 0, no = 0;
+        const unsigned long long below = (1ull << tid) - 1ull;
+        for (unsigned c = 0; c < n; c += 64u) {
+            const unsigned k = c + tid;
+            const bool live = k < n;
+            const bool walk = live && ((s_word[k * 4] | s_word[k * 4 + 1] | s_word[k * 4 + 2] | s_word[k * 4 + 3]) >> 31) != 0u;
+            const unsigned long long m1 = __ballot(walk), m2 = __ballot(live && !walk);
+            if (live) s_pos[k] = walk ? nw + (unsigned)__popcll(m1 & below) : (1u << 31) | (no + (unsigned)__popcll(m2 & below));
+            nw += (unsigned)__popcll(m1); no += (unsigned)__popcll(m2);
         }
-        const int nf = (int)(word & 0xff), ne = (int)((word >> 8) & 0xff);
-        unsigned pos = ord.far_first ? count - 1u - e : e;
-        if (sorted) {   // (uniform over the workgroup)
-            int walked = nz - nf - ne;    // this box's; the same in its eight lanes
-            walked += __shfl_xor(walked, 8); walked += __shfl_xor(walked, 16);   // the brick's
-            if ((tid & 31) == 0) s_kind[slot] = !live ? 0u : walked > 0 ? 1u : 2u;
-            __syncthreads();
-            if (tid == 0) {
-                unsigned n1 = 0, n2 = 0;
-                for (int k = 0; k < 8; ++k) { n1 += s_kind[k] == 1u; n2 += s_kind[k] == 2u; }
-                unsigned front = n1 ? atomicAdd(a.brick_count + ORDER_WORD, n1) : 0u, back = n2 ? atomicAdd(a.brick_count + ORDER_WORD + 1, n2) : 0u;
-                for (int k = 0; k < 8; ++k) s_pos[k] = s_kind[k] == 1u ? front++ : count - 1u - back++;
-            }
-            __syncthreads();
-            pos = s_pos[slot];
-        }
-        if (live && corner == 0) {
-            a.box_class[(size_t)pos * BOXES_PER_BRICK + box] = word;
-            if (box == 0 && ord.list) ord.list[pos] = b;
-            if (a.kflags & KF_COUNT_CLASSES) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
-                atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
-                atomicAdd(a.brick_count + CLASS_COUNT_WORD + 3, (unsigned)(nz - nf - ne));
-            }
+        if (tid == 0 && n) {
+            const unsigned long long was = list_reserve(pair, nw, no);
+            s_base[0] = (unsigned)was; s_base[1] = (unsigned)(was >> 32);
         }
     }
-    if (sorted && blockIdx.x * 8u < count) {   // (the workgroups that had a trip)
-        const unsigned workers = min(gridDim.x, (count + 7u) / 8u);
-        __syncthreads();
-        if (tid == 0 && atomicAdd(a.brick_count + ORDER_WORD + 2, 1u) == workers - 1u) {
-            atomicExch(a.brick_count + ORDER_WORD, 0u); atomicExch(a.brick_count + ORDER_WORD + 1, 0u); atomicExch(a.brick_count + ORDER_WORD + 2, 0u);
+    __syncthreads();
+    for (unsigned i = tid; i < n * BOXES_PER_BRICK; i += blockDim.x) {
+        const unsigned k = i / BOXES_PER_BRICK, r = s_pos[k];
+        const unsigned pos = (r >> 31) ? a.list_cap - 1u - (s_base[1] + (r & 0x7fffffffu)) : s_base[0] + r;
+        a.box_class[(size_t)pos * BOXES_PER_BRICK + i % BOXES_PER_BRICK] = s_word[i] & 0x7fffffffu;
+        if (i % BOXES_PER_BRICK == 0) region[pos] = s_brick[k];
+    }
+}
+
+// The boxes' classes for the list k_classify_bricks left (the primary pair and region), and the list again in the order
+// k_integrate_bricks takes it (the second pair and region: ord).  Eight lanes per box, 8 bricks per workgroup and trip; a reservation
+// per 8 bricks while the launch is small, per 64 beyond (S2's 23 000 bricks then take 360 atomics instead of 2 900; ~12 ns each on one
+// address).  Batches are runs of list neighbours and arrive roughly in list order, so each run of the ordered list keeps the plane order
+// of the first — which matters: the same bricks dealt round the workgroups of a fused kernel (frustum test + classes in one launch, no
+// faster: 12.5 us against 3.8 + 8.4) came out in an order that made the S2 launch 9 % slower (profiles/r04_ab_classify_fused.txt).
+// The second pair is zero when the kernel starts (the launcher clears it).
+struct BoxOrder { int *list; };
+enum { ORDER_BATCH = 64 };
+__global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl, const BoxOrder ord) {
+    const unsigned nwalk = a.brick_count[PAIR_PRIMARY], count = nwalk + a.brick_count[PAIR_PRIMARY + 1];
+    const int tid = (int)threadIdx.x, corner = tid & 7, box = (tid >> 3) & (BOXES_PER_BRICK - 1), slot = tid >> 5;
+    __shared__ unsigned s_word[ORDER_BATCH * BOXES_PER_BRICK], s_pos[ORDER_BATCH], s_base[2];
+    __shared__ int s_brick[ORDER_BATCH];
+    const unsigned batch = count <= 4096u ? 8u : (unsigned)ORDER_BATCH;
+    for (unsigned e0 = blockIdx.x * batch; e0 < count; e0 += gridDim.x * batch) {
+        const unsigned n = min(batch, count - e0);
+        for (unsigned r = 0; r < n; r += 8u) {
+            const unsigned k = r + slot;
+            if (k >= n) continue;    // (whole groups of 32 lanes)
+            const int b = a.brick_list[list_at(e0 + k, nwalk, a.list_cap)];
+            const unsigned word = classify_brick_boxes(a, sl, b, box, corner);
+            if (corner == 0) {
+                s_word[k * BOXES_PER_BRICK + box] = word;
+                if (box == 0) s_brick[k] = b;
+            }
         }
+        __syncthreads();
+        list_append(a, a.brick_count + PAIR_SECOND, ord.list, n, s_brick, s_word, s_pos, s_base);
+        __syncthreads();
     }
 }
 
@@ -991,7 +1028,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
 #if defined(XS_PROBE_WG_TIMES)   // measurement only: every workgroup's begin / end on the 100 MHz wall clock, 512 KiB into the tile room of the workspace
     const unsigned long long probe_t0 = wall_clock64();
 #endif
-    const unsigned count = *a.brick_count;
+    const unsigned nwalk = a.brick_count[a.pair_word], count = nwalk + a.brick_count[a.pair_word + 1];   // (see "the list and its order")
     unsigned n_upd = 0;
     const float far = far_limit(a);
     // The column clip's 20 plane scalars are used once per brick, outside the voxel loop.  Held in scalar registers for the
@@ -1004,11 +1041,19 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     // on different CUs — measured 29 -> 42 us on S1: the dispatcher deals consecutive workgroups round the CUs, so the eight workgroups of
     // a CU already take entries 256 apart; profiles/r04_integrate_wg_times.txt.)
     const unsigned first = blockIdx.x, stride = gridDim.x;
-    // The list is in plane order (z slowest).  Where the camera looks up the z axis the bricks of the surfaces — the walked, expensive
-    // ones — come last, and a launch ends with a tail of them, bound by instruction issue, after the free-space bricks have streamed:
-    // taken from its far end the list starts with them and the streaming fills in around (KF_FAR_FIRST, set by the launcher from the pose).
+    // A list without classes (k_classify_bricks alone) is in plane order (z slowest).  Where the camera looks up the z axis the bricks of
+    // the surfaces — the walked, expensive ones — come last, and a launch ends with a tail of them, bound by instruction issue, after the
+    // free-space bricks have streamed: taken from its far end the list starts with them and the streaming fills in around (KF_FAR_FIRST,
+    // set by the launcher from the pose; never for a list that is ordered by class).
     const bool far_first = (a.kflags & KF_FAR_FIRST) != 0;
-    auto entry = [&](unsigned e) { return far_first ? count - 1u - e : e; };
+#if defined(XS_PROBE_ZIP)   // experiment: groups of XS_PROBE_ZIP entries alternately from the front (walked bricks) and the back (streaming ones) of an ordered list
+    auto entry = [&](unsigned e) {
+        const unsigned g = e / XS_PROBE_ZIP, i = (g >> 1) * XS_PROBE_ZIP + e % XS_PROBE_ZIP;
+        return list_at((g & 1u) ? count - 1u - i : i, nwalk, a.list_cap);
+    };
+#else
+    auto entry = [&](unsigned e) { return list_at(far_first ? count - 1u - e : e, nwalk, a.list_cap); };
+#endif
     // the first entry and its class are requested together, in front of the barrier
     int b_next = 0, cls_next = BOX_MIXED;
     if (first < count) {
@@ -1115,7 +1160,7 @@ struct DepthRing {
 };
 template <bool BILINEAR>
 __global__ void __launch_bounds__(256, 8) k_integrate_bricks_ring(const IntegrateArgs a) {
-    const unsigned count = *a.brick_count;
+    const unsigned nwalk = a.brick_count[a.pair_word], count = nwalk + a.brick_count[a.pair_word + 1];
     unsigned n_upd = 0;
     __shared__ ClipPlanes s_cp;
     __shared__ unsigned s_ring[4][2][3][64];   // per wave: two slots of (value, grad, weight) rows
@@ -1128,7 +1173,7 @@ __global__ void __launch_bounds__(256, 8) k_integrate_bricks_ring(const Integrat
     const size_t plane_bytes = (size_t)a.Y * a.vstep;
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
     for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
-        const int b = __builtin_amdgcn_readfirstlane(a.brick_list[e]);
+        const int b = __builtin_amdgcn_readfirstlane(a.brick_list[list_at(e, nwalk, a.list_cap)]);
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
         const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
@@ -1254,6 +1299,9 @@ static void host_frustum(IntegrateArgs &a, float slack_scale = 1.0f) {
 // optional profiling hook: HIP events recorded immediately around the integrate kernel proper
 // (after the brick classification), on the launch stream
 static thread_local hipEvent_t g_int_ev0 = nullptr, g_int_ev1 = nullptr;
+// completion event of xs_integrate_classify's launches (rides on the last dispatch): for a caller that classifies on one stream and integrates on another
+static thread_local hipEvent_t g_class_ev = nullptr;
+extern "C" void xs_integrate_set_classify_event(void *done_event) { g_class_ev = (hipEvent_t)done_event; }
 extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) {
     g_int_ev0 = (hipEvent_t)start_event; g_int_ev1 = (hipEvent_t)stop_event;
 }
@@ -1341,20 +1389,47 @@ static bool far_end_first(const IntegrateArgs &a) {
     static const char *env_order = getenv("XS_INTEGRATE_ORDER");   // A/B aid: "near" / "far" force the list direction
     return env_order ? !strcmp(env_order, "far") : a.R.data[2].z.re > 0.0f;
 }
-// k_classify_boxes behind the brick classification, if a tile table is there and the class array fits; true = a.box_class is being written
-static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st) {
-    if (!tiles) return false;
-    a.dt = depth_tiles_view(tiles, a.drows, a.dcols);
+// the workspace's header, primary list region and capacity
+static void bind_workspace(IntegrateArgs &a, const int *res, int nz, void *workspace) {
+    a.brick_count = (unsigned *)workspace;
+    a.brick_list = (int *)((char *)workspace + 256);
+    a.list_cap = (unsigned)workspace_bricks(res, nz); a.pair_word = PAIR_PRIMARY;
+}
+static void bind_classes(IntegrateArgs &a, const int *res, int nz, void *workspace) {
     a.box_class = reinterpret_cast<unsigned *>((char *)workspace + workspace_list_bytes(res, nz));
     a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
+}
+// ... and the list k_classify_boxes has ordered, which the classes are filed under
+static void bind_ordered_list(IntegrateArgs &a, const int *res, int nz, void *workspace) {
+    bind_classes(a, res, nz, workspace);
+    a.brick_list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz)); a.pair_word = PAIR_SECOND;
+}
+// k_classify_boxes for the list that is there (the primary one): classes and order go to the second pair and region, which a then names.
+// done: completion event to ride on the dispatch, or null.
+static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st,
+                               bool second_pair_is_clear, hipEvent_t done = nullptr) {
+    if (!tiles) return false;
+    a.dt = depth_tiles_view(tiles, a.drows, a.dcols);
+    bind_classes(a, res, nz, workspace);
+    // (a list classed a second time — XS_INTEGRATE_RECLASSIFY_BOXES — finds the first classification's counts there; behind a header clear the pair is zero)
+    if (!second_pair_is_clear && hipMemsetAsync(a.brick_count + PAIR_SECOND, 0, 2 * sizeof(unsigned), st) != hipSuccess) return false;
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-    // the order the integrate kernel takes the bricks in (see k_classify_boxes); XS_INTEGRATE_SORT_LIMIT: A/B aid (0: plane order always)
-    static const int env_limit = getenv("XS_INTEGRATE_SORT_LIMIT") ? atoi(getenv("XS_INTEGRATE_SORT_LIMIT")) : 4096;
     BoxOrder ord;
     ord.list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz));
-    ord.limit = (unsigned)env_limit; ord.far_first = (a.kflags & KF_FAR_FIRST) ? 1u : 0u;
-    hipLaunchKernelGGL(k_classify_boxes, dim3(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048), dim3(256), 0, st, a, sl, ord);
+    const dim3 grid(div_up(nb, 8) < 2048 ? div_up(nb, 8) : 2048);
+    if (done) hipExtLaunchKernelGGL(k_classify_boxes, grid, dim3(256), 0, st, nullptr, done, 0, a, sl, ord);
+    else hipLaunchKernelGGL(k_classify_boxes, grid, dim3(256), 0, st, a, sl, ord);
+    a.brick_list = ord.list; a.pair_word = PAIR_SECOND;
     return true;
+}
+// The classification of a launch (header clear): the bricks against the frustum, then — with a tile table — their boxes' classes and the
+// list in order; true = a.box_class is being written.  done: completion event to ride on the last dispatch, or null.
+static bool launch_classification(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st,
+                                  hipEvent_t done = nullptr) {
+    const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
+    if (done && !tiles) hipExtLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+    return launch_box_classes(a, res, nz, workspace, tiles, sl, st, true, done);
 }
 // the pose-dependent part of the arguments the classification needs (what xs_integrate_scaled_ex sets up for it)
 static void classify_args(IntegrateArgs &a, int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18,
@@ -1388,23 +1463,18 @@ extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, con
     classify_args(a, rows, cols, intr4, res, voxel_size, Rv2c18, tv2c6, tranc_dist, z0, z1, depth_max_dev);
     if (!(a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047)) return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify: volume too large for the brick list");
     for (int p = 0; p < 6; ++p) a.fr.slack[p] *= slack_scale;
-    a.brick_count = (unsigned *)workspace;
-    a.brick_list = (int *)((char *)workspace + 256);
+    bind_workspace(a, res, z1 - z0, workspace);
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
-    const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-    hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
     // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
     // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
     static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;
     g_classes_of = nullptr;
     const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
-    if (!env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32) {
-        if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
-        if (far_end_first(a)) a.kflags |= KF_FAR_FIRST;
-        a.tranc_dist = tranc_dist;
-        if (launch_box_classes(a, res, z1 - z0, workspace, g_depth_tiles, box_slack(a, slack_scale), st)) g_classes_of = workspace;
-    }
+    const bool boxes = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32 && g_depth_tiles;
+    if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
+    // (the caller's completion event — xs_integrate_set_classify_event — rides on the dispatch)
+    if (launch_classification(a, res, z1 - z0, workspace, boxes ? g_depth_tiles : nullptr, box_slack(a, slack_scale), st, g_class_ev)) g_classes_of = workspace;
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -1497,14 +1567,36 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     a.zchunk = nz;
     dim3 block(64, 4);
     if (workspace && a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047) {  // packed brick ids: 10 + 10 + 11 bits
-        a.brick_count = (unsigned *)workspace;
-        a.brick_list = (int *)((char *)workspace + 256);
+        bind_workspace(a, res, nz, workspace);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
+        // 32-bit lane offsets from the brick's first voxel whenever a brick spans less than 4 GiB of an array (always, short of absurd
+        // pitches): no spills, the state loads take a scalar base (S1 launch 40.5 -> 39.2 us for the whole call, S2 unchanged)
+        static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel; "off64" = 64-bit pointers per lane
+        const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
+        const bool ring = env_k && !strcmp(env_k, "ring") && !a.signmap && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31);
+        const bool sign = a.signmap != nullptr;
+        // the boxes' classes (free space / nothing to write / exact walk) and the list's order: those xs_integrate_classify left for this
+        // list, or decided here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here,
+        // in the workspace
+        static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;   // A/B aid, as the flag
+        const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
+        g_classes_of = nullptr;
+        const bool use_tiles = off32 && !ring && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
+        auto tile_table = [&]() -> const DepthTile * {   // the caller's, or one built in the workspace's tile room
+            if (g_depth_tiles || xs_depth_tiles_bytes(rows, cols) > TILE_ROOM_BYTES) return g_depth_tiles;
+            DepthTile *own = reinterpret_cast<DepthTile *>((char *)workspace + workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz));
+            launch_scale_depth(depth_scaled, scaled_step, rows, cols, (float *)nullptr, (size_t)0, (float *)nullptr, own, st);
+            return own;
+        };
         if (!(flags & XS_INTEGRATE_LIST_IS_READY)) {   // (else: xs_integrate_classify has run on this stream for a covering pose)
             if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR))
-                XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // brick count + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
-            hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+                XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // list pairs + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
+            launch_classification(a, res, nz, workspace, use_tiles ? tile_table() : nullptr, BoxSlack{0.f, 0.f, 0.f}, st);
+        } else if (use_tiles) {
+            if (classes_ahead) bind_ordered_list(a, res, nz, workspace);
+            else if (!posted) launch_box_classes(a, res, nz, workspace, tile_table(), BoxSlack{0.f, 0.f, 0.f}, st, false);   // (a posted launch has no pose yet to classify with)
         }
+        if (a.box_class) a.kflags &= ~(unsigned)KF_FAR_FIRST;   // the list is ordered by class
         // resident workgroups stride over the list: 256 CUs x 8
         static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
         const int gmax = env_g > 0 ? env_g : 8192;
@@ -1513,35 +1605,6 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // the kernel's own begin / end timestamps), so it adds no marker packets to the stream and times what
         // rocprofv3 times
         // (either event may be null: a completion event alone lets another stream wait for this kernel without a marker packet)
-        // 32-bit lane offsets from the brick's first voxel whenever a brick spans less than 4 GiB of an array (always, short of absurd
-        // pitches): no spills, the state loads take a scalar base (S1 launch 40.5 -> 39.2 us for the whole call, S2 unchanged)
-        static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel; "off64" = 64-bit pointers per lane
-        const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
-        const bool sign = a.signmap != nullptr;
-        // the boxes' classes (free space / nothing to write / exact walk): those xs_integrate_classify left for this list, or classified
-        // here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here, in the workspace
-        static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;   // A/B aid, as the flag
-        const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
-        g_classes_of = nullptr;
-        if (off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES)) {
-            if (classes_ahead) {
-                a.box_class = reinterpret_cast<unsigned *>((char *)workspace + workspace_list_bytes(res, nz));
-                a.probe_offset = workspace_class_bytes(res, nz) + TILE_ROOM_BYTES / 4;
-            }
-            else if (!posted) {   // (a posted launch has no pose yet to classify with)
-                const DepthTile *tiles = g_depth_tiles;
-                if (!tiles && xs_depth_tiles_bytes(rows, cols) <= TILE_ROOM_BYTES) {
-                    DepthTile *own = reinterpret_cast<DepthTile *>((char *)workspace + workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz));
-                    launch_scale_depth(depth_scaled, scaled_step, rows, cols, (float *)nullptr, (size_t)0, (float *)nullptr, own, st);
-                    tiles = own;
-                }
-                launch_box_classes(a, res, nz, workspace, tiles, BoxSlack{0.f, 0.f, 0.f}, st);
-            }
-        }
-        if (a.box_class) {   // k_classify_boxes has also put the bricks in the order they are taken in
-            a.brick_list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz));
-            a.kflags &= ~(unsigned)KF_FAR_FIRST;
-        }
         void (*kern)(const IntegrateArgs) =
             sign ? (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true, false, true> : k_integrate_bricks<true, false, false, true>)
                                      : (off32 ? k_integrate_bricks<false, true, false, true> : k_integrate_bricks<false, false, false, true>))
@@ -1553,8 +1616,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
                         : (threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>);
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
-        if (env_k && !strcmp(env_k, "ring") && !a.signmap && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31))
-            kern = k_integrate_bricks_ring<false>;
+        if (ring && !a.box_class) kern = k_integrate_bricks_ring<false>;
         static const int env_lds = getenv("XS_INTEGRATE_DYN_LDS") ? atoi(getenv("XS_INTEGRATE_DYN_LDS")) : 0;   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, g_int_ev0, g_int_ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, env_lds, st, a);

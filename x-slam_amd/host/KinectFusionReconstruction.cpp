@@ -20,6 +20,7 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipEventCreateWithFlags(&surface_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&scale_done_, hipEventDisableTiming));
+    hipSafeCall(hipEventCreateWithFlags(&classify_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&tail_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&surface_done_next_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&scale_done_next_, hipEventDisableTiming));
@@ -35,6 +36,8 @@ void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn 
 }
 
 KinectFusionReconstruction::~KinectFusionReconstruction() {
+    if (getenv("XS_KF_DEBUG_COVERS"))   // tuning aid: how often the list classified ahead held for the final pose (0: neither list nor classes, 1: the list only, 3: both)
+        std::fprintf(stderr, "list covers: none %lld  list only %lld  list and box classes %lld\n", list_cover_counts_[0], list_cover_counts_[1], list_cover_counts_[3]);
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (surface_done_) (void)hipEventDestroy(surface_done_);
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
@@ -42,6 +45,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (surface_done_next_) (void)hipEventDestroy(surface_done_next_);
     if (scale_done_next_) (void)hipEventDestroy(scale_done_next_);
     if (scale_done_) (void)hipEventDestroy(scale_done_);
+    if (classify_done_) (void)hipEventDestroy(classify_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (gather_counts_host_) (void)hipHostFree(gather_counts_host_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
@@ -121,6 +125,8 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     icp_post_pose = config.as<bool>("icp_post_pose", true);
     icp_real_current_maps = config.as<bool>("icp_real_current_maps", true);
     integrate_classify_ahead = config.as<bool>("integrate_classify_ahead", true);
+    integrate_classify_beside_icp = config.as<bool>("integrate_classify_beside_icp", false);
+    integrate_classify_early = std::max(0, config.as<int>("integrate_classify_early", 0));
     integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
     integrate_post_pose = config.as<bool>("integrate_post_pose", false);
     integrate_post_early = config.as<bool>("integrate_post_early", false);
@@ -401,7 +407,9 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 // (with integrate_post_pose the integrate kernel follows the classification into the queue, gated on its mailbox: the host's three
                 // launches — classification, gate, integrate — go in while the last, 18 us, ICP launch runs; integrate_post_early puts them in one
                 // iteration earlier, with planes from a pose two updates old: 16 % of those were not covered at slack 2)
-                if ((integrate_post_pose && integrate_post_early ? enqueued == total_iters : n == total_iters - 1) && !list_ready_ && integrate_classify_ahead && integrate_split())
+                // (integrate_classify_early = k: k iterations before the last, i.e. for a pose k + 1 updates old — on the auxiliary stream the
+                // classification is then finished long before the final pose is, and the integrate launch needs no wait packet)
+                if ((integrate_post_pose && integrate_post_early ? enqueued == total_iters : n == std::max(0, total_iters - 1 - integrate_classify_early)) && !list_ready_ && integrate_classify_ahead && integrate_split())
                     ClassifyAhead(Rcurr, tcurr);
                 const unsigned long long seq = seq_of[n];
                 if (n + 1 < total_iters) {
@@ -641,15 +649,22 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
     Vector3cf tv2c = GetTranslation(v2c);
     std::memcpy(list_Rv2c_, &device_cast<MatS33>(Rv2c).data[0].x.re, sizeof(list_Rv2c_));
     std::memcpy(list_tv2c_, &device_cast<devComplex3>(tv2c).x.re, sizeof(list_tv2c_));
-    hipStream_t st = current_stream();
+    // integrate_classify_beside_icp (off by default: measured, no gain — see the header): on the auxiliary stream instead; everything the two
+    // classification kernels read — the scaled depth's maximum, the tile table, the cleared header — was written on that stream.  The integrate
+    // launch then waits for their completion event.
+    const bool beside = integrate_classify_beside_icp && aux_stream_ && integrate_header_clear_;
+    hipStream_t st = beside ? aux_stream_ : current_stream();
     // the scaled depth's maximum and the cleared header come from the auxiliary stream
-    if (scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
+    if (!beside && scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
     xs_integrate_set_depth_tiles(depth_tiles_.ptr());   // the boxes' classes are decided here too, with the slack's pads (xs_integrate_list_covers checks the final pose against them)
+    if (beside) xs_integrate_set_classify_event(classify_done_);
     check_rc(xs_integrate_classify(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
                                    tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
                                    integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
+    xs_integrate_set_classify_event(nullptr);
     xs_integrate_set_depth_tiles(nullptr);
+    classify_recorded_ = beside;
     list_ready_ = true;
     EnqueuePostedIntegrate();
 }
@@ -671,6 +686,7 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     if (!integrate_post_pose || !integrate_split() || !integrate_mailbox_ || !integrate_mailbox_in_device_ || !list_ready_) return;
     if (zs0 != zo0 || zs1 != zo1) return;   // (halo bands: several calls per frame)
     hipStream_t st = current_stream();
+    WaitForClassification(st);
     unsigned long long *counters = PrepareFrameCounters(st);
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
@@ -707,9 +723,16 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
 // stream, has filled the workspace header, and reads the frame's depth maximum — while the retried frame's SurfaceMeasure clears that header
 // and rewrites the maximum on the auxiliary stream, ordered only behind the previous frame's integrate kernel.  So the failure path (rare: a
 // singular system, a launch that timed out) drains the main stream, clears the header there and forgets the list.
+// the list and classes ClassifyAhead left on the auxiliary stream: the stream st reads them next
+void KinectFusionReconstruction::WaitForClassification(hipStream_t st) {
+    if (!classify_recorded_) return;
+    classify_recorded_ = false;
+    if (hipEventQuery(classify_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, classify_done_, 0));
+}
 void KinectFusionReconstruction::AbandonClassifiedList() {
     if (!list_ready_) return;
     list_ready_ = false;
+    if (classify_recorded_) { classify_recorded_ = false; hipSafeCall(hipStreamSynchronize(aux_stream_)); }
     if (posted_pending_) {   // the integrate launch waiting for this frame's pose leaves without touching the volume
         xs_icp_post_pose(integrate_mailbox_, nullptr, nullptr, posted_seq_, 1);
         posted_pending_ = false;
@@ -810,8 +833,10 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             unsigned list_flag = 0;
             if (i == 0 && list_ready_) {
                 list_ready_ = false;
+                WaitForClassification(st);
                 const int covers = xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_,
                                                             list_tv2c_, integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re);
+                ++list_cover_counts_[covers & 3];
                 if (covers)   // (bit 1 clear: the list holds but the boxes' classes were padded for a nearer pose — they are decided again, the list stays)
                     list_flag = XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR | ((covers & 2) ? 0u : XS_INTEGRATE_RECLASSIFY_BOXES);
                 else   // the last update moved the frustum further than the widened list allows for (never seen): start over

@@ -58,6 +58,14 @@ public:
     // the integrate call's brick classification enqueued behind the last ICP launch, with the pose that launch starts from (YAML
     // integrate_classify_ahead, default true; single GPU with the posted ICP loop): IntegrateFrame then finds the list ready
     bool integrate_classify_ahead = true;
+    // ... on the auxiliary stream, beside that launch instead of behind it (YAML integrate_classify_beside_icp, default FALSE).  Measured, no
+    // gain: a level-0 ICP launch fills the chip (one 16-wave workgroup per CU, all of its registers and 158 of 160 KB of LDS), so the two
+    // classification kernels do not run beside it but in front of its workgroups — the launch they share the chip with takes 26 us
+    // instead of 17.7 — and an integrate launch that has to wait for another stream's event starts 10 us later than one that follows its
+    // own queue (profiles/r04_ab_classify_beside_icp.txt).
+    bool integrate_classify_beside_icp = false;
+    int integrate_classify_early = 0;          // YAML integrate_classify_early: that many ICP iterations before the last (a pose that many more updates old)
+    long long list_cover_counts_[4] = {0, 0, 0, 0};   // what xs_integrate_list_covers said of the lists classified ahead (XS_KF_DEBUG_COVERS prints them)
     // the integrate kernel itself enqueued behind that classification, handed the final pose through a mailbox of its own and a one-wave gate
     // kernel (YAML integrate_post_pose, default FALSE; needs integrate_classify_ahead and a mailbox in device memory).  Round 3, first form: all
     // three launches went in one ICP iteration early (YAML integrate_post_early) — 16 % of the frames were then not covered by the planes of a
@@ -302,6 +310,9 @@ public:
     unsigned debug_post_rng_ = 12345u;
 private:
     void AbandonClassifiedList();
+    void WaitForClassification(hipStream_t st);
+    hipEvent_t classify_done_ = nullptr;       // completion of ClassifyAhead's launches on the auxiliary stream (rides on the last dispatch)
+    bool classify_recorded_ = false;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
     hipEvent_t surface_done_ = nullptr, integrate_done_ = nullptr, scale_done_ = nullptr;
     hipEvent_t integrate_done_now_ = nullptr;   // the event that marks the last integrate call's completion (integrate_done_, or its dispatch's stop event)
