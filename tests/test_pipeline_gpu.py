@@ -241,13 +241,20 @@ def test_brick_list_classified_ahead_changes_nothing(dev):
     starts from) against the plain order and against a list slack of 1 — with which no final pose is ever covered, so every frame
     takes the fall-back (header cleared again, classification repeated); and integrate_post_pose (the integrate kernel itself
     enqueued behind the classification and handed the final pose through its mailbox), covered and — slack 1 — never covered (the
-    posted launch told to leave every frame): the same poses, counts and volume, bit for bit."""
+    posted launch told to leave every frame): the same poses, counts and volume, bit for bit.  Also the two scheduling switches that
+    were measured and left off: the classification on the auxiliary stream beside the ICP launch (integrate_classify_beside_icp: the
+    integrate launch waits for its completion event) and one / two ICP iterations early (integrate_classify_early: a pose that many
+    more updates old — some frames then classify again, some decide only the boxes again)."""
     torch, pl = dev
     prm = synth.s1_params(128)
     runs = [pl.KinectFusion(dict(prm, integrate_classify_ahead=False)), pl.KinectFusion(dict(prm, integrate_classify_ahead=True)),
             pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_slack=1.0)),
             pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_post_pose=True)),
-            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_post_pose=True, integrate_classify_slack=1.0))]
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_post_pose=True, integrate_classify_slack=1.0)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True, integrate_classify_early=1)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_early=2)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True, integrate_post_pose=True))]
     blank = upload(torch, np.zeros_like(synth.s1_frame(0)))
     for k in list(range(6)) + ["blank", 6, 7]:
         d = blank if k == "blank" else upload(torch, synth.s1_frame(k))
