@@ -244,7 +244,8 @@ def test_brick_list_classified_ahead_changes_nothing(dev):
     posted launch told to leave every frame): the same poses, counts and volume, bit for bit.  Also the two scheduling switches that
     were measured and left off: the classification on the auxiliary stream beside the ICP launch (integrate_classify_beside_icp: the
     integrate launch waits for its completion event) and one / two ICP iterations early (integrate_classify_early: a pose that many
-    more updates old — some frames then classify again, some decide only the boxes again)."""
+    more updates old — some frames then classify again, some decide only the boxes again); and the classification at the frame's start
+    for a predicted pose (integrate_classify_predicted), at the usual slack and at a wide one."""
     torch, pl = dev
     prm = synth.s1_params(128)
     runs = [pl.KinectFusion(dict(prm, integrate_classify_ahead=False)), pl.KinectFusion(dict(prm, integrate_classify_ahead=True)),
@@ -254,7 +255,9 @@ def test_brick_list_classified_ahead_changes_nothing(dev):
             pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True)),
             pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True, integrate_classify_early=1)),
             pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_early=2)),
-            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True, integrate_post_pose=True))]
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_beside_icp=True, integrate_post_pose=True)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_predicted=True)),
+            pl.KinectFusion(dict(prm, integrate_classify_ahead=True, integrate_classify_predicted=True, integrate_classify_slack=6.0))]
     blank = upload(torch, np.zeros_like(synth.s1_frame(0)))
     for k in list(range(6)) + ["blank", 6, 7]:
         d = blank if k == "blank" else upload(torch, synth.s1_frame(k))

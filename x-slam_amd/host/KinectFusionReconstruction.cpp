@@ -127,6 +127,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     integrate_classify_ahead = config.as<bool>("integrate_classify_ahead", true);
     integrate_classify_beside_icp = config.as<bool>("integrate_classify_beside_icp", false);
     integrate_classify_early = std::max(0, config.as<int>("integrate_classify_early", 0));
+    integrate_classify_predicted = config.as<bool>("integrate_classify_predicted", false);
     integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
     integrate_post_pose = config.as<bool>("integrate_post_pose", false);
     integrate_post_early = config.as<bool>("integrate_post_early", false);
@@ -312,7 +313,7 @@ int KinectFusionReconstruction::AlignDepthToReconstruction(const DeviceArray2D<u
 // reference :177-235
 int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, Matrix3frm Rprev_inv, Vector3cf tprev) {
     icp_log.clear();
-    list_ready_ = false;
+    if (!list_predicted_) list_ready_ = false;   // (a list classified for the predicted pose, on the auxiliary stream, stays: SurfaceMeasure)
     if (frame_id == 0) return 0;
     Matrix4cf c2w_prev = inverse(world2camera_record.back());
     Matrix4cf c2w_curr = c2w_prev;
@@ -635,6 +636,14 @@ void KinectFusionReconstruction::flush_pending_fold(hipStream_t st) {
 }
 
 // reference :237-278
+// the volume-to-camera pose a list is classified for, from a camera-to-world one
+void KinectFusionReconstruction::SetListPose(const Matrix4cf &c2w) {
+    Matrix4cf v2c = inverse(world2volume * c2w);
+    Matrix3frm Rv2c = GetRotation(v2c);
+    Vector3cf tv2c = GetTranslation(v2c);
+    std::memcpy(list_Rv2c_, &device_cast<MatS33>(Rv2c).data[0].x.re, sizeof(list_Rv2c_));
+    std::memcpy(list_tv2c_, &device_cast<devComplex3>(tv2c).x.re, sizeof(list_tv2c_));
+}
 // xs_integrate_classify for the camera pose (Rcurr, tcurr) = camera-to-world, on the main stream (behind the ICP launches)
 void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr) {
     Matrix4cf c2w;
@@ -644,11 +653,7 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
         for (int j = 0; j < 3; ++j) c2w(i, j) = Rcurr(i, j);
         c2w(i, 3) = tcurr[i];
     }
-    Matrix4cf v2c = inverse(world2volume * c2w);
-    Matrix3frm Rv2c = GetRotation(v2c);
-    Vector3cf tv2c = GetTranslation(v2c);
-    std::memcpy(list_Rv2c_, &device_cast<MatS33>(Rv2c).data[0].x.re, sizeof(list_Rv2c_));
-    std::memcpy(list_tv2c_, &device_cast<devComplex3>(tv2c).x.re, sizeof(list_tv2c_));
+    SetListPose(c2w);
     // integrate_classify_beside_icp (off by default: measured, no gain — see the header): on the auxiliary stream instead; everything the two
     // classification kernels read — the scaled depth's maximum, the tile table, the cleared header — was written on that stream.  The integrate
     // launch then waits for their completion event.
@@ -656,17 +661,45 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
     hipStream_t st = beside ? aux_stream_ : current_stream();
     // the scaled depth's maximum and the cleared header come from the auxiliary stream
     if (!beside && scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
+    EnqueueClassification(st, beside);
+    EnqueuePostedIntegrate();
+}
+// the two classification kernels for list_Rv2c_ / list_tv2c_ on stream st; with_event: their completion rides on the last dispatch
+// (classify_done_: the stream that integrates is another one)
+void KinectFusionReconstruction::EnqueueClassification(hipStream_t st, bool with_event) {
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
     xs_integrate_set_depth_tiles(depth_tiles_.ptr());   // the boxes' classes are decided here too, with the slack's pads (xs_integrate_list_covers checks the final pose against them)
-    if (beside) xs_integrate_set_classify_event(classify_done_);
+    if (with_event) xs_integrate_set_classify_event(classify_done_);
     check_rc(xs_integrate_classify(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
                                    tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
                                    integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
     xs_integrate_set_classify_event(nullptr);
     xs_integrate_set_depth_tiles(nullptr);
-    classify_recorded_ = beside;
+    classify_recorded_ = with_event;
     list_ready_ = true;
-    EnqueuePostedIntegrate();
+}
+// integrate_classify_predicted (off by default): the classification for the pose the frame is EXPECTED to end at — the previous pose moved
+// on by the previous frame's motion — at the frame's very start, on the auxiliary stream (behind the header clear and the depth scaling,
+// i.e. under the previous frame's raycast and the first, small ICP launches); IntegrateFrame checks the final pose against the list's and
+// the classes' slack as it does for a list classified behind the last ICP launch, and a frame that moved otherwise classifies again there.
+// It would take the two classification kernels (4.8 + 7.8 us) off the chain between the last ICP reduction and the integrate kernel, but
+// on the benchmark scene — which slides along a wall: the estimated trajectory jitters by more than the slack allows — only a third of
+// the frames are covered at slack 2 and 72 % at slack 6, where the wider pads cost the integrate kernel 4 us; the others classify after
+// the final pose, i.e. later than ClassifyAhead would have: no gain (profiles/r04_ab_classify_predicted.txt).  Same volume bit for bit
+// either way (tested).
+void KinectFusionReconstruction::ClassifyPredicted() {
+    list_predicted_ = false;
+    if (!integrate_classify_predicted || !integrate_classify_ahead || integrate_post_pose || !integrate_split() || !integrate_header_clear_ ||
+        !aux_stream_ || world2camera_record.empty() || use_gtPose)
+        return;
+    Matrix4cf w2c = world2camera_record.back();
+    if (world2camera_record.size() >= 2) {   // constant velocity: W(n+1) = (W(n) W(n-1)^-1) W(n)
+        const Matrix4cf step = w2c * inverse(world2camera_record[world2camera_record.size() - 2]);
+        w2c = step * w2c;
+    }
+    SetListPose(inverse(w2c));
+    EnqueueClassification(aux_stream_, true);
+    list_predicted_ = true;
 }
 
 // this frame's counter slot; entering a half of the ring clears that half (its frames were folded or abandoned at least COUNTER_RING / 2
@@ -832,7 +865,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             const bool split = integrate_split() && integrate_header_clear_ && i == 0;
             unsigned list_flag = 0;
             if (i == 0 && list_ready_) {
-                list_ready_ = false;
+                list_ready_ = false; list_predicted_ = false;
                 WaitForClassification(st);
                 const int covers = xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_,
                                                             list_tv2c_, integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re);
@@ -1071,6 +1104,8 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
         EnqueueScale(depth_frame_d);
         stage_end(ST_SCALE);
     }
+    list_ready_ = false;
+    ClassifyPredicted();
     current_stream() = main_stream;
     // the main stream picks the maps up — without a wait packet when they are already there (the usual case once the
     // previous frame's tail is the longer of the two)

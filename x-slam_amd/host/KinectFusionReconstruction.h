@@ -64,6 +64,11 @@ public:
     // instead of 17.7 — and an integrate launch that has to wait for another stream's event starts 10 us later than one that follows its
     // own queue (profiles/r04_ab_classify_beside_icp.txt).
     bool integrate_classify_beside_icp = false;
+    // the classification at the frame's start, for the pose a constant-velocity model predicts, on the auxiliary stream (YAML
+    // integrate_classify_predicted, default FALSE: measured, no gain on the benchmark scene; not with integrate_post_pose or ground-truth
+    // poses): see ClassifyPredicted
+    bool integrate_classify_predicted = false;
+    bool list_predicted_ = false;              // the list that is ready was classified for a predicted pose (this frame's SurfaceMeasure)
     int integrate_classify_early = 0;          // YAML integrate_classify_early: that many ICP iterations before the last (a pose that many more updates old)
     long long list_cover_counts_[4] = {0, 0, 0, 0};   // what xs_integrate_list_covers said of the lists classified ahead (XS_KF_DEBUG_COVERS prints them)
     // the integrate kernel itself enqueued behind that classification, handed the final pose through a mailbox of its own and a one-wave gate
@@ -105,6 +110,9 @@ public:
     bool list_ready_ = false;
     float list_Rv2c_[18]{}, list_tv2c_[6]{};
     void ClassifyAhead(const Matrix3frm &Rcurr, const Vector3cf &tcurr);
+    void ClassifyPredicted();
+    void SetListPose(const Matrix4cf &c2w);
+    void EnqueueClassification(hipStream_t st, bool with_event);
     bool real_maps_valid_ = false;
 
     bool use_gtPose = false;
