@@ -396,6 +396,53 @@ def test_integrate_size_independent_properties_512(dev):
     assert np.all(v2[free] == 1.0)
 
 
+def test_frustum_filling_scene_512_classes_and_order_against_the_walk_everywhere(dev):
+    """Scene S2 (the frustum fills the volume: 23 000 listed bricks at 512^3 — the launch on which integrate is HBM-bound, and the one
+    whose list is ordered with a reservation per 64 bricks): three launches with the boxes' classes and the ordered list against the
+    per-voxel walk of every listed voxel (XS_INTEGRATE_NO_TILES), volumes and counts bit for bit; the ordered list holds the listed
+    bricks once each, those with planes to walk in front."""
+    torch, capi = dev
+    n = 512
+    prm = synth.s2_params(n)
+    res = [n, n, n]
+    Hh, Ww = synth.HEIGHT, synth.WIDTH
+    vs, trunc = float(np.float32(prm["tsdf_voxel_size"])), synth.tranc_dist(prm)
+    depth = torch.from_numpy(synth.render_s2().view(np.int16)).cuda()
+    scaled = torch.empty((Hh, Ww), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    capi.scale_depth_max(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax)
+    R = np.zeros((3, 3, 2), np.float32); R[[0, 1, 2], [0, 1, 2], 0] = 1
+    t = np.zeros((3, 2), np.float32); t[:, 0] = [-prm["init_x"], -prm["init_y"], -prm["init_z"]]; t[0, 1] = 1e-7
+    k4 = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+    vols, counts = [], []
+    for flags in (64, 32):
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        c = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 2, res, vs, R, t, trunc, v, w, g, n * 4, flags, updated=c, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        vols.append((v, w, g)); counts.append(int(c.item()))
+        if flags == 64:
+            host = ws.cpu().numpy()
+            list_off, cap, class_off, second_off = capi.integrate_list_layout(res)
+            count = int(host[:4].view(np.int32)[0])
+            nwalk, nother = (int(x) for x in host[208:216].view(np.int32))
+            assert count > 4096 and nwalk + nother == count and nwalk > 1000 and nother > 1000
+            region = host[second_off:second_off + cap * 4].view(np.int32)
+            ids = np.concatenate([region[:nwalk], region[cap - nother:]])
+            assert np.array_equal(np.sort(ids), np.sort(host[list_off:list_off + 4 * count].view(np.int32)))
+            words = host[class_off:class_off + cap * 16].view(np.uint32).reshape(cap, 4)
+            walked = lambda wd: (8 - (wd & 0xff).astype(np.int64) - ((wd >> 8) & 0xff).astype(np.int64)).sum(axis=1)
+            assert (walked(words[:nwalk]) > 0).all() and (walked(words[cap - nother:]) == 0).all()
+            assert class_counts(ws)[0] > 10000     # wave-sized boxes wholly in free space
+    assert counts[0] == counts[1] > 3 * 30_000_000
+    for x, y in zip(*vols):
+        assert torch.equal(x, y)
+
+
 def test_full_size_properties_512(dev):
     """Size-independent properties at the benchmark's full size (512^3, scene S1): z-slab launches tile the
     whole-volume launch bit for bit and count the same voxels; integrating the same frame again leaves every
