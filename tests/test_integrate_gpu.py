@@ -346,18 +346,6 @@ def test_integrate_stores_only_words_that_change(dev, oracle, threshold):
     assert b[1].max() == 3 and (b[0] == 1.0).sum() > 1000
 
 
-def test_lds_dma_ring_experiment_writes_the_same_volume():
-    """XS_INTEGRATE_KERNEL=ring selects the round-3 experiment (voxel state prefetched by LDS-DMA into a per-wave ring, gather
-    first, counted vmcnt wait; measured slower than the walk and not the default): the brick-path tests of this file pass
-    with it unchanged — same volumes as the column walk, bit for bit.  A child process, because the switch is read once."""
-    import os, subprocess, sys
-    env = dict(os.environ, XS_INTEGRATE_KERNEL="ring")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_integrate_gpu.py", "-x", "-q", "-k",
-                        "far_clip or non_cubic or stores_only or rotated"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_integrate_empty_inputs(dev, oracle):
     torch, capi = dev
     prm = synth.s1_params(64)

@@ -3,6 +3,7 @@
 // small host-side table that the launchers consult (xs_const_div_get).  A constant that has not been prepared, or that fails, is
 // divided by with the IEEE sequence — never silently with the short form.
 #include "xs_device.h"
+#include "xs_env.h"
 #include "../../include/xslam_amd.h"
 #include <math.h>
 #include <mutex>
@@ -32,7 +33,7 @@ struct Entry { unsigned bits; unsigned ok; };
 std::mutex g_mu;
 Entry g_tab[32];
 int g_n = 0;
-bool g_enabled = getenv("XS_CONST_DIV_OFF") == nullptr;   // (environment switch: measurement aid, like xs_const_div_enable)
+bool g_enabled = !xs::exp_env_set("XS_CONST_DIV_OFF");   // (measurement aid of an XS_EXPERIMENTS build; the product switch is xs_const_div_enable)
 }
 
 /* Test aid: with on = 0 every launcher divides (xs_const_div_state reads 0) whatever has been prepared; returns the previous setting. */

@@ -13,6 +13,7 @@
 // second launch.  How each phase was measured: profiles/tools/trace_icp.sh, profiles/r02_icp_phases.txt.
 #include <string.h>
 #include "xs_device.h"
+#include "xs_env.h"
 #include "xs_mailbox.h"
 #include "xs_icp_solve.h"
 #include "../../include/xslam_amd.h"
@@ -771,7 +772,7 @@ static int icp_blocks(int cols, int y0, int y1, int *waves = nullptr) {
     // 640 x 480 frame: 4 800): one sixteen-wave workgroup per CU, 18 or 19 tiles each (k_icp<., 16, 2, true>; `waves` 17 marks it) —
     // 256 records for the last workgroup to add instead of 512 or 600.  XS_ICP_BALANCED (measurement aid): 1 = 512 eight-wave workgroups
     // of nine or ten tiles (`waves` 9), 0 = the one-tile-per-wave launch.
-    static const int mode = getenv("XS_ICP_BALANCED") ? atoi(getenv("XS_ICP_BALANCED")) : 2;
+    static const int mode = product_env_int("XS_ICP_BALANCED", 2);   // (a documented switch: INTEGRATION.md "Environment"; tests/test_publish_stress_gpu.py runs both balanced instances)
     if (mode != 0 && tiles > 8 * 512 && tiles <= 10 * 512) {
         if (waves) *waves = mode == 1 ? 9 : 17;
         return mode == 1 ? 512 : 256;
@@ -991,7 +992,7 @@ extern "C" int xs_icp_mailbox_alloc(void **mailbox, int *in_device_memory) {
     int dev = 0, large_bar = 0;
     XS_CHECK(hipGetDevice(&dev));
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
-    const char *force_host = getenv("XS_ICP_MAILBOX_HOST");
+    const char *force_host = getenv("XS_ICP_MAILBOX_HOST");   // (a documented switch: INTEGRATION.md "Environment")
     void *p = nullptr;
     if (large_bar && !(force_host && force_host[0] == '1') &&
         hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess) {

@@ -11,6 +11,7 @@
 // where the 2 + 6 trilinear samples run in complex arithmetic.
 #include <hip/hip_ext.h>
 #include "xs_device.h"
+#include "xs_env.h"
 #include "xs_signmap.h"
 #include "xs_pyramid.h"
 #include <type_traits>
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
                     const float fr = xq - (float)i;
                     return is_set(i) || (fr < 0.02f && is_set(i - 1)) || (fr > 0.98f && is_set(i + 1));
                 };
-#if defined(XS_PROBE_SIGNMAP_BOTH)   // measurement only: the simpler static rule (see above)
+#if defined(XS_EXPERIMENTS) && defined(XS_SIGNMAP_BOTH)   // measurement only: the simpler static rule (see above)
                 const bool uns = flagged_at(a.sm.t[runs ? k + 1 : 0]) || (k == 0 ? is_set(0) : flagged_at(a.sm.t[runs ? k : 0]));
 #else
                 const bool uns = flagged_at(a.sm.t[runs ? k + 1 : 0]) || (k == 0 && is_set(0));   // (t[0] = 0.2 is sample 0's own position)
@@ -721,7 +722,7 @@ static thread_local int *g_ray_steps = nullptr;
 extern "C" void xs_raycast_set_step_buffer(int *steps_dev) { g_ray_steps = steps_dev; }
 
 static int ray_wshift() {
-    static const int env_ws = getenv("XS_RAY_WSHIFT") ? atoi(getenv("XS_RAY_WSHIFT")) : 3;
+    static const int env_ws = exp_env_int("XS_RAY_WSHIFT", 3);
     return (env_ws >= 0 && env_ws <= 6) ? env_ws : 3;
 }
 // spacing of the per-wave sign-map samples (k_raycast, MAP): dt + (5.2 + dt) * delta <= 0.9 brick edges, delta = the pixel tile's half
@@ -835,12 +836,12 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     if (workspace) {
         // march (few registers, many waves, eight gathers in flight per lane) then the crossings
         a.hits = nullptr;
-        static const bool env_pair = getenv("XS_RAY_MAP_TWO_KERNELS") != nullptr;   // measurement: the mapped march and the crossing as two launches
+        static const bool env_pair = exp_env_set("XS_RAY_MAP_TWO_KERNELS");   // measurement: the mapped march and the crossing as two launches
         if (a.sm.dil && !env_pair) {
             // with the sign map the march is a few batches long: it and the crossing are one launch (five waves per SIMD hold the
             // frame's 4 800 waves either way) — no second dispatch, no crossing-time plane written and read back
             a.hits = hits_dev;
-            static const bool env_no_pyr = getenv("XS_RAY_NO_PYRAMID") != nullptr;   // A/B aid: the pyramid stays a launch of its own
+            static const bool env_no_pyr = exp_env_set("XS_RAY_NO_PYRAMID");   // A/B aid: the pyramid stays a launch of its own
             if (g_ray_pyr_set && !env_no_pyr) {
                 a.pyr = g_ray_pyr;
                 a.pyr.in[0] = a.vmap; a.pyr.in[1] = a.nmap; a.pyr.istep = map_step; a.pyr.rows0 = rows; a.pyr.cols0 = cols;

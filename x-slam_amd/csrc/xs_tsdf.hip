@@ -21,6 +21,7 @@
 #include "xs_device.h"
 #include "xs_mailbox.h"
 #include "xs_signmap.h"
+#include "xs_env.h"
 #include <algorithm>
 #include <stdlib.h>
 #include "../../include/xslam_amd.h"
@@ -216,7 +217,7 @@ struct IntegrateArgs {
     unsigned char *signmap;       // xs_signmap.h buffer (whole-volume launches) or null: bricks that receive a negative value are marked
     DepthTiles dt;                // per-tile depth range of the frame (k_scale_depth), for k_classify_boxes
     unsigned *box_class;          // [list entry][BOXES_PER_BRICK] box_word (k_classify_boxes) or null: every box takes the exact walk
-    size_t probe_offset;          // XS_PROBE_WG_TIMES only: bytes from box_class to the record area
+    size_t probe_offset;          // XS_EXPERIMENTS + XS_WG_TIMES only: bytes from box_class to the record area
 };
 enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };   // KF_FAR_FIRST: the list is taken from its end (see k_integrate_bricks)  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
 enum { CLASS_COUNT_WORD = 48 };    // write every updated voxel's three words even where the bits do not change (measurement aid)
@@ -340,11 +341,7 @@ __device__ __forceinline__ void pixel_depth(const VoxelPixel &q, const Depth &di
         dimg.two(q.coo_y, q.coo_x, w.d00, w.d10);
         dimg.two(q.coo_y + 1, q.coo_x, w.d01, w.d11);
     } else {
-#if defined(XS_PROBE_NODEPTH)   // measurement only: no depth gather either
-        float d = 4.5f + 1e-9f * q.near_x * q.near_y; asm volatile("" : "+v"(d)); w.n = d;
-#else
         w.n = dimg.one(q.near_y, q.near_x);
-#endif
     }
 }
 template <bool BILINEAR>
@@ -452,26 +449,6 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Po
     return update_voxel(a, k, p, pre_v, pre_g, pre_w, out_v, out_g, out_w);
 }
 
-// Three LDS-DMA loads (value, grad, weight rows of one plane: no destination register) into a 768-byte LDS slot.
-__device__ __forceinline__ void lds_dma3(unsigned voff, const void *pv, const void *pg, const void *pw, unsigned lds) {
-    unsigned keep;
-    const unsigned l1 = lds + 256, l2 = lds + 512;
-    // M0 holds the LDS address of lane 0's word; the compiler does not preserve it around a statement, so it is saved and put back.
-    // (s_nop 4 first: a base pointer the compiler has just fetched back from a spill lane (v_readlane) needs five wait states before a
-    // vector-memory instruction reads it, and the compiler pads nothing inside a statement)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
-                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(pv), "s"(pg), "s"(pw), "s"(lds), "s"(l1), "s"(l2) : "memory");
-}
-// XS_WALK_PREFETCH (experiment, r04): before its first trip the OFF32 walk asks for the state of all its planes at once — by LDS-DMA into
-// a junk slot, so no register holds them: the lines are in L2 when the trips ask again.  A wave's vector-memory operations complete in
-// issue order, so the walk's trips each expose one full HBM latency; with the prefetch the brick pays it once.
-#ifndef XS_WALK_PREFETCH
-#define XS_WALK_PREFETCH 0
-#endif
 // z in [zb, ze) of column (x, y).  The voxel's current state (coalesced 256 B rows) is requested
 // before the projection arithmetic so its HBM latency runs under it.  (Two planes per trip with
 // six reads in flight was measured slower: 102 VGPRs halve the resident waves.)
@@ -503,15 +480,6 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
         char *bv = reinterpret_cast<char *>(a.value) + ubase, *bw = reinterpret_cast<char *>(a.weight) + ubase, *bg = reinterpret_cast<char *>(a.grad) + ubase;
         const unsigned plane = (unsigned)a.Y * (unsigned)a.vstep;
         unsigned off = lane_off + (unsigned)(zb - zb0) * plane;
-#if XS_WALK_PREFETCH
-        {
-            __shared__ unsigned s_junk[3 * 64];
-            const unsigned junk = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&s_junk[0]);
-            unsigned poff = off;
-#pragma unroll 1
-            for (int z = zb; z < ze; ++z, poff += plane) lds_dma3(poff, bv, bg, bw, junk);
-        }
-#endif
         for (int z = zb; z < ze; ++z, off += plane) {
             float *pos = reinterpret_cast<float *>(bv + off), *gpos = reinterpret_cast<float *>(bg + off);
             int *wpos = reinterpret_cast<int *>(bw + off);
@@ -533,32 +501,19 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
     // (Requesting the state of voxel z+1 one trip ahead, in front of or behind the depth gather, was
     // measured slower: loads return in issue order and the extra live registers cost a wave.)
     for (int z = zb; z < ze; ++z, pos += zstride, wpos += zstride, gpos += zstride) {
-#if defined(XS_PROBE_NOMEM)   // measurement only: the walk without its state loads and stores (profiles/tools/probe_integrate_floor.sh)
-        float v0 = 1.0f, g0 = 0.0f; int w0 = 5;
-        asm volatile("" : "+v"(v0), "+v"(g0), "+v"(w0));
-        float ov, og; int ow;
-        if (integrate_voxel<BILINEAR>(a, ps, k, z, v0, g0, w0, ov, og, ow)) { asm volatile("" ::"v"(ov), "v"(og), "v"(ow)); ++n_upd; }
-#else
         const float v0 = *pos, g0 = *gpos;
         const int w0 = *wpos;
         float ov, og; int ow;
         if (integrate_voxel<BILINEAR>(a, ps, k, z, v0, g0, w0, ov, og, ow)) {
             // only the words whose bits change are stored (same volume, fewer bytes: in free space in front of a surface the running
             // mean of (1, 0) with (1, 0) is (1, 0) again, and a saturated weight stays)
-#if defined(XS_PROBE_NT_STORES)   // measurement only: non-temporal stores (profiles/tools/probe_integrate_nt.sh)
-            if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) __builtin_nontemporal_store(ov, pos);
-            if ((unsigned)(ow ^ w0) | always) __builtin_nontemporal_store(ow, wpos);
-            if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) __builtin_nontemporal_store(og, gpos);
-#else
             if ((__float_as_uint(ov) ^ __float_as_uint(v0)) | always) *pos = ov;
             if ((unsigned)(ow ^ w0) | always) *wpos = ow;
             if ((__float_as_uint(og) ^ __float_as_uint(g0)) | always) *gpos = og;
-#endif
             if (SIGN) vmin = fminf(vmin, ov);
             ++n_upd;
         }
         else asm volatile("" ::"v"(v0), "v"(g0), "v"(w0));
-#endif
         // (the empty asm consumes the three loads on the paths that left early: without it they are
         // still in flight at the loop head, and the wait the compiler puts there to protect their
         // registers also waits for the previous trip's stores to be acknowledged)
@@ -567,76 +522,6 @@ __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const
     return n_upd;
 }
 
-
-// The OFF32 walk, G planes at a time (XS_WALK_GROUP = G > 0).  The plain walk's trip is a chain — state loads, projection, depth gather,
-// update, stores — and a wave's vector-memory operations complete in issue order, so every plane exposes a gather behind a memory latency
-// behind the previous plane's store acknowledgements: ~1.5 us per plane on the benchmark scene, 12 us for a brick, which is the launch
-// (all of its bricks are resident at once: profiles/r04_integrate_wg_times.txt).  Here a group's state loads go out first, then the G
-// pixels are found and their depth requested, and only then is anything waited for: one exposed latency per group.  Nothing but the
-// depth words and a mask is carried from the first half to the second — the projection is evaluated again there (same operations on the
-// same operands: same bits; the empty asm keeps the compiler from carrying the first evaluation's ~14 registers per plane across).
-template <bool BILINEAR, bool SIGN, int G>
-__device__ __forceinline__ unsigned integrate_span_grouped(const IntegrateArgs &a, const PoseRT &ps, int x, int y, int zb, int ze, size_t ubase, int zb0, unsigned lane_off) {
-    unsigned n_upd = 0;
-    const float vgx = (x + 0.5f) * a.voxel_size;
-    const float vgy = (y + 0.5f) * a.voxel_size;
-    VoxelCtx k;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) k.base[r] = ps.R.data[r].x * vgx + ps.R.data[r].y * vgy;
-    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
-    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
-    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
-    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
-    float vmin = 0.0f;
-    char *bv = reinterpret_cast<char *>(a.value) + ubase, *bw = reinterpret_cast<char *>(a.weight) + ubase, *bg = reinterpret_cast<char *>(a.grad) + ubase;
-    const unsigned plane = (unsigned)a.Y * (unsigned)a.vstep;
-    unsigned off = lane_off + (unsigned)(zb - zb0) * plane;
-    const DepthGlobal dimg{a.depth, a.dstep};
-#pragma unroll 1
-    for (int z = zb; z < ze; z += G, off += G * plane) {
-        float v0[G], g0[G]; int w0[G];
-        DepthWords<BILINEAR> dw[G];
-        unsigned seen = 0;
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-            if (z + j < ze) {
-                v0[j] = *reinterpret_cast<const float *>(bv + (off + j * plane));
-                g0[j] = *reinterpret_cast<const float *>(bg + (off + j * plane));
-                w0[j] = *reinterpret_cast<const int *>(bw + (off + j * plane));
-            }
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-            if (z + j < ze) {
-                VoxelProj p; VoxelPixel q;
-                if (voxel_pixel(a, ps, k, z + j, p, q)) { pixel_depth<BILINEAR>(q, dimg, dw[j]); seen |= 1u << j; }
-            }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            if (seen & (1u << j)) {
-                int zz = z + j;
-                asm volatile("" : "+v"(zz));
-                VoxelProj p; VoxelPixel q;
-                cfloat tsdf;
-                if (voxel_pixel(a, ps, k, zz, p, q) && voxel_depth<BILINEAR>(a, q, dw[j], p) && voxel_tsdf(a, k, p, tsdf)) {
-                    float ov, og; int ow;
-                    running_mean(a.max_weight, tsdf, v0[j], g0[j], w0[j], ov, og, ow);
-                    if ((__float_as_uint(ov) ^ __float_as_uint(v0[j])) | always) *reinterpret_cast<float *>(bv + (off + j * plane)) = ov;
-                    if ((unsigned)(ow ^ w0[j]) | always) *reinterpret_cast<int *>(bw + (off + j * plane)) = ow;
-                    if ((__float_as_uint(og) ^ __float_as_uint(g0[j])) | always) *reinterpret_cast<float *>(bg + (off + j * plane)) = og;
-                    if (SIGN) vmin = fminf(vmin, ov);
-                    ++n_upd;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) asm volatile("" ::"v"(v0[j]), "v"(g0[j]), "v"(w0[j]));   // (see integrate_span: loads of planes that left early)
-    }
-    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
-    return n_upd;
-}
-#ifndef XS_WALK_GROUP
-#define XS_WALK_GROUP 0
-#endif
 
 
 // ---- what a brick is, before any of its voxels is touched ----------------------------------------------------------------------
@@ -910,9 +795,6 @@ __device__ __forceinline__ unsigned classify_brick_boxes(const IntegrateArgs &a,
     const int nz = ze0 - zb0;
     unsigned word = box_word(0, nz, 0);   // a wave without a column of the brick in the volume: nothing to write
     if (wx0 < a.X && wy0 < a.Y) word = classify_box(a, sl, wx0, min(wx0 + BOX_WX, a.X), wy0, min(wy0 + BOX_WY, a.Y), zb0, ze0, corner);
-#if defined(XS_PROBE_ALL_FREE)   // measurement only (wrong volume): every walked plane streams like free space — the free path's ceiling
-    if ((int)(word & 0xff) + (int)((word >> 8) & 0xff) < nz) word = box_word(nz, 0, 0);
-#endif
     const int nf = (int)(word & 0xff), ne = (int)((word >> 8) & 0xff);
     if (corner == 0 && (a.kflags & KF_COUNT_CLASSES)) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
         atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
@@ -1025,7 +907,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
         }
         ps.t.x = cfloat(f(18), f(19)); ps.t.y = cfloat(f(20), f(21)); ps.t.z = cfloat(f(22), f(23));
     }
-#if defined(XS_PROBE_WG_TIMES)   // measurement only: every workgroup's begin / end on the 100 MHz wall clock, 512 KiB into the tile room of the workspace
+#if defined(XS_EXPERIMENTS) && defined(XS_WG_TIMES)   // measurement only: every workgroup's begin / end on the 100 MHz wall clock, 512 KiB into the tile room of the workspace
     const unsigned long long probe_t0 = wall_clock64();
 #endif
     const unsigned nwalk = a.brick_count[a.pair_word], count = nwalk + a.brick_count[a.pair_word + 1];   // (see "the list and its order")
@@ -1046,14 +928,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     // free-space bricks have streamed: taken from its far end the list starts with them and the streaming fills in around (KF_FAR_FIRST,
     // set by the launcher from the pose; never for a list that is ordered by class).
     const bool far_first = (a.kflags & KF_FAR_FIRST) != 0;
-#if defined(XS_PROBE_ZIP)   // experiment: groups of XS_PROBE_ZIP entries alternately from the front (walked bricks) and the back (streaming ones) of an ordered list
-    auto entry = [&](unsigned e) {
-        const unsigned g = e / XS_PROBE_ZIP, i = (g >> 1) * XS_PROBE_ZIP + e % XS_PROBE_ZIP;
-        return list_at((g & 1u) ? count - 1u - i : i, nwalk, a.list_cap);
-    };
-#else
     auto entry = [&](unsigned e) { return list_at(far_first ? count - 1u - e : e, nwalk, a.list_cap); };
-#endif
     // the first entry and its class are requested together, in front of the barrier
     int b_next = 0, cls_next = BOX_MIXED;
     if (first < count) {
@@ -1101,17 +976,13 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
             if (zb < ze) {
                 if constexpr (OFF32) {
                     const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-#if XS_WALK_GROUP
-                    n_upd += integrate_span_grouped<BILINEAR, SIGN, XS_WALK_GROUP>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
-#else
                     n_upd += integrate_span<BILINEAR, true, SIGN>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
-#endif
                 } else
                     n_upd += integrate_span<BILINEAR, false, SIGN>(a, ps, x, y, zb, ze);
             }
         }
     }
-#if defined(XS_PROBE_WG_TIMES)
+#if defined(XS_EXPERIMENTS) && defined(XS_WG_TIMES)
     if (a.box_class && threadIdx.x == 0) {
         unsigned *rec = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(a.box_class) + a.probe_offset) + 4u * (blockIdx.x * 4 + threadIdx.y);
         rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[entry(blockIdx.x) * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = (n_upd & 0xffu) | ((__builtin_amdgcn_s_getreg(0xF814) & 0xfu) << 8) | (__builtin_amdgcn_s_getreg(0xF804) << 16);   // + XCC_ID, HW_ID (wave, SIMD, pipe, CU, SH, SE)
@@ -1120,123 +991,6 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
 }
 
-
-// ---- path 2, round 3 experiment: the walk with its voxel state prefetched by LDS-DMA ----------
-// The walk asks for a voxel's state at the top of its trip and gathers the depth ~60 instructions later; a wave's vector-memory
-// operations complete in issue order, so the gather — an L1 / L2 hit — comes back behind the three HBM reads, and every trip of
-// every wave exposes one full memory latency (the eight waves of a SIMD cover for each other; 3 x 256 B per wave in flight).
-// Here the order is turned round: in trip j the gather goes out first, the state of plane j + 1 right behind it — by LDS-DMA
-// (global_load_lds_dword: no destination register; a per-wave ring of two slots) — and the wave waits with vmcnt(3): for the
-// gather and everything older, which includes plane j's state (requested a whole trip ago), but not for the three requests it has
-// just made.  One asm statement holds the gather, the three DMAs (with their own lane mask: the lanes whose column has plane
-// j + 1) and the wait, so the count is exact by construction.
-struct RingRefill {   // wave-uniform but for voff: the next plane's state -> the slot at lds, for the lanes in mask (never empty when has)
-    bool has; unsigned long long mask; const void *pv, *pg, *pw; unsigned lds, voff;
-};
-struct DepthRing {
-    const float *depth; int dstep; RingRefill rf;
-    __device__ __forceinline__ float one(int y, int x) const {
-        const unsigned goff = (unsigned)(y * dstep + x * 4);
-        float d;
-        if (rf.has) {
-            unsigned keep; unsigned long long ex;
-            const unsigned l1 = rf.lds + 256, l2 = rf.lds + 512;
-            asm volatile("s_nop 4\n\tglobal_load_dword %0, %3, %4\n\t"
-                         "s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\t"
-                         "s_mov_b32 %1, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
-                         "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dword %6, %7\n\t"
-                         "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dword %6, %8\n\t"
-                         "s_mov_b32 m0, %12\n\ts_nop 0\n\tglobal_load_lds_dword %6, %9\n\t"
-                         "s_mov_b32 m0, %1\n\ts_mov_b64 exec, %2\n\t"
-                         "s_waitcnt vmcnt(3)"
-                         : "=&v"(d), "=&s"(keep), "=&s"(ex)
-                         : "v"(goff), "s"(depth), "s"(rf.mask), "v"(rf.voff), "s"(rf.pv), "s"(rf.pg), "s"(rf.pw), "s"(rf.lds), "s"(l1), "s"(l2)
-                         : "memory");
-        } else
-            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(goff), "s"(depth) : "memory");
-        return d;
-    }
-    __device__ __forceinline__ void two(int y, int x, float &a, float &b) const { DepthGlobal{depth, (size_t)dstep}.two(y, x, a, b); }
-};
-template <bool BILINEAR>
-__global__ void __launch_bounds__(256, 8) k_integrate_bricks_ring(const IntegrateArgs a) {
-    const unsigned nwalk = a.brick_count[a.pair_word], count = nwalk + a.brick_count[a.pair_word + 1];
-    unsigned n_upd = 0;
-    __shared__ ClipPlanes s_cp;
-    __shared__ unsigned s_ring[4][2][3][64];   // per wave: two slots of (value, grad, weight) rows
-    const int tid = threadIdx.y * 64 + threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[tid] = reinterpret_cast<const float *>(&a.cp)[tid];
-    __syncthreads();
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&s_ring[wave][0][0][0]);
-    const int lx = tid % BRICK_X, ly = tid / BRICK_X;
-    const unsigned lane_off = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u;
-    const size_t plane_bytes = (size_t)a.Y * a.vstep;
-    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
-    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
-        const int b = __builtin_amdgcn_readfirstlane(a.brick_list[list_at(e, nwalk, a.list_cap)]);
-        const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
-        const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
-        const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
-        int zb = zb0, ze = ze0;
-        asm volatile("" ::: "memory");
-        if (x < a.X && y < a.Y) clip_column(s_cp, far_limit(a), x, y, zb, ze);
-        else ze = zb;
-        if (__builtin_amdgcn_ballot_w64(zb < ze) == 0) continue;
-        VoxelCtx k;
-        {
-            const float vgx = (x + 0.5f) * a.voxel_size, vgy = (y + 0.5f) * a.voxel_size;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) k.base[r] = a.R.data[r].x * vgx + a.R.data[r].y * vgy;
-            k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
-            k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
-            k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
-        }
-        const size_t brick_off = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-        const char *pv = reinterpret_cast<const char *>(a.value) + brick_off;
-        const char *pg = reinterpret_cast<const char *>(a.grad) + brick_off;
-        const char *pw = reinterpret_cast<const char *>(a.weight) + brick_off;
-        const int nz = ze0 - zb0;
-        if (zb0 >= zb && zb0 < ze) lds_dma3(lane_off, pv, pg, pw, ring_lds);   // plane 0 -> slot 0
-#pragma unroll 1
-        for (int j = 0; j < nz; ++j) {
-            const int z = zb0 + j, slot = j & 1;
-            const bool in = z >= zb && z < ze;
-            // plane j + 1 -> the other slot (its previous tenant, plane j - 1, was consumed in the previous trip)
-            DepthRing dimg{a.depth, (int)a.dstep, {}};
-            const unsigned long long m2 = (j + 1 < nz) ? __builtin_amdgcn_ballot_w64(z + 1 >= zb && z + 1 < ze) : 0ull;
-            dimg.rf.has = m2 != 0; dimg.rf.mask = m2;
-            dimg.rf.pv = pv + (j + 1) * plane_bytes; dimg.rf.pg = pg + (j + 1) * plane_bytes; dimg.rf.pw = pw + (j + 1) * plane_bytes;
-            dimg.rf.lds = ring_lds + (slot ^ 1) * 768; dimg.rf.voff = lane_off;
-            bool wr = false, gathered = false;
-            cfloat tsdf(1.0f, 0.0f);
-            if (in) {
-                VoxelProj p;
-                p.Dp = cfloat(-1.0f, 0.0f);
-                const bool vis = project_voxel<BILINEAR>(a, PoseRT{a.R, a.t}, k, z, p, dimg);
-                gathered = p.Dp.re >= 0.0f;   // (the fetch ran: a depth is never negative)
-                wr = vis && voxel_tsdf(a, k, p, tsdf);
-            }
-            if (__builtin_amdgcn_ballot_w64(gathered) == 0) {   // no lane gathered: the refill has not gone out, and nothing is consumed
-                if (dimg.rf.has) {
-                    if (z + 1 >= zb && z + 1 < ze) lds_dma3(lane_off, dimg.rf.pv, dimg.rf.pg, dimg.rf.pw, dimg.rf.lds);
-                    // plane j + 1's state must have landed when trip j + 1 consumes it: its wait leaves only that trip's own three requests out
-                }
-                continue;
-            }
-            if (wr) {
-                const unsigned v0 = s_ring[wave][slot][0][lane], g0 = s_ring[wave][slot][1][lane], w0 = s_ring[wave][slot][2][lane];
-                float ov, og; int ow;
-                running_mean(a.max_weight, tsdf, __uint_as_float(v0), __uint_as_float(g0), (int)w0, ov, og, ow);
-                char *qv = const_cast<char *>(pv) + j * plane_bytes, *qg = const_cast<char *>(pg) + j * plane_bytes, *qw = const_cast<char *>(pw) + j * plane_bytes;
-                if ((__float_as_uint(ov) ^ v0) | always) *reinterpret_cast<float *>(qv + lane_off) = ov;
-                if (((unsigned)ow ^ w0) | always) *reinterpret_cast<int *>(qw + lane_off) = ow;
-                if ((__float_as_uint(og) ^ g0) | always) *reinterpret_cast<float *>(qg + lane_off) = og;
-                ++n_upd;
-            }
-        }
-    }
-    if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
-}
 
 static void load_mat(const float *p, MatS33 &m) {
     for (int r = 0; r < 3; ++r) {
@@ -1364,8 +1118,8 @@ static BoxSlack box_slack(const IntegrateArgs &a, float slack_scale) {
     const float vs = a.voxel_size, ext = (float)std::max(a.X, std::max(a.Y, a.Z));
     auto mag = [&](const cfloat3 &row, float t) { return fabsf(t) + (fabsf(row.x.re) + fabsf(row.y.re) + fabsf(row.z.re)) * vs * ext; };
     const float k = 2e-3f * (slack_scale - 1.0f);
-    static const float lateral = getenv("XS_BOX_SLACK_LATERAL") ? (float)atof(getenv("XS_BOX_SLACK_LATERAL")) : 2.0f;   // tuning aid
-    static const float axial = getenv("XS_BOX_SLACK_AXIAL") ? (float)atof(getenv("XS_BOX_SLACK_AXIAL")) : 0.3f;
+    static const float lateral = exp_env_float("XS_BOX_SLACK_LATERAL", 2.0f);   // (tuning aids of an XS_EXPERIMENTS build: xs_env.h)
+    static const float axial = exp_env_float("XS_BOX_SLACK_AXIAL", 0.3f);
     BoxSlack sl;
     sl.dX = lateral * k * mag(a.R.data[0], a.t.x.re); sl.dY = lateral * k * mag(a.R.data[1], a.t.y.re); sl.dC = axial * k * mag(a.R.data[2], a.t.z.re);
     return sl;
@@ -1386,7 +1140,7 @@ static bool box_slack_covers(const IntegrateArgs &l, const IntegrateArgs &f, con
 }
 // camera depth grows with z: the far bricks end the list, and the list is taken from that end (KF_FAR_FIRST)
 static bool far_end_first(const IntegrateArgs &a) {
-    static const char *env_order = getenv("XS_INTEGRATE_ORDER");   // A/B aid: "near" / "far" force the list direction
+    static const char *env_order = exp_env_str("XS_INTEGRATE_ORDER");   // A/B aid: "near" / "far" force the list direction
     return env_order ? !strcmp(env_order, "far") : a.R.data[2].z.re > 0.0f;
 }
 // the workspace's header, primary list region and capacity
@@ -1442,7 +1196,7 @@ static void classify_args(IntegrateArgs &a, int rows, int cols, const float *int
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.voxel_size = voxel_size; a.depth_max = depth_max_dev;
     host_frustum(a);
-    static const int env_bz = getenv("XS_BRICK_Z") ? atoi(getenv("XS_BRICK_Z")) : 0;  // tuning aid (as in xs_integrate_scaled_ex)
+    static const int env_bz = exp_env_int("XS_BRICK_Z", 0);  // tuning aid (as in xs_integrate_scaled_ex)
     a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
     a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(z1 - z0, a.brick_z);
 }
@@ -1468,7 +1222,7 @@ extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, con
     if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
     // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
     // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
-    static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;
+    static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");
     g_classes_of = nullptr;
     const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
     const bool boxes = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32 && g_depth_tiles;
@@ -1546,7 +1300,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev; a.depth_max = depth_max_dev;
     a.brick_list = nullptr; a.brick_count = nullptr; a.kflags = 0;
-    static const bool env_always = getenv("XS_INTEGRATE_ALWAYS_STORE") != nullptr;   // measurement aid, as the flag
+    static const bool env_always = exp_env_set("XS_INTEGRATE_ALWAYS_STORE");   // measurement aid, as the flag
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
     if (far_end_first(a)) a.kflags |= KF_FAR_FIRST;
@@ -1561,7 +1315,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     }
     host_frustum(a, posted ? g_post_slack : 1.0f);
     const int nz = z1 - z0;
-    static const int env_bz = getenv("XS_BRICK_Z") ? atoi(getenv("XS_BRICK_Z")) : 0;  // tuning aid
+    static const int env_bz = exp_env_int("XS_BRICK_Z", 0);  // tuning aid
     a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
     a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, a.brick_z);
     a.zchunk = nz;
@@ -1571,17 +1325,16 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
         // 32-bit lane offsets from the brick's first voxel whenever a brick spans less than 4 GiB of an array (always, short of absurd
         // pitches): no spills, the state loads take a scalar base (S1 launch 40.5 -> 39.2 us for the whole call, S2 unchanged)
-        static const char *env_k = getenv("XS_INTEGRATE_KERNEL");   // experiment: "ring" = the LDS-DMA ring kernel; "off64" = 64-bit pointers per lane
+        static const char *env_k = exp_env_str("XS_INTEGRATE_KERNEL");   // experiment: "off64" = 64-bit pointers per lane
         const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
-        const bool ring = env_k && !strcmp(env_k, "ring") && !a.signmap && threshold <= 0.0f && (size_t)a.drows * a.dstep < (1ull << 31) && (size_t)BRICK_Y * a.vstep < (1ull << 31);
         const bool sign = a.signmap != nullptr;
         // the boxes' classes (free space / nothing to write / exact walk) and the list's order: those xs_integrate_classify left for this
         // list, or decided here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here,
         // in the workspace
-        static const bool env_no_tiles = getenv("XS_INTEGRATE_NO_TILES") != nullptr;   // A/B aid, as the flag
+        static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");   // A/B aid, as the flag
         const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
         g_classes_of = nullptr;
-        const bool use_tiles = off32 && !ring && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
+        const bool use_tiles = off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
         auto tile_table = [&]() -> const DepthTile * {   // the caller's, or one built in the workspace's tile room
             if (g_depth_tiles || xs_depth_tiles_bytes(rows, cols) > TILE_ROOM_BYTES) return g_depth_tiles;
             DepthTile *own = reinterpret_cast<DepthTile *>((char *)workspace + workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz));
@@ -1598,7 +1351,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         }
         if (a.box_class) a.kflags &= ~(unsigned)KF_FAR_FIRST;   // the list is ordered by class
         // resident workgroups stride over the list: 256 CUs x 8
-        static const int env_g = getenv("XS_BRICK_GRID") ? atoi(getenv("XS_BRICK_GRID")) : 0;
+        static const int env_g = exp_env_int("XS_BRICK_GRID", 0);
         const int gmax = env_g > 0 ? env_g : 8192;
         const int g = nb < gmax ? nb : gmax;
         // profiling: the event pair rides on the dispatch packet itself (hipExtLaunchKernelGGL: start / stop are
@@ -1616,8 +1369,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
                         : (threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>);
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
-        if (ring && !a.box_class) kern = k_integrate_bricks_ring<false>;
-        static const int env_lds = getenv("XS_INTEGRATE_DYN_LDS") ? atoi(getenv("XS_INTEGRATE_DYN_LDS")) : 0;   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU
+        static const int env_lds = exp_env_int("XS_INTEGRATE_DYN_LDS", 0);   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU
         if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, g_int_ev0, g_int_ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, env_lds, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
@@ -2008,7 +1760,7 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     // kernel slower: four times the band voxels per lane, worse balance.)  Tiles of 64 x 4 columns x zchunk
     // planes; the workgroups stride over them.  (While every workgroup paid an L2 write-back for its record, 4096 of them
     // halved the streaming rate against 1024; the records now leave with write-through stores: block_fold_and_finish.)
-    static const int env_blocks = getenv("XS_HESS_BLOCKS") ? atoi(getenv("XS_HESS_BLOCKS")) : 0;  // tuning aid
+    static const int env_blocks = exp_env_int("XS_HESS_BLOCKS", 0);  // tuning aid
     int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
     // one workgroup per column of tiles while that gives 1024 .. 4096 of them (512^3: 1024, 1024^3: 4096 — measured best:
     // the Gauss-Newton pass at 1024^3 runs 15 % faster with 4096 workgroups walking one column each than with 1024 walking

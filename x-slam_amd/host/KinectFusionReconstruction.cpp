@@ -36,8 +36,6 @@ void KinectFusionReconstruction::SetSharding(int rank, int count, collective_fn 
 }
 
 KinectFusionReconstruction::~KinectFusionReconstruction() {
-    if (getenv("XS_KF_DEBUG_COVERS"))   // tuning aid: how often the list classified ahead held for the final pose (0: neither list nor classes, 1: the list only, 3: both)
-        std::fprintf(stderr, "list covers: none %lld  list only %lld  list and box classes %lld\n", list_cover_counts_[0], list_cover_counts_[1], list_cover_counts_[3]);
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (surface_done_) (void)hipEventDestroy(surface_done_);
     if (integrate_done_) (void)hipEventDestroy(integrate_done_);
