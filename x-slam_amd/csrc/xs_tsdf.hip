@@ -219,8 +219,12 @@ struct IntegrateArgs {
     unsigned *box_class;          // [list entry][BOXES_PER_BRICK] box_word (k_classify_boxes) or null: every box takes the exact walk
     size_t probe_offset;          // XS_EXPERIMENTS + XS_WG_TIMES only: bytes from box_class to the record area
 };
-enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };   // KF_FAR_FIRST: the list is taken from its end (see k_integrate_bricks)  // KF_COUNT_CLASSES: the kernel counts the boxes it classified (workspace header, words 48..50: free, empty, mixed)
-enum { CLASS_COUNT_WORD = 48 };    // write every updated voxel's three words even where the bits do not change (measurement aid)
+// KF_ALWAYS_STORE: write every updated voxel's three words even where the bits do not change (measurement aid)
+// KF_COUNT_CLASSES: the classification counts its boxes in the workspace header, words CLASS_COUNT_WORD + 0..3 and + 6: boxes wholly free /
+//                   wholly empty / with planes to walk, planes walked, planes streamed with the in-image test (EDGE boxes)
+// KF_FAR_FIRST:     the list is taken from its end (see k_integrate_bricks)
+enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };
+enum { CLASS_COUNT_WORD = 48 };
 
 namespace {
 // device side of the frustum: add the far limit (see struct Frustum).  Behind the farthest
@@ -327,6 +331,19 @@ __device__ __forceinline__ bool voxel_pixel(const IntegrateArgs &a, const PoseRT
     if (!(px_.coo_x > 1 && px_.coo_y > 1 && px_.coo_x < a.dcols - 1 && px_.coo_y < a.drows - 1)) return false;
     px_.near_x = __float2int_rn(o.image_x.re); px_.near_y = __float2int_rn(o.image_y.re);
     return true;
+}
+// what a column's voxels share: the z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy) — v_g has zero imaginary part, so each
+// complex product is (re*vg, im*vg) — and the conservative image window in un-divided form (one pixel of slack on each side)
+__device__ __forceinline__ VoxelCtx voxel_ctx(const IntegrateArgs &a, const PoseRT &ps, int x, int y) {
+    const float vgx = (x + 0.5f) * a.voxel_size;
+    const float vgy = (y + 0.5f) * a.voxel_size;
+    VoxelCtx k;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) k.base[r] = ps.R.data[r].x * vgx + ps.R.data[r].y * vgy;
+    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
+    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
+    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
+    return k;
 }
 template <bool BILINEAR> struct DepthWords;
 template <> struct DepthWords<false> { float n; };
@@ -458,17 +475,7 @@ __device__ __forceinline__ bool integrate_voxel(const IntegrateArgs &a, const Po
 template <bool BILINEAR, bool OFF32 = false, bool SIGN = false>   // SIGN: a.signmap is marked (a template parameter: the walk is bound by instruction issue)
 __device__ __forceinline__ unsigned integrate_span(const IntegrateArgs &a, const PoseRT &ps, int x, int y, int zb, int ze, size_t ubase = 0, int zb0 = 0, unsigned lane_off = 0) {
     unsigned n_upd = 0;
-    const float vgx = (x + 0.5f) * a.voxel_size;
-    const float vgy = (y + 0.5f) * a.voxel_size;
-    VoxelCtx k;
-    // z-invariant part of dot(R.row, v_g): (row.x*vgx) + (row.y*vgy); v_g has zero imaginary
-    // part, so each complex product is (re*vg, im*vg)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) k.base[r] = ps.R.data[r].x * vgx + ps.R.data[r].y * vgy;
-    k.fx = a.intr.fx; k.fy = a.intr.fy; k.cx = a.intr.cx; k.cy = a.intr.cy;
-    // conservative image window in un-divided form (one pixel of slack on each side)
-    k.ulo = 1.5f - k.cx; k.uhi = (a.dcols - 0.5f) - k.cx + 1.0f;
-    k.vlo = 1.5f - k.cy; k.vhi = (a.drows - 0.5f) - k.cy + 1.0f;
+    const VoxelCtx k = voxel_ctx(a, ps, x, y);
     const size_t row = (size_t)(zb - a.z0) * a.Y + y;
     float *pos = row_ptr(a.value, a.vstep, 0) + row * (a.vstep / 4) + x;
     int *wpos = row_ptr(a.weight, a.vstep, 0) + row * (a.vstep / 4) + x;
@@ -563,9 +570,23 @@ template <bool MAX> __device__ __forceinline__ float fold64(float v) {  // over 
 // A box's verdict, plane by plane: along the box's z the camera depth c is affine, the depth range of the pixels the box can see is one
 // pair (lo, hi) for the whole box — so the planes in front of everything (FREE) are the ones at the near end, the planes behind
 // everything (EMPTY) the ones at the far end, and what lies between takes the per-voxel walk: two counts and the direction.
-//   word = free planes | empty planes << 8 | (c falls with z) << 16
+//   word = free planes | empty planes << 8 | (c falls with z) << 16 | EDGE << 17
 // A surface across the planes puts its truncation band (six or seven planes wide) into one or two bricks' boxes: only those planes are walked.
-__device__ __forceinline__ unsigned box_word(int n_free, int n_empty, int falls) { return (unsigned)n_free | ((unsigned)n_empty << 8) | ((unsigned)falls << 16); }
+//
+// EDGE (round 5): the box's pixel range leaves the image — a box on the view frustum's side.  Its "free" planes are free WHERE THEY ARE IN
+// THE IMAGE: every voxel of them that passes the reference's in-image test (TsdfFusion.cu:123-124) sees a valid depth farther away than its
+// own c by more than the band (the range's depth bounds are taken over the part of it that lies in the image), so it is written with
+// tsdf = (1, 0) like any free voxel, and the voxels that fail the test are not written: what is left of the per-voxel work is that test
+// (integrate_edge_column).  Before, such a box walked every plane it could not call empty — and the frustum's sides pass through free
+// space almost everywhere: 72 % of the planes walked on the benchmark scene at 512^3 and at 1024^3 (profiles/tools/emulate_box_classes.py,
+// profiles/r05_box_classes_emulated.txt); with the pose slack's pads on the pixel range (classes decided ahead of the final pose) a 32-voxel
+// box at 1024^3 is on an edge more often than not.  An EDGE box needs c >= EDGE_CMIN over its corners: the test's shortcut is derived
+// for voxels that are not at the camera (integrate_edge_column).
+enum : unsigned { BOX_EDGE_BIT = 1u << 17 };
+#define XS_EDGE_CMIN 0.05f
+__device__ __forceinline__ unsigned box_word(int n_free, int n_empty, int falls, bool edge = false) {
+    return (unsigned)n_free | ((unsigned)n_empty << 8) | ((unsigned)falls << 16) | (edge ? (unsigned)BOX_EDGE_BIT : 0u);
+}
 __device__ __forceinline__ float dpp_fold4min(float v) { v = fminf(v, dpp_xor1(v)); return fminf(v, dpp_xor2(v)); }
 __device__ __forceinline__ float dpp_fold4max(float v) { v = fmaxf(v, dpp_xor1(v)); return fmaxf(v, dpp_xor2(v)); }
 // box = voxel indices [x0, x1) x [y0, y1) x [z0, z1), not empty.  Eight lanes per box (a wave classifies eight boxes at once): lane
@@ -618,7 +639,8 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
     lo = fold8<false>(lo); hi = fold8<true>(hi);
     const float band = (a.tranc_dist * 1.001f + 1e-5f) + 2e-4f;   // the walk's own band (update_voxel) + margin
     if (cmin - hi > band) return all_empty;                 // behind everything the box can see (hi = 0: nothing valid there)
-    if (inside && lo - cmax > band) return box_word(nz, 0, 0);   // in front of everything it can see (lo = 0 where a pixel is invalid)
+    const bool may_stream = inside || cmin >= XS_EDGE_CMIN;   // (cmin carries the pose slack: it bounds every covered pose's c)
+    if (may_stream && lo - cmax > band) return box_word(nz, 0, 0, !inside);   // in front of everything it can see (lo = 0 where a pixel is invalid)
     if (nz > 8) return all_walk;                            // (more planes per brick than lanes per box: a tuning configuration)
     // Plane by plane.  The four corners of the box's first plane are lanes 0 - 3 (corner bit 2 clear), of its last plane lanes 4 - 7; c moves
     // by dzc per plane at every (x, y).  Lane j takes plane j with the c range of the first plane's corners shifted j planes along.
@@ -628,7 +650,7 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
     const float dzc = a.R.data[2].z.re * a.voxel_size;
     const float pl_lo = (c0_lo + (float)corner * dzc) - sl.dC - 1e-5f, pl_hi = (c0_hi + (float)corner * dzc) + sl.dC + 1e-5f;   // plane `corner`'s c range
     const bool p_ok = corner < nz;
-    const bool p_free = p_ok && inside && lo - pl_hi > band, p_empty = p_ok && pl_lo - hi > band;
+    const bool p_free = p_ok && may_stream && lo - pl_hi > band, p_empty = p_ok && pl_lo - hi > band;
     const int shift = (int)(threadIdx.x & 63u) & ~7;          // the group's first lane in the wave
     const unsigned fm = (unsigned)(__builtin_amdgcn_ballot_w64(p_free) >> shift) & 0xffu, em = (unsigned)(__builtin_amdgcn_ballot_w64(p_empty) >> shift) & 0xffu;
     const int falls = dzc < 0.f ? 1 : 0;
@@ -641,7 +663,7 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
         n_empty = __builtin_ctz(~em | 0x100u);
     }
     n_free = min(n_free, nz); n_empty = min(n_empty, nz - n_free);
-    return box_word(n_free, n_empty, falls);
+    return box_word(n_free, n_empty, falls, !inside && n_free > 0);
 }
 // FREE box: voxels (x, y, zb .. ze - 1) of this lane's column (which lies in the volume).  A rolling pipeline over groups of FREE_CHUNK
 // planes: the next group's state is requested before the current group is updated and stored, so the wave always has reads in flight
@@ -687,6 +709,59 @@ __device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a
     }
     if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
     return (unsigned)(ze - zb);
+}
+
+
+// EDGE box: like integrate_free_column, but a voxel is updated only if it passes the reference's in-image test (TsdfFusion.cu:123-124) —
+// the one per-voxel decision left (see BOX_EDGE_BIT).  The exact path (voxel_pixel) decides it from
+//     image_x = Re(px * (1 / v_c.z)) + cx,   coo_x = floor(image_x - 0.5),   1 < coo_x < cols - 1   <=>   2.5 <= image_x < cols - 0.5
+// (and the same in y).  Here the real parts X, Y, c of v_c are formed with the exact path's own operations (the real part of each complex
+// sum and product: the same bits), and the window is tested on the un-divided coordinates with a margin of EDGE_MARGIN pixels: the float
+// image_x differs from fx X / c + cx in real arithmetic by < 3e-4 px (three roundings of magnitudes <= 640, the imaginary products ~1e-14),
+// the un-divided terms by < 1e-4 px — two hundred times inside the margin, at any c >= XS_EDGE_CMIN.  A voxel inside the window by the
+// margin is in the image, one outside by the margin is not, and the few in between (a strip 2 x EDGE_MARGIN px wide along the image
+// border: a few per cent of the rows of an edge box) run the exact test itself — wave-uniformly skipped where no lane needs it.
+#define XS_EDGE_MARGIN 0.03125f
+struct EdgeWindow { float ulo, uhi, vlo, vhi; };   // the window shrunk by the margin, relative to the principal point
+__device__ __forceinline__ bool edge_in_image(const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, const EdgeWindow &w, int z) {
+    const float vgz = (z + 0.5f) * a.voxel_size;
+    const float X = (k.base[0].re + ps.R.data[0].z.re * vgz) + ps.t.x.re;
+    const float Y = (k.base[1].re + ps.R.data[1].z.re * vgz) + ps.t.y.re;
+    const float c = (k.base[2].re + ps.R.data[2].z.re * vgz) + ps.t.z.re;
+    const float pxr = X * k.fx, pyr = Y * k.fy;
+    const float d = fminf(fminf(pxr - w.ulo * c, w.uhi * c - pxr), fminf(pyr - w.vlo * c, w.vhi * c - pyr));   // >= 0: inside by the margin
+    bool in = d >= 0.0f;
+    const bool unsure = !in && !(d < -2.0f * XS_EDGE_MARGIN * c);   // (NaN: unsure — the exact test decides)
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
+        if (unsure) { VoxelProj p; VoxelPixel q; in = voxel_pixel(a, ps, k, z, p, q); }
+    }
+    return in;
+}
+template <bool SIGN>
+__device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a, const PoseRT &ps, char *bv, char *bw, char *bg, unsigned off, unsigned plane,
+                                                          int x, int y, int zb, int ze) {
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    const VoxelCtx k = voxel_ctx(a, ps, x, y);
+    EdgeWindow w;
+    w.ulo = (2.5f + XS_EDGE_MARGIN) - k.cx; w.uhi = ((a.dcols - 0.5f) - XS_EDGE_MARGIN) - k.cx;
+    w.vlo = (2.5f + XS_EDGE_MARGIN) - k.cy; w.vhi = ((a.drows - 0.5f) - XS_EDGE_MARGIN) - k.cy;
+    float vmin = 0.0f;
+    unsigned n = 0;
+    // the free column's rolling pipeline, one plane per group: the next plane's test and state request go out before this plane's stores
+    FreeGroup A, B;
+    bool inA = edge_in_image(a, ps, k, w, zb), inB = false;
+    if (inA) free_group_load(A, bv, bw, bg, off, plane, 1);
+#pragma unroll 1
+    for (int z = zb; z < ze; z += 2, off += 2 * plane) {
+        inB = z + 1 < ze && edge_in_image(a, ps, k, w, z + 1);
+        if (inB) free_group_load(B, bv, bw, bg, off + plane, plane, 1);
+        if (inA) { free_group_store<SIGN>(a, A, bv, bw, bg, off, plane, 1, always, vmin); ++n; }
+        inA = z + 2 < ze && edge_in_image(a, ps, k, w, z + 2);
+        if (inA) free_group_load(A, bv, bw, bg, off + 2 * plane, plane, 1);
+        if (inB) { free_group_store<SIGN>(a, B, bv, bw, bg, off + plane, plane, 1, always, vmin); ++n; }
+    }
+    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
+    return n;
 }
 
 }  // namespace
@@ -799,6 +874,7 @@ __device__ __forceinline__ unsigned classify_brick_boxes(const IntegrateArgs &a,
     if (corner == 0 && (a.kflags & KF_COUNT_CLASSES)) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
         atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
         atomicAdd(a.brick_count + CLASS_COUNT_WORD + 3, (unsigned)(nz - nf - ne));
+        if (word & BOX_EDGE_BIT) atomicAdd(a.brick_count + CLASS_COUNT_WORD + 6, (unsigned)nf);   // planes streamed with the in-image test (words + 4, + 5: the second ListPair)
     }
     return word | (nf + ne < nz ? 1u << 31 : 0u);
 }
@@ -961,9 +1037,10 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
                 walk_lo = falls ? zb0 + ne : zb0 + nf; walk_hi = falls ? ze0 - nf : ze0 - ne;
                 if (nf > 0 && x < a.X && y < a.Y) {
                     const size_t ubase = ((size_t)(f0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-                    n_upd += integrate_free_column<SIGN>(a, reinterpret_cast<char *>(a.value) + ubase, reinterpret_cast<char *>(a.weight) + ubase,
-                                                         reinterpret_cast<char *>(a.grad) + ubase, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u,
-                                                         (unsigned)a.Y * (unsigned)a.vstep, x, y, f0, f1);
+                    char *fv = reinterpret_cast<char *>(a.value) + ubase, *fw = reinterpret_cast<char *>(a.weight) + ubase, *fg = reinterpret_cast<char *>(a.grad) + ubase;
+                    const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
+                    if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column<SIGN>(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
+                    else n_upd += integrate_free_column<SIGN>(a, fv, fw, fg, foff, fplane, x, y, f0, f1);
                 }
                 if (walk_lo >= walk_hi) continue;
             }
@@ -1166,7 +1243,8 @@ static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *w
     a.dt = depth_tiles_view(tiles, a.drows, a.dcols);
     bind_classes(a, res, nz, workspace);
     // (a list classed a second time — XS_INTEGRATE_RECLASSIFY_BOXES — finds the first classification's counts there; behind a header clear the pair is zero)
-    if (!second_pair_is_clear && hipMemsetAsync(a.brick_count + PAIR_SECOND, 0, 2 * sizeof(unsigned), st) != hipSuccess) return false;
+    // (... and its class counters: words CLASS_COUNT_WORD .. + 6 hold the counters, the second pair between them — one fill)
+    if (!second_pair_is_clear && hipMemsetAsync(a.brick_count + CLASS_COUNT_WORD, 0, 7 * sizeof(unsigned), st) != hipSuccess) return false;
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
     BoxOrder ord;
     ord.list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz));
