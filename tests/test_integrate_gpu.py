@@ -493,16 +493,7 @@ def tiles_numpy(scaled, tw=8, th=8):
     return out
 
 
-def holed(d, rng, n_holes=40, speckle=0.002):
-    """A depth frame with rectangular holes (0), out-of-range pixels and speckle."""
-    d = d.copy()
-    h, w = d.shape
-    for _ in range(n_holes):
-        y, x = rng.integers(0, h - 30), rng.integers(0, w - 40)
-        d[y:y + rng.integers(1, 30), x:x + rng.integers(1, 40)] = rng.choice([0, 150, 6000])
-    m = rng.random(d.shape) < speckle
-    d[m] = 0
-    return d
+holed = synth.holed   # (shared with bench.py's roofline_s2.noisy)
 
 
 @pytest.mark.parametrize("shape", [(480, 640), (150, 200), (97, 131)])

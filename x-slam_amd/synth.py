@@ -133,9 +133,25 @@ def s1_params(n=256, seed=(0, 3), seed_h=1e-7, threshold=0.0):
     )
 
 
-def render_s2(width=WIDTH, height=HEIGHT):
-    """Static view of a plane 4.5 m in front of the camera (z-depth constant)."""
-    return np.full((height, width), 4500, np.uint16)
+def render_s2(width=WIDTH, height=HEIGHT, noise_mm=0.0, frame=0):
+    """Static view of a plane 4.5 m in front of the camera (z-depth constant); noise_mm: SURVEY 8(d)'s uniform sensor noise."""
+    mm = np.full((height, width), 4500.0)
+    if noise_mm > 0:
+        mm = mm + noise_mm * _hash_noise(frame, width * height).reshape(height, width)
+    return np.clip(np.rint(mm), 0, 65535).astype(np.uint16)
+
+
+def holed(d, rng, n_holes=40, speckle=0.002):
+    """A depth frame with rectangular holes (0), out-of-range pixels (150 / 6000 mm: outside the 200..5000 gate of TsdfFusion.cu:76-81)
+    and speckle (single invalid pixels): what a real sensor's frame looks like to the integrate kernel's box classification."""
+    d = d.copy()
+    h, w = d.shape
+    for _ in range(n_holes):
+        y, x = rng.integers(0, h - 30), rng.integers(0, w - 40)
+        d[y:y + rng.integers(1, 30), x:x + rng.integers(1, 40)] = rng.choice([0, 150, 6000])
+    m = rng.random(d.shape) < speckle
+    d[m] = 0
+    return d
 
 
 def s2_params(n=512):
