@@ -149,6 +149,59 @@ void xs_integrate_set_timing_events(void *start_event, void *stop_event);
  * launch, on the auxiliary stream); NULL disables. */
 void xs_integrate_set_classify_event(void *done_event);
 
+/* ---- Options structs (round 5): what the per-thread setters above carry, as an argument ------------------------------------------
+ * xs_integrate_scaled_ex2 / xs_integrate_classify_ex / xs_raycast_ex / xs_raycast_slab_ex / xs_resize_pyramid_ex take everything the call
+ * needs in their argument lists; they read NO per-thread state, so nothing a previous call set (or an early return forgot to clear) can
+ * leak into them.  The setters (xs_integrate_set_*, xs_raycast_set_*, xs_resize_pyramid_set_completion_event) remain as thin wrappers:
+ * they fill one per-thread struct of the same type, which only the older entry points (xs_integrate_scaled*, xs_integrate_classify,
+ * xs_raycast, xs_raycast_slab, xs_resize_pyramid) read.  Zero-initialise a struct, set struct_bytes = sizeof(it), fill what applies.
+ *
+ * The library remembers, per host thread, what xs_integrate_classify* last classified (workspace, pose, slack): a following integrate call
+ * with XS_INTEGRATE_LIST_IS_READY uses those box classes only after checking ITS pose against the slack they were padded for, and
+ * decides the boxes again with its own pose otherwise — XS_INTEGRATE_RECLASSIFY_BOXES is a hint that saves the check, not a
+ * correctness requirement (the brick LIST itself is the caller's claim: xs_integrate_list_covers). */
+typedef struct xs_integrate_opts {
+    unsigned struct_bytes;           /* sizeof(xs_integrate_opts) */
+    unsigned flags;                  /* XS_INTEGRATE_* */
+    const void *depth_tiles;         /* this frame's xs_scale_depth_tiles table, or NULL (the call builds its own in its workspace) */
+    void *signmap;                   /* the sign map the call marks, or NULL */
+    void *start_event, *stop_event;  /* hipEvent_t riding on the integrate kernel's dispatch (classify: stop_event = its last dispatch); NULL = none */
+    const void *pose_mailbox;        /* XS_INTEGRATE_POSE_POSTED: the mailbox the gate polls ... */
+    unsigned mailbox_seq;            /* ... the sequence number it waits for ... */
+    float mailbox_slack;             /* ... the factor the call widens the list pose's frustum planes by ... */
+    void *pose_dev;                  /* ... and 128 bytes of device memory through which the gate hands the pose on */
+} xs_integrate_opts;
+int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
+                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
+                            int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
+                            unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, const xs_integrate_opts *opts, void *stream);
+int xs_integrate_classify_ex(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
+                             float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale,
+                             const xs_integrate_opts *opts, void *stream);
+typedef struct xs_raycast_opts {
+    unsigned struct_bytes;           /* sizeof(xs_raycast_opts) */
+    int signmap_shift;               /* the sign map's brick shift (2..6) */
+    const void *signmap;             /* the sign map the march goes by, or NULL (march from t = 0.2) */
+    float signmap_tranc_dist;        /* the truncation distance the map was reset for */
+    float *pyr_vmap1, *pyr_nmap1;    /* model-map pyramid built by the one-launch form (all four or none) */
+    size_t pyr_step1;
+    float *pyr_vmap2, *pyr_nmap2;
+    size_t pyr_step2;
+    void *completion_event;          /* hipEvent_t riding on the one-launch form's dispatch, or NULL */
+    int *steps_dev;                  /* measurement: rows x cols ints receiving every ray's march length, or NULL */
+    int pyramid_built;               /* OUT: 1 if the call built the pyramid (else launch xs_resize_pyramid) */
+} xs_raycast_opts;
+int xs_raycast_ex(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                  float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+                  float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
+                  xs_raycast_opts *opts, void *stream);
+int xs_raycast_slab_ex(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                       float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+                       int zs0, int zs1, int z0, int z1, float *vmap, float *nmap, size_t map_step, int rows, int cols, int *keys_dev,
+                       const xs_raycast_opts *opts, void *stream);
+int xs_resize_pyramid_ex(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
+                         size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *completion_event, void *stream);
+
 /* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */
 size_t xs_tsdf_reduce_workspace_bytes(void);
 /* float4 ComputeLocalTsdf_hessian(depth, Intr, depthScaled, res, voxel_size, const MatD33& Rv2c,

@@ -825,3 +825,106 @@ def test_brick_classification_adversarial_grazing_surfaces(dev):
                 assert np.array_equal(x, y), trial
             assert a[1] == b[1] and a[1] > 1000, trial
     assert total[0] > 20 and total[1] > 0 and total[2] > 100, total
+
+
+def _one_frame_setup(torch, capi, n, k=3, threshold=0.0):
+    prm = synth.s1_params(n, threshold=threshold)
+    res = [n, n, n]
+    H, W = synth.HEIGHT, synth.WIDTH
+    depth = torch.from_numpy(synth.s1_frame(k).astype(np.int16)).cuda()
+    scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    tiles = torch.zeros(capi.depth_tiles_bytes(H, W), dtype=torch.uint8, device="cuda")
+    capi.scale_depth_tiles(depth, W * 2, H, W, scaled, W * 4, dmax, tiles)
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+    T = s1_transforms(k, prm)
+
+    def volume():
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        return v, w, g
+    common = lambda vol, R, t: (scaled, W * 4, H, W, intr_of(prm), 100, res, prm["tsdf_voxel_size"], R, t, tranc_dist(prm), vol[0], vol[1], vol[2], n * 4)
+    return prm, res, T, scaled, dmax, tiles, ws, volume, common
+
+
+def test_options_struct_entry_points_read_no_thread_state(dev):
+    """xs_integrate_scaled_ex2 / xs_integrate_classify_ex take the depth tiles, the sign map and the events in their options struct and read
+    nothing the per-thread setters left: with a poisoned per-thread tile table (all zeros: every box would be called empty and nothing
+    written) they produce the plain call's volume bit for bit, with the tiles handed over in the struct or built by the call itself."""
+    torch, capi = dev
+    n = 128
+    prm, res, T, scaled, dmax, tiles, ws, volume, common = _one_frame_setup(torch, capi, n)
+    ref = volume()
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    capi.integrate_scaled_ex(*common(ref, T["Rv2c"], T["tv2c"]), 32, updated=cnt, depth_max=dmax, workspace=ws)   # the per-voxel walk everywhere
+    torch.cuda.synchronize()
+    U = int(cnt.item())
+    assert U > 10000
+    poison = torch.zeros_like(tiles)
+    capi.integrate_set_depth_tiles(poison)
+    try:
+        for own_tiles in (tiles, None):
+            vol = volume()
+            cnt.zero_()
+            capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=0, depth_tiles=own_tiles), updated=cnt, depth_max=dmax, workspace=ws)
+            torch.cuda.synchronize()
+            assert int(cnt.item()) == U
+            for a, b in zip(ref, vol):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        # ... and classified ahead through the struct
+        vol = volume()
+        cnt.zero_()
+        capi.integrate_classify_ex(synth.HEIGHT, synth.WIDTH, intr_of(prm), res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), ws,
+                                   capi.integrate_opts(flags=0, depth_tiles=tiles), slack_scale=2.0, depth_max=dmax)
+        capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=4 | 1, depth_tiles=tiles), updated=cnt, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == U
+        for a, b in zip(ref, vol):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        # the older entry point does read the per-thread table: the poison shows (this is what the struct calls are immune to)
+        vol = volume()
+        cnt.zero_()
+        capi.integrate_scaled_ex(*common(vol, T["Rv2c"], T["tv2c"]), 0, updated=cnt, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) < U
+    finally:
+        capi.integrate_set_depth_tiles(None)
+    with pytest.raises(capi.XsError):
+        bad = capi.integrate_opts()
+        bad.struct_bytes = 8
+        capi.integrate_scaled_ex2(*common(ref, T["Rv2c"], T["tv2c"]), bad, depth_max=dmax, workspace=ws)
+
+
+def test_classes_decided_ahead_are_checked_against_the_launch_pose(dev):
+    """box classes left by xs_integrate_classify were trusted whenever the caller set LIST_IS_READY.  The library now
+    remembers the pose and slack they were padded for and decides the boxes again when the launch's pose lies outside: a caller that
+    passes LIST_IS_READY for a pose the LIST covers but the CLASSES do not (xs_integrate_list_covers == 1), without the
+    RECLASSIFY_BOXES hint, still gets the plain call's volume bit for bit."""
+    torch, capi = dev
+    n = 128
+    prm, res, T, scaled, dmax, tiles, ws, volume, common = _one_frame_setup(torch, capi, n)
+    H, W = synth.HEIGHT, synth.WIDTH
+    R, t = T["Rv2c"], T["tv2c"]
+    found = None
+    for dz in (0.004, 0.006, 0.008, 0.012, 0.016, 0.02, 0.03):     # along the viewing axis: the classes' pad there is a third of a sideways one
+        t2 = np.array(t, np.float32).copy(); t2[2, 0] += dz
+        if capi.integrate_list_covers(H, W, intr_of(prm), res, prm["tsdf_voxel_size"], R, t, 2.0, R, t2) == 1:
+            found = t2
+            break
+    assert found is not None, "no pose with a covered list and uncovered classes among the candidates"
+    ref = volume()
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    capi.integrate_scaled_ex(*common(ref, R, found), 32, updated=cnt, depth_max=dmax, workspace=ws)
+    torch.cuda.synchronize()
+    U = int(cnt.item())
+    for hint in (0, 128):     # without and with XS_INTEGRATE_RECLASSIFY_BOXES
+        vol = volume()
+        cnt.zero_()
+        capi.integrate_classify_ex(H, W, intr_of(prm), res, prm["tsdf_voxel_size"], R, t, tranc_dist(prm), ws, capi.integrate_opts(depth_tiles=tiles),
+                                   slack_scale=2.0, depth_max=dmax)
+        capi.integrate_scaled_ex2(*common(vol, R, found), capi.integrate_opts(flags=4 | 1 | hint, depth_tiles=tiles), updated=cnt, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == U, hint
+        for a, b in zip(ref, vol):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), hint

@@ -229,6 +229,14 @@ def test_sharded_protocol_world2_gloo(oracle):
     mp.spawn(_worker, args=(2, _free_port(), 48, 2), nprocs=2, join=True)
 
 
+@pytest.mark.timeout(900)
+def test_sharded_protocol_world4_gloo(oracle):
+    """Four ranks (12-plane slabs of a 48^3 volume: every inner rank's 6-plane halos reach half way into both neighbours), each a process,
+    gloo collectives: min-key all-reduce, counts, the four-way gather-v of the owned pixels, the 440-byte ICP all-reduce."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(4, _free_port(), 48, 2), nprocs=4, join=True)
+
+
 def test_slab_and_row_bounds_tile():
     sh = importlib.import_module("x-slam_amd.sharded")
     for world in (1, 2, 3, 4, 8):

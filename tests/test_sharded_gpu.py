@@ -44,11 +44,15 @@ def run_world(torch, sh, prm, world, frames):
     return shards, results
 
 
+# world 4 and 8 (north_star's rank count) at 128^3: 32- and 16-plane slabs whose 6-plane halos reach into both neighbours; eight orchestrators as
+# threads of one process on one card (x-slam_amd/sharded.py LocalWorld) — every collective of the real run, met at a barrier
+WORLDS = [(2, 96), (3, 96), (4, 128), (8, 128)]
+
+
 @pytest.mark.parametrize("rows_sharded", [False, True], ids=["icp_replicated", "icp_row_shards"])
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(dev, world, rows_sharded):
+@pytest.mark.parametrize("world,n", WORLDS)
+def test_sharded_equals_single(dev, world, n, rows_sharded):
     torch, pl, sh = dev
-    n = 96
     prm = dict(synth.s1_params(n), icp_shard_rows=rows_sharded)
     frames = [0, 1, 2]
     single = pl.KinectFusion(prm)
@@ -110,14 +114,14 @@ def test_sharded_equals_single(dev, world, rows_sharded):
     single.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_composite_by_gather_equals_the_sum_of_maps_and_halves_the_bytes(dev, world):
+@pytest.mark.parametrize("world,n", WORLDS)
+def test_composite_by_gather_equals_the_sum_of_maps_and_halves_the_bytes(dev, world, n):
     """The raycast composite as an owner-compacted exchange (every rank packs the pixels it owns, the packs are gathered and scattered:
     shard_composite_gather, the default) against the int32 sum of the maps (round 3): the same poses, counts, ICP sums and composed maps on
     every rank, bit for bit, over six frames — and at most 0.55 of the bytes received, summed over the ranks and counting the min-key
     all-reduce both forms share (a ring all-reduce moves every pixel's 48 bytes twice, the gather each owned pixel's 52 once)."""
     torch, pl, sh = dev
-    prm = synth.s1_params(96)
+    prm = synth.s1_params(n)
     frames = list(range(6))
     s_g, g = run_world(torch, sh, dict(prm, shard_composite_gather=True), world, frames)
     s_s, a = run_world(torch, sh, dict(prm, shard_composite_gather=False), world, frames)
@@ -142,14 +146,15 @@ def test_composite_by_gather_equals_the_sum_of_maps_and_halves_the_bytes(dev, wo
         s.close()
 
 
-def test_sharded_sign_map_changes_nothing(dev):
+@pytest.mark.parametrize("world", [3, 8])
+def test_sharded_sign_map_changes_nothing(dev, world):
     """Every rank keeps a sign map of the planes it stores (owned slab + halo, marked by its own integrate calls) and its slab march
-    evaluates only the iterations that map leaves: poses, counts and ICP sums of a three-rank run with and without, bit for bit."""
+    evaluates only the iterations that map leaves: poses, counts and ICP sums of a three- and an eight-rank run with and without, bit for bit."""
     torch, pl, sh = dev
     prm = synth.s1_params(128)
     frames = list(range(6))
-    s_on, on = run_world(torch, sh, dict(prm, raycast_sign_map=True), 3, frames)
-    s_off, off = run_world(torch, sh, dict(prm, raycast_sign_map=False), 3, frames)
+    s_on, on = run_world(torch, sh, dict(prm, raycast_sign_map=True), world, frames)
+    s_off, off = run_world(torch, sh, dict(prm, raycast_sign_map=False), world, frames)
     for a_, b_ in zip(on, off):
         assert np.array_equal(a_[0], b_[0]) and a_[1] == b_[1] and a_[2] == b_[2]
         assert np.array_equal(a_[3], b_[3])

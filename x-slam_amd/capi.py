@@ -34,7 +34,30 @@ def _load():
 
 _lib = _load()
 
+class IntegrateOpts(C.Structure):
+    """xs_integrate_opts (include/xslam_amd.h): what an integrate / classify call takes besides its arguments proper."""
+    _fields_ = [("struct_bytes", C.c_uint), ("flags", C.c_uint), ("depth_tiles", C.c_void_p), ("signmap", C.c_void_p),
+                ("start_event", C.c_void_p), ("stop_event", C.c_void_p), ("pose_mailbox", C.c_void_p), ("mailbox_seq", C.c_uint),
+                ("mailbox_slack", C.c_float), ("pose_dev", C.c_void_p)]
+
+
+class RaycastOpts(C.Structure):
+    """xs_raycast_opts (include/xslam_amd.h)."""
+    _fields_ = [("struct_bytes", C.c_uint), ("signmap_shift", C.c_int), ("signmap", C.c_void_p), ("signmap_tranc_dist", C.c_float),
+                ("pyr_vmap1", C.c_void_p), ("pyr_nmap1", C.c_void_p), ("pyr_step1", C.c_size_t), ("pyr_vmap2", C.c_void_p), ("pyr_nmap2", C.c_void_p),
+                ("pyr_step2", C.c_size_t), ("completion_event", C.c_void_p), ("steps_dev", C.c_void_p), ("pyramid_built", C.c_int)]
+
+
 _SIGS = {
+    "xs_integrate_scaled_ex2": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, C.c_int, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, _vp, _vp,
+                                         _sz, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(IntegrateOpts), _vp]),
+    "xs_integrate_classify_ex": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _vp, _vp,
+                                           C.c_float, C.POINTER(IntegrateOpts), _vp]),
+    "xs_raycast_ex": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, _vp, _vp, _sz,
+                                C.c_int, C.c_int, _vp, _vp, C.POINTER(RaycastOpts), _vp]),
+    "xs_raycast_slab_ex": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, _i32p, C.c_float, _vp, _vp, _sz, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, C.POINTER(RaycastOpts), _vp]),
+    "xs_resize_pyramid_ex": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp]),
     "xs_last_error": (C.c_char_p, []),
     "xs_abi_version": (C.c_int, []),
     "xs_init_volume": (C.c_int, [_vp, _vp, _vp, _sz, _i32p, C.c_int, C.c_int, _vp]),
@@ -274,6 +297,40 @@ def integrate_scaled_ex(depth_scaled, scaled_step, rows, cols, intr, max_weight,
                                       _ptr(workspace), flags, _stream(stream)))
 
 
+def integrate_opts(flags=0, depth_tiles=None, signmap=None, start_event=None, stop_event=None, pose_mailbox=None, mailbox_seq=0, mailbox_slack=2.0,
+                   pose_dev=None):
+    """An xs_integrate_opts for integrate_scaled_ex2 / integrate_classify_ex (tensors or raw addresses for the pointers)."""
+    o = IntegrateOpts()
+    o.struct_bytes = C.sizeof(IntegrateOpts)
+    o.flags = flags
+    o.depth_tiles, o.signmap, o.pose_mailbox, o.pose_dev = _ptr(depth_tiles), _ptr(signmap), _ptr(pose_mailbox), _ptr(pose_dev)
+    o.start_event = start_event.value if hasattr(start_event, "value") else start_event
+    o.stop_event = stop_event.value if hasattr(stop_event, "value") else stop_event
+    o.mailbox_seq, o.mailbox_slack = mailbox_seq, mailbox_slack
+    return o
+
+
+def integrate_scaled_ex2(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight,
+                         grad, vol_step, opts, threshold=0.0, z0=0, z1=None, updated=None, depth_max=None, workspace=None, stream=None):
+    """xs_integrate_scaled_ex2: everything the call needs in its arguments (opts: integrate_opts(...)); reads no per-thread state."""
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
+    z1 = int(r[2]) if z1 is None else z1
+    check(_lib.xs_integrate_scaled_ex2(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), max_weight,
+                                       r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
+                                       _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _ptr(depth_max),
+                                       _ptr(workspace), C.byref(opts), _stream(stream)))
+
+
+def integrate_classify_ex(rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, workspace, opts, slack_scale=2.0, z0=0, z1=None,
+                          depth_max=None, stream=None):
+    r = _ia(res, 3)
+    k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
+    check(_lib.xs_integrate_classify_ex(rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p),
+                                        t.ctypes.data_as(_f32p), tranc_dist, z0, int(r[2]) if z1 is None else z1, _ptr(depth_max), _ptr(workspace),
+                                        slack_scale, C.byref(opts), _stream(stream)))
+
+
 def integrate_classify(rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, workspace, slack_scale=2.0, flags=0, z0=0, z1=None,
                        depth_max=None, stream=None):
     """The brick classification of an integrate call on its own, for a pose near the final one (xs_integrate_classify)."""
@@ -449,6 +506,31 @@ def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, gr
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
                           vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _ptr(workspace), _stream(stream)))
+
+
+def raycast_opts(signmap=None, shift=3, tranc_dist=0.0, pyramid=None, completion_event=None, steps=None):
+    """An xs_raycast_opts; pyramid = (vmap1, nmap1, step1, vmap2, nmap2, step2) or None."""
+    o = RaycastOpts()
+    o.struct_bytes = C.sizeof(RaycastOpts)
+    o.signmap, o.signmap_shift, o.signmap_tranc_dist = _ptr(signmap), shift, tranc_dist
+    if pyramid is not None:
+        o.pyr_vmap1, o.pyr_nmap1, o.pyr_step1, o.pyr_vmap2, o.pyr_nmap2, o.pyr_step2 = (_ptr(pyramid[0]), _ptr(pyramid[1]), pyramid[2],
+                                                                                       _ptr(pyramid[3]), _ptr(pyramid[4]), pyramid[5])
+    o.completion_event = completion_event.value if hasattr(completion_event, "value") else completion_event
+    o.steps_dev = _ptr(steps)
+    return o
+
+
+def raycast_ex(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols, opts,
+               hits=None, workspace=None, stream=None):
+    """xs_raycast_ex: xs_raycast with its options as an argument (opts: raycast_opts(...); opts.pyramid_built is set by the call)."""
+    _prep(voxel_size)
+    r = _ia(res, 3)
+    k = _fa(intr, 4)
+    a, b, c, d = _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
+    P = lambda x: x.ctypes.data_as(_f32p)
+    check(_lib.xs_raycast_ex(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad), vol_step,
+                             _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _ptr(workspace), C.byref(opts), _stream(stream)))
 
 
 def raycast_set_step_buffer(buf):

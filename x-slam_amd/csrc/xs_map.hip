@@ -382,6 +382,11 @@ extern "C" void xs_resize_pyramid_set_completion_event(void *event) { g_pyramid_
  * of the level-0 maps; all level-0 maps share in_step, level-1 mid_step, level-2 out_step. */
 extern "C" int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
                                  size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *stream) {
+    return xs_resize_pyramid_ex(vmap0, nmap0, in_step, rows0, cols0, vmap1, nmap1, mid_step, vmap2, nmap2, out_step, g_pyramid_done, stream);
+}
+// (the same with the completion event as an argument: reads no per-thread state)
+extern "C" int xs_resize_pyramid_ex(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
+                                    size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *completion_event, void *stream) {
     if (!vmap0 || !nmap0 || !vmap1 || !nmap1 || !vmap2 || !nmap2) return xs_set_error(hipErrorInvalidValue, "xs_resize_pyramid: null pointer");
     const int rows1 = rows0 / 2, cols1 = cols0 / 2;
     if (rows1 <= 0 || cols1 <= 0) return 0;
@@ -391,7 +396,7 @@ extern "C" int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t 
     a.out[0] = (cfloat *)vmap2; a.out[1] = (cfloat *)nmap2;
     a.istep = in_step; a.mstep = mid_step; a.ostep = out_step; a.rows0 = rows0; a.cols0 = cols0;
     dim3 block(64, 4), grid(div_up(div_up(cols1, 2), 64), div_up(div_up(rows1, 2), 4), 2);
-    if (g_pyramid_done) hipExtLaunchKernelGGL(k_resize_pyramid, grid, block, 0, (hipStream_t)stream, nullptr, g_pyramid_done, 0, a);
+    if (completion_event) hipExtLaunchKernelGGL(k_resize_pyramid, grid, block, 0, (hipStream_t)stream, nullptr, (hipEvent_t)completion_event, 0, a);
     else hipLaunchKernelGGL(k_resize_pyramid, grid, block, 0, (hipStream_t)stream, a);
     XS_CHECK(hipGetLastError());
     return 0;

@@ -717,9 +717,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
     }
 }
 
+// What the per-thread setters hold for the older entry points (xs_raycast, xs_raycast_slab): one options struct, the same type
+// xs_raycast_ex / xs_raycast_slab_ex take as an argument (and read nothing else).
+static thread_local xs_raycast_opts g_ray_legacy = {};
 // measurement hook (bench.py): a device buffer of rows x cols ints that the single-GPU march fills with every ray's step count
-static thread_local int *g_ray_steps = nullptr;
-extern "C" void xs_raycast_set_step_buffer(int *steps_dev) { g_ray_steps = steps_dev; }
+extern "C" void xs_raycast_set_step_buffer(int *steps_dev) { g_ray_legacy.steps_dev = steps_dev; }
 
 static int ray_wshift() {
     static const int env_ws = exp_env_int("XS_RAY_WSHIFT", 3);
@@ -744,12 +746,9 @@ extern "C" int xs_raycast_signmap_shift(const float *intr4, float voxel_size, fl
     return 0;
 }
 
-// the sign map (xs_signmap.h) the following single-GPU launches of this thread start their rays from; null = every ray from t = 0.2
-static thread_local void *g_ray_signmap = nullptr;
-static thread_local int g_ray_signmap_shift = 0;
-static thread_local float g_ray_signmap_tranc = 0.0f;
+// the sign map (xs_signmap.h) the following xs_raycast / xs_raycast_slab calls of this thread start their rays from; null = every ray from t = 0.2
 extern "C" void xs_raycast_set_signmap(const void *signmap, int shift, float tranc_dist) {
-    g_ray_signmap = const_cast<void *>(signmap); g_ray_signmap_shift = shift; g_ray_signmap_tranc = tranc_dist;
+    g_ray_legacy.signmap = signmap; g_ray_legacy.signmap_shift = shift; g_ray_legacy.signmap_tranc_dist = tranc_dist;
 }
 
 // do the resident planes of one volume array span at most 4 GiB (and the 24-bit products hold)?
@@ -784,22 +783,31 @@ static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y =
 // xs_resize_pyramid takes them): the one-launch form of the raycast (workspace + sign map) then builds it inside the raycast kernel, and
 // xs_raycast_pyramid_built() says whether that call did (else the caller launches xs_resize_pyramid as before).  A completion event rides
 // on that launch like xs_resize_pyramid_set_completion_event's on the pyramid kernel.
-static thread_local PyramidArgs g_ray_pyr = {};
-static thread_local bool g_ray_pyr_set = false, g_ray_pyr_built = false;
-static thread_local hipEvent_t g_ray_done = nullptr;
 extern "C" void xs_raycast_set_pyramid(float *vmap1, float *nmap1, size_t step1, float *vmap2, float *nmap2, size_t step2) {
-    g_ray_pyr_set = vmap1 && nmap1 && vmap2 && nmap2;
-    g_ray_pyr.mid[0] = (cfloat *)vmap1; g_ray_pyr.mid[1] = (cfloat *)nmap1; g_ray_pyr.out[0] = (cfloat *)vmap2; g_ray_pyr.out[1] = (cfloat *)nmap2;
-    g_ray_pyr.mstep = step1; g_ray_pyr.ostep = step2;
+    g_ray_legacy.pyr_vmap1 = vmap1; g_ray_legacy.pyr_nmap1 = nmap1; g_ray_legacy.pyr_step1 = step1;
+    g_ray_legacy.pyr_vmap2 = vmap2; g_ray_legacy.pyr_nmap2 = nmap2; g_ray_legacy.pyr_step2 = step2;
 }
-extern "C" int xs_raycast_pyramid_built(void) { return g_ray_pyr_built ? 1 : 0; }
-extern "C" void xs_raycast_set_completion_event(void *event) { g_ray_done = (hipEvent_t)event; }
+extern "C" int xs_raycast_pyramid_built(void) { return g_ray_legacy.pyramid_built; }
+extern "C" void xs_raycast_set_completion_event(void *event) { g_ray_legacy.completion_event = event; }
 
+// the older entry point: the options are what the per-thread setters left
 extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                           float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                           float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
                           void *stream) {
-    g_ray_pyr_built = false;
+    g_ray_legacy.struct_bytes = sizeof(xs_raycast_opts);
+    return xs_raycast_ex(intr4, Rc2v18, tc2v6, Rv2w18, tv2w6, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols, hits_dev,
+                         workspace, &g_ray_legacy, stream);
+}
+extern "C" int xs_raycast_ex(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                             float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+                             float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
+                             xs_raycast_opts *opts, void *stream) {
+    xs_raycast_opts none = {};
+    none.struct_bytes = sizeof(none);
+    xs_raycast_opts &o = opts ? *opts : none;
+    if (o.struct_bytes != sizeof(xs_raycast_opts)) return xs_set_error(hipErrorInvalidValue, "xs_raycast_ex: opts->struct_bytes is not sizeof(xs_raycast_opts)");
+    o.pyramid_built = 0;
     if (!intr4 || !Rc2v18 || !tc2v6 || !Rv2w18 || !tv2w6 || !res || !value || !grad || !vmap || !nmap)
         return xs_set_error(hipErrorInvalidValue, "xs_raycast: null pointer");
     if (rows <= 0 || cols <= 0) return 0;
@@ -814,18 +822,18 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.vmap = (cfloat *)vmap; a.nmap = (cfloat *)nmap; a.mstep = map_step;
     a.zs0 = 0; a.zs1 = res[2]; a.z0 = 0; a.z1 = res[2]; a.keys = nullptr;
-    a.hits = hits_dev; a.cross_t = workspace; a.steps = g_ray_steps;
+    a.hits = hits_dev; a.cross_t = workspace; a.steps = o.steps_dev;
     a.sm = SignMap{};
     a.pyr = PyramidArgs{};
-    if (g_ray_signmap && workspace) {
+    if (o.signmap && workspace) {
         // the map's time table was written for one truncation distance (xs_signmap_reset): any other would resume at wrong times
-        if (g_ray_signmap_tranc * 0.8f != a.time_step || g_ray_signmap_shift < 2 || g_ray_signmap_shift > 6)
+        if (o.signmap_tranc_dist * 0.8f != a.time_step || o.signmap_shift < 2 || o.signmap_shift > 6)
             return xs_set_error(hipErrorInvalidValue, "xs_raycast: the sign map was prepared for another truncation distance");
         static thread_local float nt_for = 0.0f;
         static thread_local int nt = 0;
         if (nt_for != a.time_step) { nt = signmap_steps(a.time_step); nt_for = a.time_step; }
         if (nt == 0) return xs_set_error(hipErrorInvalidValue, "xs_raycast: the march has more steps than the sign map's time table holds");
-        a.sm = signmap_view(g_ray_signmap, res, g_ray_signmap_shift, nt);
+        a.sm = signmap_view(const_cast<void *>(o.signmap), res, o.signmap_shift, nt);
     }
     a.wshift = ray_wshift();
     a.sm_dt = 0.0f; a.sm_rounds = 0;
@@ -842,13 +850,14 @@ extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *
             // frame's 4 800 waves either way) — no second dispatch, no crossing-time plane written and read back
             a.hits = hits_dev;
             static const bool env_no_pyr = exp_env_set("XS_RAY_NO_PYRAMID");   // A/B aid: the pyramid stays a launch of its own
-            if (g_ray_pyr_set && !env_no_pyr) {
-                a.pyr = g_ray_pyr;
+            if (o.pyr_vmap1 && o.pyr_nmap1 && o.pyr_vmap2 && o.pyr_nmap2 && !env_no_pyr) {
+                a.pyr.mid[0] = (cfloat *)o.pyr_vmap1; a.pyr.mid[1] = (cfloat *)o.pyr_nmap1; a.pyr.out[0] = (cfloat *)o.pyr_vmap2; a.pyr.out[1] = (cfloat *)o.pyr_nmap2;
+                a.pyr.mstep = o.pyr_step1; a.pyr.ostep = o.pyr_step2;
                 a.pyr.in[0] = a.vmap; a.pyr.in[1] = a.nmap; a.pyr.istep = map_step; a.pyr.rows0 = rows; a.pyr.cols0 = cols;
-                g_ray_pyr_built = true;
+                o.pyramid_built = 1;
             }
             void (*kern)(const RaycastArgs) = off32 ? ((a.dv.ok & 2u) ? k_raycast<0, true, true, true> : k_raycast<0, true, false, true>) : k_raycast<0, false, false, true>;
-            if (g_ray_done) hipExtLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, nullptr, g_ray_done, 0, a);
+            if (o.completion_event) hipExtLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, nullptr, (hipEvent_t)o.completion_event, 0, a);
             else hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, a);
             XS_CHECK(hipGetLastError());
             return 0;
@@ -881,6 +890,18 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
                                float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                                int zs0, int zs1, int z0, int z1, float *vmap, float *nmap, size_t map_step, int rows, int cols,
                                int *keys_dev, void *stream) {
+    g_ray_legacy.struct_bytes = sizeof(xs_raycast_opts);
+    return xs_raycast_slab_ex(intr4, Rc2v18, tc2v6, Rv2w18, tv2w6, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap, map_step, rows,
+                              cols, keys_dev, &g_ray_legacy, stream);
+}
+extern "C" int xs_raycast_slab_ex(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
+                                  float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
+                                  int zs0, int zs1, int z0, int z1, float *vmap, float *nmap, size_t map_step, int rows, int cols,
+                                  int *keys_dev, const xs_raycast_opts *opts, void *stream) {
+    xs_raycast_opts none = {};
+    none.struct_bytes = sizeof(none);
+    const xs_raycast_opts &o = opts ? *opts : none;
+    if (o.struct_bytes != sizeof(xs_raycast_opts)) return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab_ex: opts->struct_bytes is not sizeof(xs_raycast_opts)");
     if (!intr4 || !Rc2v18 || !tc2v6 || !Rv2w18 || !tv2w6 || !res || !value || !grad || !vmap || !nmap || !keys_dev)
         return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: null pointer");
     if (zs0 < 0 || zs1 > res[2] || z0 < zs0 || z1 > zs1 || z1 < z0) return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: bad slab");
@@ -900,13 +921,13 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
     a.sm = SignMap{};
     a.pyr = PyramidArgs{};
     a.sm_dt = 0.0f; a.sm_rounds = 0;
-    if (g_ray_signmap) {
+    if (o.signmap) {
         // this rank's sign map (marked by its own integrate calls: owned slab + halo): the march evaluates the iterations it leaves
-        if (g_ray_signmap_tranc * 0.8f != a.time_step || g_ray_signmap_shift < 2 || g_ray_signmap_shift > 6)
+        if (o.signmap_tranc_dist * 0.8f != a.time_step || o.signmap_shift < 2 || o.signmap_shift > 6)
             return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: the sign map was prepared for another truncation distance");
         const int nt = signmap_steps(a.time_step);
         if (nt == 0) return xs_set_error(hipErrorInvalidValue, "xs_raycast_slab: the march has more steps than the sign map's time table holds");
-        a.sm = signmap_view(g_ray_signmap, res, g_ray_signmap_shift, nt);
+        a.sm = signmap_view(const_cast<void *>(o.signmap), res, o.signmap_shift, nt);
     }
     a.wshift = ray_wshift();
     dim3 block(256), grid(div_up(div_up(cols, 2 << a.wshift) * div_up(rows, 128 >> a.wshift), 8) * 8);

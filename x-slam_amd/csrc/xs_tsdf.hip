@@ -1127,34 +1127,22 @@ static void host_frustum(IntegrateArgs &a, float slack_scale = 1.0f) {
     }
 }
 
-// optional profiling hook: HIP events recorded immediately around the integrate kernel proper
-// (after the brick classification), on the launch stream
-static thread_local hipEvent_t g_int_ev0 = nullptr, g_int_ev1 = nullptr;
-// completion event of xs_integrate_classify's launches (rides on the last dispatch): for a caller that classifies on one stream and integrates on another
-static thread_local hipEvent_t g_class_ev = nullptr;
-extern "C" void xs_integrate_set_classify_event(void *done_event) { g_class_ev = (hipEvent_t)done_event; }
-extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) {
-    g_int_ev0 = (hipEvent_t)start_event; g_int_ev1 = (hipEvent_t)stop_event;
-}
-
-// posted-pose hook (see k_integrate_bricks<., ., true>): the mailbox the next XS_INTEGRATE_POSE_POSTED call's kernel polls, its number, and the
-// factor by which that call widens the frustum planes of the pose it is given (the list's pose)
-static thread_local const unsigned *g_post_mailbox = nullptr;
-static thread_local unsigned g_post_seq = 0;
-static thread_local float g_post_slack = 2.0f;
-static thread_local unsigned *g_post_pose_dev = nullptr;
+// What the per-thread setters hold for the OLDER entry points (xs_integrate_scaled*, xs_integrate_classify): one options struct of the type
+// xs_integrate_scaled_ex2 / xs_integrate_classify_ex take as an argument — those read no per-thread state at all.
+//   start / stop event   HIP events riding on the integrate kernel's own dispatch (after the brick classification)
+//   classify event       completion of xs_integrate_classify's launches (rides on the last dispatch): classify on one stream, integrate on another
+//   pose mailbox         see k_integrate_bricks<., ., true>: the mailbox the next XS_INTEGRATE_POSE_POSTED call's gate polls, its number, the
+//                        factor by which that call widens the frustum planes of the pose it is given (the list's pose), the hand-over buffer
+//   sign map             the map (xs_signmap.h) the launches mark; depth tiles: the frame's table (xs_scale_depth_tiles), null = the call builds its own
+static thread_local xs_integrate_opts g_legacy = {sizeof(xs_integrate_opts), 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 2.0f, nullptr};
+static thread_local void *g_legacy_class_ev = nullptr;
+extern "C" void xs_integrate_set_classify_event(void *done_event) { g_legacy_class_ev = done_event; }
+extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) { g_legacy.start_event = start_event; g_legacy.stop_event = stop_event; }
 extern "C" void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mailbox_seq, float slack_scale, void *pose_dev) {
-    g_post_mailbox = (const unsigned *)mailbox; g_post_seq = mailbox_seq; g_post_slack = slack_scale; g_post_pose_dev = (unsigned *)pose_dev;
+    g_legacy.pose_mailbox = mailbox; g_legacy.mailbox_seq = mailbox_seq; g_legacy.mailbox_slack = slack_scale; g_legacy.pose_dev = pose_dev;
 }
-
-/* bytes of device workspace xs_integrate_scaled wants for a slab of nz planes (brick work list) */
-// the sign map (xs_signmap.h) the following launches of this thread mark; null = none
-static thread_local unsigned char *g_signmap = nullptr;
-extern "C" void xs_integrate_set_signmap(void *signmap) { g_signmap = static_cast<unsigned char *>(signmap); }
-// the frame's depth-tile table (xs_scale_depth_tiles) for the following launches of this thread; null = the call builds its own from the
-// scaled image, in its workspace
-static thread_local const DepthTile *g_depth_tiles = nullptr;
-extern "C" void xs_integrate_set_depth_tiles(const void *tiles) { g_depth_tiles = static_cast<const DepthTile *>(tiles); }
+extern "C" void xs_integrate_set_signmap(void *signmap) { g_legacy.signmap = signmap; }
+extern "C" void xs_integrate_set_depth_tiles(const void *tiles) { g_legacy.depth_tiles = tiles; }
 enum { TILE_ROOM_BYTES = 1 << 20 };   // the workspace's own tile table: images of up to 131 072 tiles (e.g. 4096 x 2048 pixels); larger ones take the exact walk everywhere
 // workspace: 256-byte header | brick list (int per brick) | box classes (BOXES_PER_BRICK words per list entry) | the call's own depth tiles
 static size_t workspace_bricks(const int *res, int nz) { return (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2); }   // room for 2-plane bricks
@@ -1166,9 +1154,11 @@ extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
     return workspace_order_offset(res, nz) + ((workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255);
 }
-// the workspace whose box classes xs_integrate_classify has written on this thread's behalf (for the xs_integrate_scaled_ex call with
-// XS_INTEGRATE_LIST_IS_READY that follows), and the slack they were classified with
-static thread_local const void *g_classes_of = nullptr;
+// What xs_integrate_classify* last classified on this thread's behalf: the workspace whose box classes it wrote, the pose and the slack
+// they were padded for.  The integrate call with XS_INTEGRATE_LIST_IS_READY that follows uses those classes only if ITS pose lies within
+// that slack (box_slack_covers) — checked here, whatever the caller says — and decides the boxes again with its own pose otherwise.
+struct ClassesAhead { const void *workspace; float R18[18], t6[6]; float slack_scale; };
+static thread_local ClassesAhead g_classes_ahead = {nullptr, {}, {}, 1.0f};
 
 /* The two tiny launches xs_integrate_scaled wraps around its kernels, for a caller that takes them off its critical path
  * (xs_integrate_scaled_ex with XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD): the clear of the workspace's 256-byte
@@ -1288,6 +1278,16 @@ static void classify_args(IntegrateArgs &a, int rows, int cols, const float *int
 extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
                                      float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale, unsigned flags,
                                      void *stream) {
+    xs_integrate_opts o = g_legacy;   // the older entry point: the options are what the per-thread setters left
+    o.flags = flags; o.start_event = nullptr; o.stop_event = g_legacy_class_ev;
+    return xs_integrate_classify_ex(rows, cols, intr4, res, voxel_size, Rv2c18, tv2c6, tranc_dist, z0, z1, depth_max_dev, workspace, slack_scale, &o, stream);
+}
+extern "C" int xs_integrate_classify_ex(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
+                                        float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale,
+                                        const xs_integrate_opts *opts, void *stream) {
+    if (!opts || opts->struct_bytes != sizeof(xs_integrate_opts)) return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify_ex: opts->struct_bytes is not sizeof(xs_integrate_opts)");
+    const unsigned flags = opts->flags;
+    const DepthTile *depth_tiles = static_cast<const DepthTile *>(opts->depth_tiles);
     if (!intr4 || !res || !Rv2c18 || !tv2c6 || !workspace || !(slack_scale >= 1.0f))
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify: bad argument");
     if (z0 < 0 || z1 > res[2] || z1 <= z0 || res[0] <= 0 || res[1] <= 0) return xs_set_error(hipErrorInvalidValue, "xs_integrate_classify: bad slab");
@@ -1301,12 +1301,16 @@ extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, con
     // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
     // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
     static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");
-    g_classes_of = nullptr;
+    g_classes_ahead.workspace = nullptr;
+    // (the 32-bit-offset condition on the tightest pitch: the integrate call tests the real one and decides the boxes itself when it disagrees)
     const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
-    const bool boxes = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32 && g_depth_tiles;
+    const bool boxes = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32 && depth_tiles;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
     // (the caller's completion event — xs_integrate_set_classify_event — rides on the dispatch)
-    if (launch_classification(a, res, z1 - z0, workspace, boxes ? g_depth_tiles : nullptr, box_slack(a, slack_scale), st, g_class_ev)) g_classes_of = workspace;
+    if (launch_classification(a, res, z1 - z0, workspace, boxes ? depth_tiles : nullptr, box_slack(a, slack_scale), st, (hipEvent_t)opts->stop_event)) {
+        g_classes_ahead.workspace = workspace; g_classes_ahead.slack_scale = slack_scale;
+        memcpy(g_classes_ahead.R18, Rv2c18, sizeof(g_classes_ahead.R18)); memcpy(g_classes_ahead.t6, tv2c6, sizeof(g_classes_ahead.t6));
+    }
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -1357,6 +1361,20 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
                                       const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                                       float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
                                       unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, unsigned flags, void *stream) {
+    xs_integrate_opts o = g_legacy;   // the older entry point: the options are what the per-thread setters left
+    o.flags = flags;
+    return xs_integrate_scaled_ex2(depth_scaled, scaled_step, rows, cols, intr4, max_weight, res, voxel_size, Rv2c18, tv2c6, tranc_dist, value, weight, grad,
+                                   vol_step, threshold, z0, z1, updated_dev, depth_max_dev, workspace, &o, stream);
+}
+extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
+                                       const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
+                                       float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
+                                       unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, const xs_integrate_opts *opts,
+                                       void *stream) {
+    if (!opts || opts->struct_bytes != sizeof(xs_integrate_opts)) return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex2: opts->struct_bytes is not sizeof(xs_integrate_opts)");
+    const unsigned flags = opts->flags;
+    const hipEvent_t ev0 = (hipEvent_t)opts->start_event, ev1 = (hipEvent_t)opts->stop_event;
+    const DepthTile *depth_tiles = static_cast<const DepthTile *>(opts->depth_tiles);
     if (!depth_scaled || !intr4 || !res || !Rv2c18 || !tv2c6 || !value || !weight || !grad)
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: null pointer");
     if ((flags & (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD | XS_INTEGRATE_LIST_IS_READY)) && !workspace)
@@ -1365,8 +1383,8 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled: bad slab or pitch");
     hipStream_t st = (hipStream_t)stream;
     if (z1 == z0 || res[0] == 0 || res[1] == 0) {   // nothing to launch: the caller's timing / completion events are recorded all the same
-        if (g_int_ev0) XS_CHECK(hipEventRecord(g_int_ev0, st));
-        if (g_int_ev1) XS_CHECK(hipEventRecord(g_int_ev1, st));
+        if (ev0) XS_CHECK(hipEventRecord(ev0, st));
+        if (ev1) XS_CHECK(hipEventRecord(ev1, st));
         return 0;
     }
     IntegrateArgs a;
@@ -1385,13 +1403,13 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
     a.dt = depth_tiles_view(nullptr, rows, cols); a.box_class = nullptr;
-    a.signmap = g_signmap;   // (a slab launch marks the bricks of its own planes: the map is indexed by whole-volume coordinates)
+    a.signmap = static_cast<unsigned char *>(opts->signmap);   // (a slab launch marks the bricks of its own planes: the map is indexed by whole-volume coordinates)
     if (posted) {
-        if (!workspace || !(flags & XS_INTEGRATE_LIST_IS_READY) || !g_post_mailbox || !g_post_pose_dev)
+        if (!workspace || !(flags & XS_INTEGRATE_LIST_IS_READY) || !opts->pose_mailbox || !opts->pose_dev)
             return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: a posted launch needs the classified list and a mailbox (xs_integrate_set_pose_mailbox)");
-        a.mailbox = g_post_mailbox; a.mailbox_seq = g_post_seq; a.pose_dev = g_post_pose_dev;
+        a.mailbox = (const unsigned *)opts->pose_mailbox; a.mailbox_seq = opts->mailbox_seq; a.pose_dev = (unsigned *)opts->pose_dev;
     }
-    host_frustum(a, posted ? g_post_slack : 1.0f);
+    host_frustum(a, posted ? opts->mailbox_slack : 1.0f);
     const int nz = z1 - z0;
     static const int env_bz = exp_env_int("XS_BRICK_Z", 0);  // tuning aid
     a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
@@ -1410,11 +1428,18 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // list, or decided here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here,
         // in the workspace
         static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");   // A/B aid, as the flag
-        const bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_of == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
-        g_classes_of = nullptr;
+        // the classes xs_integrate_classify* left hold for this launch only if its pose lies within the slack they were padded for: checked
+        // here (a posted launch is handed the list's own pose and receives a covered one through its mailbox: xs_integrate_pose_covered)
+        bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_ahead.workspace == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
+        if (classes_ahead && !posted) {
+            IntegrateArgs l = a;
+            load_mat(g_classes_ahead.R18, l.R); load_vec(g_classes_ahead.t6, l.t);
+            classes_ahead = box_slack_covers(l, a, res, g_classes_ahead.slack_scale);
+        }
+        g_classes_ahead.workspace = nullptr;
         const bool use_tiles = off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
         auto tile_table = [&]() -> const DepthTile * {   // the caller's, or one built in the workspace's tile room
-            if (g_depth_tiles || xs_depth_tiles_bytes(rows, cols) > TILE_ROOM_BYTES) return g_depth_tiles;
+            if (depth_tiles || xs_depth_tiles_bytes(rows, cols) > TILE_ROOM_BYTES) return depth_tiles;
             DepthTile *own = reinterpret_cast<DepthTile *>((char *)workspace + workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz));
             launch_scale_depth(depth_scaled, scaled_step, rows, cols, (float *)nullptr, (size_t)0, (float *)nullptr, own, st);
             return own;
@@ -1448,7 +1473,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
         static const int env_lds = exp_env_int("XS_INTEGRATE_DYN_LDS", 0);   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU
-        if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, g_int_ev0, g_int_ev1, 0, a);
+        if (ev0 || ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, ev0, ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, env_lds, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
             hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
@@ -1462,7 +1487,7 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
         // orchestrator's auxiliary stream does — must find it recorded whichever kernel ran)
         void (*kern)(const IntegrateArgs) = a.signmap ? (threshold > 0.0f ? k_integrate<true, true> : k_integrate<false, true>)
                                                       : (threshold > 0.0f ? k_integrate<true> : k_integrate<false>);
-        if (g_int_ev0 || g_int_ev1) hipExtLaunchKernelGGL(kern, grid, block, 0, st, g_int_ev0, g_int_ev1, 0, a);
+        if (ev0 || ev1) hipExtLaunchKernelGGL(kern, grid, block, 0, st, ev0, ev1, 0, a);
         else hipLaunchKernelGGL(kern, grid, block, 0, st, a);
     }
     XS_CHECK(hipGetLastError());

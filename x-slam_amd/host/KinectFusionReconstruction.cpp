@@ -666,13 +666,14 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
 // (classify_done_: the stream that integrates is another one)
 void KinectFusionReconstruction::EnqueueClassification(hipStream_t st, bool with_event) {
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
-    xs_integrate_set_depth_tiles(depth_tiles_.ptr());   // the boxes' classes are decided here too, with the slack's pads (xs_integrate_list_covers checks the final pose against them)
-    if (with_event) xs_integrate_set_classify_event(classify_done_);
-    check_rc(xs_integrate_classify(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
-                                   tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
-                                   integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u, st), "integrate classification");
-    xs_integrate_set_classify_event(nullptr);
-    xs_integrate_set_depth_tiles(nullptr);
+    xs_integrate_opts o = {};
+    o.struct_bytes = sizeof(o);
+    o.flags = integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u;
+    o.depth_tiles = depth_tiles_.ptr();   // the boxes' classes are decided here too, with the slack's pads (the integrate call checks its pose against them)
+    o.stop_event = with_event ? classify_done_ : nullptr;
+    check_rc(xs_integrate_classify_ex(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
+                                      tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_classify_slack,
+                                      &o, st), "integrate classification");
     classify_recorded_ = with_event;
     list_ready_ = true;
 }
@@ -722,28 +723,26 @@ void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
     DeviceArray2D<int> weight = tsdf_volume_d_ptr->weight();
+    xs_integrate_opts o = {};
+    o.struct_bytes = sizeof(o);
     hipEvent_t integrate_stop = integrate_done_;
     if (profiling) {
         integrate_stop = prof_ring_[prof_pending_].ev[ST_INTEGRATE][1];
-        xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], integrate_stop);
+        o.start_event = prof_ring_[prof_pending_].ev[ST_INTEGRATE][0];
         prof_ring_[prof_pending_].used[ST_INTEGRATE] = true;
-    } else
-        xs_integrate_set_timing_events(nullptr, integrate_stop);
+    }
+    o.stop_event = integrate_stop;
     if (++integrate_mail_seq_ == 0u) ++integrate_mail_seq_;
     posted_seq_ = integrate_mail_seq_;
-    xs_integrate_set_pose_mailbox(integrate_mailbox_, posted_seq_, integrate_classify_slack, posted_pose_.ptr());
-    xs_integrate_set_signmap(sign_map_ptr());
-    xs_integrate_set_depth_tiles(depth_tiles_.ptr());
+    o.pose_mailbox = integrate_mailbox_; o.mailbox_seq = posted_seq_; o.mailbox_slack = integrate_classify_slack; o.pose_dev = posted_pose_.ptr();
+    o.signmap = sign_map_ptr();
+    o.depth_tiles = depth_tiles_.ptr();
     const bool split = integrate_header_clear_;   // header cleared and count folded on the auxiliary stream (SurfaceMeasure)
-    check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_height, depth_width, &kinect_intrinsic.fx, max_integration_weight,
-                                    res, voxel_size, list_Rv2c_, list_tv2c_, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), weight.ptr(0), grad.ptr(0),
-                                    value.step(), biInterpolate_threshold, zo0, zo1, counters, depth_max_.ptr(), integrate_ws_.ptr(),
-                                    XS_INTEGRATE_POSE_POSTED | XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR | (split ? XS_INTEGRATE_NO_FOLD : 0u), st),
+    o.flags = XS_INTEGRATE_POSE_POSTED | XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR | (split ? XS_INTEGRATE_NO_FOLD : 0u);
+    check_rc(xs_integrate_scaled_ex2(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_height, depth_width, &kinect_intrinsic.fx, max_integration_weight,
+                                     res, voxel_size, list_Rv2c_, list_tv2c_, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr(0), weight.ptr(0), grad.ptr(0),
+                                     value.step(), biInterpolate_threshold, zo0, zo1, counters, depth_max_.ptr(), integrate_ws_.ptr(), &o, st),
              "integrateTsdfVolume (posted)");
-    xs_integrate_set_timing_events(nullptr, nullptr);
-    xs_integrate_set_pose_mailbox(nullptr, 0, 1.0f, nullptr);
-    xs_integrate_set_signmap(nullptr);
-    xs_integrate_set_depth_tiles(nullptr);
     posted_pending_ = true;
     posted_at_ = std::chrono::steady_clock::now();
     posted_stop_ = integrate_stop;
@@ -842,16 +841,18 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     // (its stop event — the profiling pair's when profiling) instead of a marker packet behind it, which the raycast
     // launch would queue behind (~5 us of every frame).
     hipEvent_t integrate_stop = integrate_done_;
+    xs_integrate_opts o = {};   // everything the integrate calls below take besides their arguments proper (no per-thread setters)
+    o.struct_bytes = sizeof(o);
     if (integrated_by_post) integrate_stop = posted_stop_;
     else if (profiling) {
         integrate_stop = prof_ring_[prof_pending_].ev[ST_INTEGRATE][1];
-        xs_integrate_set_timing_events(prof_ring_[prof_pending_].ev[ST_INTEGRATE][0], integrate_stop);
+        o.start_event = prof_ring_[prof_pending_].ev[ST_INTEGRATE][0]; o.stop_event = integrate_stop;
         prof_ring_[prof_pending_].used[ST_INTEGRATE] = true;
     } else if (integrate_split())
-        xs_integrate_set_timing_events(nullptr, integrate_stop);
+        o.stop_event = integrate_stop;
     if (!integrated_by_post) {
-        xs_integrate_set_signmap(sign_map_ptr());   // (a rank of a sharded volume: the owned planes and both halo bands mark it)
-        xs_integrate_set_depth_tiles(depth_tiles_.ptr());
+        o.signmap = sign_map_ptr();   // (a rank of a sharded volume: the owned planes and both halo bands mark it)
+        o.depth_tiles = depth_tiles_.ptr();
         // owned planes (counted), then the two halo bands every neighbour also integrates: the
         // update is per voxel and deterministic, so a halo voxel carries the owner's exact bits
         const int zr[3][2] = {{zo0, zo1}, {zs0, zo0}, {zo1, zs1}};
@@ -873,18 +874,16 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
                 else   // the last update moved the frustum further than the widened list allows for (never seen): start over
                     check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
             }
-            check_rc(xs_integrate_scaled_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
-                                            &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
-                                            &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
-                                            grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters : nullptr,
-                                            depth_max_dev, integrate_ws_.ptr(),
-                                            (split ? (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD) : 0u) | list_flag, st),
+            o.flags = (split ? (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD) : 0u) | list_flag;
+            check_rc(xs_integrate_scaled_ex2(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
+                                             &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
+                                             &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
+                                             grad.ptr((int)off), value.step(), biInterpolate_threshold, za, zb, i == 0 ? counters : nullptr,
+                                             depth_max_dev, integrate_ws_.ptr(), &o, st),
                      "integrateTsdfVolume");
             if (split) { integrate_header_clear_ = false; pending_fold_ = counters; }
-            if (i == 0) xs_integrate_set_timing_events(nullptr, nullptr);
+            if (i == 0) { o.start_event = nullptr; o.stop_event = nullptr; }   // (the event pair rides on the owned planes' launch only)
         }
-        xs_integrate_set_signmap(nullptr);
-        xs_integrate_set_depth_tiles(nullptr);
     }
 
     if (integrate_split()) integrate_done_now_ = integrate_stop;          // attached to the dispatch above
@@ -922,12 +921,10 @@ void KinectFusionReconstruction::ModelMapPyramid() {
         const int rows0 = vmaps_g_prev_d[0].rows() / 3, cols0 = vmaps_g_prev_d[0].cols();
         if (PreparePyramidLevels()) {
             // (its completion = the end of the frame's tail: what the announced next frame's map preparation waits for, HintNextFrame)
-            xs_resize_pyramid_set_completion_event(tail_done_);
-            check_rc(xs_resize_pyramid(&vmaps_g_prev_d[0].ptr()->re, &nmaps_g_prev_d[0].ptr()->re, vmaps_g_prev_d[0].step(), rows0, cols0,
-                                       &vmaps_g_prev_d[1].ptr()->re, &nmaps_g_prev_d[1].ptr()->re, vmaps_g_prev_d[1].step(),
-                                       &vmaps_g_prev_d[2].ptr()->re, &nmaps_g_prev_d[2].ptr()->re, vmaps_g_prev_d[2].step(), current_stream()),
+            check_rc(xs_resize_pyramid_ex(&vmaps_g_prev_d[0].ptr()->re, &nmaps_g_prev_d[0].ptr()->re, vmaps_g_prev_d[0].step(), rows0, cols0,
+                                          &vmaps_g_prev_d[1].ptr()->re, &nmaps_g_prev_d[1].ptr()->re, vmaps_g_prev_d[1].step(),
+                                          &vmaps_g_prev_d[2].ptr()->re, &nmaps_g_prev_d[2].ptr()->re, vmaps_g_prev_d[2].step(), tail_done_, current_stream()),
                      "resizeMap");
-            xs_resize_pyramid_set_completion_event(nullptr);
             tail_recorded_ = true;
             return;
         }
@@ -1128,23 +1125,22 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     if (sign_map_stale_) { RebuildSignMap(); sign_map_stale_ = false; }   // (xs_kf_volume_ptr handed the value array out since the last raycast)
+    xs_raycast_opts ro = {};   // the sign map, the pyramid outputs and the completion event of the raycast calls below (no per-thread setters)
+    ro.struct_bytes = sizeof(ro);
+    ro.signmap = sign_map_ptr(); ro.signmap_shift = raycast_sign_map_shift; ro.signmap_tranc_dist = tsdf_volume_d_ptr->getTsdfTruncDist();
     if (shard_count == 1 && !force_shard_composite) {
-        xs_raycast_set_signmap(sign_map_ptr(), raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist());
         // the model-map pyramid rides in the raycast launch where it can (three levels, the level-0 model maps, one launch: the sign map's
         // form): ModelMapPyramid then has nothing to launch, and the tail's completion event rides on the raycast
         pyramid_in_raycast_ = false;
         const bool own_maps = &xyz_g_d == &vmaps_g_prev_d[0] && &normal_g_d == &nmaps_g_prev_d[0];
         if (raycast_builds_pyramid && own_maps && PreparePyramidLevels()) {
-            xs_raycast_set_pyramid(&vmaps_g_prev_d[1].ptr()->re, &nmaps_g_prev_d[1].ptr()->re, vmaps_g_prev_d[1].step(),
-                                   &vmaps_g_prev_d[2].ptr()->re, &nmaps_g_prev_d[2].ptr()->re, vmaps_g_prev_d[2].step());
-            xs_raycast_set_completion_event(tail_done_);
+            ro.pyr_vmap1 = &vmaps_g_prev_d[1].ptr()->re; ro.pyr_nmap1 = &nmaps_g_prev_d[1].ptr()->re; ro.pyr_step1 = vmaps_g_prev_d[1].step();
+            ro.pyr_vmap2 = &vmaps_g_prev_d[2].ptr()->re; ro.pyr_nmap2 = &nmaps_g_prev_d[2].ptr()->re; ro.pyr_step2 = vmaps_g_prev_d[2].step();
+            ro.completion_event = tail_done_;
         }
         raycast(kinect_intrinsic, device_Rc2v, device_tc2v, device_Rv2w, device_tv2w, tsdf_volume_d_ptr->getTsdfTruncDist(), volume_res,
-                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, hits_counter_, ray_ws_.ptr());
-        if (xs_raycast_pyramid_built()) { pyramid_in_raycast_ = true; tail_recorded_ = true; }
-        xs_raycast_set_pyramid(nullptr, nullptr, 0, nullptr, nullptr, 0);
-        xs_raycast_set_completion_event(nullptr);
-        xs_raycast_set_signmap(nullptr, 0, 0.0f);
+                voxel_size, tsdf_volume_d_ptr->value(), tsdf_volume_d_ptr->grad(), xyz_g_d, normal_g_d, hits_counter_, ray_ws_.ptr(), &ro);
+        if (ro.pyramid_built) { pyramid_in_raycast_ = true; tail_recorded_ = true; }
         return 0;
     }
     // sharded: march this rank's planes, agree on the first event of every ray, add the winners
@@ -1152,11 +1148,9 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     const int rows = xyz_g_d.rows() / 3, cols = xyz_g_d.cols();
     hipStream_t st = current_stream();
     DeviceArray2D<float> value = tsdf_volume_d_ptr->value(), grad = tsdf_volume_d_ptr->grad();
-    xs_raycast_set_signmap(sign_map_ptr(), raycast_sign_map_shift, tsdf_volume_d_ptr->getTsdfTruncDist());
-    check_rc(xs_raycast_slab(&kinect_intrinsic.fx, &device_Rc2v.data[0].x.re, &device_tc2v.x.re, &device_Rv2w.data[0].x.re, &device_tv2w.x.re,
-                             tsdf_volume_d_ptr->getTsdfTruncDist(), res, voxel_size, value.ptr(), grad.ptr(), value.step(), zs0, zs1, zo0, zo1,
-                             &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, ray_keys_.ptr(), st), "raycast");
-    xs_raycast_set_signmap(nullptr, 0, 0.0f);
+    check_rc(xs_raycast_slab_ex(&kinect_intrinsic.fx, &device_Rc2v.data[0].x.re, &device_tc2v.x.re, &device_Rv2w.data[0].x.re, &device_tv2w.x.re,
+                                tsdf_volume_d_ptr->getTsdfTruncDist(), res, voxel_size, value.ptr(), grad.ptr(), value.step(), zs0, zs1, zo0, zo1,
+                                &xyz_g_d.ptr()->re, &normal_g_d.ptr()->re, xyz_g_d.step(), rows, cols, ray_keys_.ptr(), &ro, st), "raycast");
     hipSafeCall(hipMemcpyAsync(ray_min_keys_.ptr(), ray_keys_.ptr(), (size_t)rows * cols * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (collective) collective(collective_user, 1, ray_min_keys_.ptr(), (long)rows * cols);
     // (what a rank receives: a ring all-reduce of S bytes over N ranks moves 2 (N - 1) / N x S through every rank, a gather the other ranks' parts)

@@ -64,11 +64,11 @@ inline void integrateTsdfVolume(const PtrStepSz<ushort> &depth, const Intr &intr
 inline void raycast(const Intr &intr, const MatS33 &Rc2v, const devComplex3 &tc2v, const MatS33 &Rv2w, const devComplex3 &tv2w,
                     float tranc_dist, const int3 &volume_resolution, float voxel_size, const PtrStep<float> &value_volume,
                     const PtrStep<float> &grad_volume, MapArr &vmap, MapArr &nmap, unsigned long long *hits_dev = nullptr,
-                    float *workspace = nullptr) {
+                    float *workspace = nullptr, xs_raycast_opts *opts = nullptr) {   // opts: sign map, pyramid outputs, completion event (xs_raycast_ex)
     const int res[3] = {volume_resolution.x, volume_resolution.y, volume_resolution.z};
-    xs_host::check_rc(xs_raycast(&intr.fx, &Rc2v.data[0].x.re, &tc2v.x.re, &Rv2w.data[0].x.re, &tv2w.x.re, tranc_dist, res, voxel_size,
-                                 value_volume.data, grad_volume.data, value_volume.step, &vmap.ptr()->re, &nmap.ptr()->re, vmap.step(),
-                                 vmap.rows() / 3, vmap.cols(), hits_dev, workspace, xs_host::current_stream()), "raycast");
+    xs_host::check_rc(xs_raycast_ex(&intr.fx, &Rc2v.data[0].x.re, &tc2v.x.re, &Rv2w.data[0].x.re, &tv2w.x.re, tranc_dist, res, voxel_size,
+                                    value_volume.data, grad_volume.data, value_volume.step, &vmap.ptr()->re, &nmap.ptr()->re, vmap.step(),
+                                    vmap.rows() / 3, vmap.cols(), hits_dev, workspace, opts, xs_host::current_stream()), "raycast");
 }
 
 // ICP.h:24-31.  gbuf / mbuf are accepted for signature compatibility; the single-launch

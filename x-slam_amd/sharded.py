@@ -198,7 +198,11 @@ class ShardedKinectFusion(pl.KinectFusion):
                     key = (base, -1, OP_GATHERV)
                     t = views.get(key)
                     if t is None:     # the whole gather buffer (the orchestrator allocates it once: room for every pixel)
-                        t = views[key] = self._torch.as_tensor(_DevView(base, self.width * self.height * 52, "|u1"), device="cuda")
+                        # (entry size from the library, not a literal: xs_raycast_compose_entry_bytes.  Stream ordering: the orchestrator's
+                        # copy of this rank's own part into the buffer is enqueued on the stream torch.distributed orders its collectives
+                        # against — the current stream, which the pipeline was created on; a pipeline on another stream must synchronise first)
+                        from . import capi as _capi
+                        t = views[key] = self._torch.as_tensor(_DevView(base, self.width * self.height * _capi.raycast_compose_entry_bytes(), "|u1"), device="cuda")
                     gatherv_tensor(self._dist, self._torch, t, off)
                     return
                 key = (int(ptr), int(count), int(op))
