@@ -118,7 +118,7 @@ def test_sharded_equals_single(dev, world, n, rows_sharded):
 def test_composite_by_gather_equals_the_sum_of_maps_and_halves_the_bytes(dev, world, n):
     """The raycast composite as an owner-compacted exchange (every rank packs the pixels it owns, the packs are gathered and scattered:
     shard_composite_gather, the default) against the int32 sum of the maps (round 3): the same poses, counts, ICP sums and composed maps on
-    every rank, bit for bit, over six frames — and at most 0.55 of the bytes received, summed over the ranks and counting the min-key
+    every rank, bit for bit, over six frames — and at most 0.58 of the bytes received, summed over the ranks and counting the min-key
     all-reduce both forms share (a ring all-reduce moves every pixel's 48 bytes twice, the gather each owned pixel's 52 once)."""
     torch, pl, sh = dev
     prm = synth.s1_params(n)
@@ -141,7 +141,9 @@ def test_composite_by_gather_equals_the_sum_of_maps_and_halves_the_bytes(dev, wo
     # bytes received, summed over the ranks (in this scene one rank owns nearly every hit: it receives next to nothing and the others all of
     # it, where the ring all-reduce loads every rank alike)
     bg, bs = sum(s.composite_bytes() for s in s_g), sum(s.composite_bytes() for s in s_s)
-    assert 0 < bg <= 0.55 * bs, (bg, bs)
+    # per pixel and summed over N ranks: the sum of the maps moves 2 (N - 1) x (4 + 48) bytes, the gather 2 (N - 1) x 4 (the keys both forms share)
+    # + (N - 1) x 52 x the fraction of pixels with a hit: a ratio of 0.077 + 0.5 x hit fraction whatever N (0.55 at this scene's 0.95)
+    assert 0 < bg <= 0.58 * bs, (bg, bs)
     for s in s_g + s_s:
         s.close()
 
