@@ -136,6 +136,9 @@ long long xs_kf_composite_bytes(void *kf);
 /* integrate_post_pose: how many posted integrate launches were given their pose, and how many were told to leave because the final pose was
  * not covered by the planes they had been given (those frames took the plain call) */
 void xs_kf_posted_integrate_counts(void *kf, long long *accepted, long long *refused);
+/* How often the brick list and box classes decided ahead of a frame's final pose (behind its last ICP launch) held for that pose: counts4[0]
+ * neither (everything classified again), [1] the list only (the boxes decided again with the final pose), [3] both. */
+void xs_kf_list_cover_counts(void *kf, long long *counts4);
 
 /* volume checkpoint (value + grad + weight + poses)   cf. saveTSDFVolume, .cpp:438-447 */
 int xs_kf_save_checkpoint(void *kf, const char *path);

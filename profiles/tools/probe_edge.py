@@ -16,7 +16,7 @@ for e in ev:
     assert hip.hipEventCreate(C.byref(e)) == 0
 
 
-def run(n, mode, slack=2.0, threshold=0.0, frames=20):
+def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False):
     prm = synth.s1_params(n, threshold=threshold); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel_size"])); trunc = synth.tranc_dist(prm)
     value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
     grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
@@ -27,42 +27,46 @@ def run(n, mode, slack=2.0, threshold=0.0, frames=20):
     intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
     counter = torch.zeros(1, dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
-    times, Us, classes = [], [], None
+    times, Us, classes, vcount = [], [], None, 0
     for k in range(frames):
         depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
         dmax.zero_()
         capi.scale_depth_tiles(depth, W * 2, H, W, scaled, W * 4, dmax, tiles)
         T = synth.s1_transforms(k, prm)
         counter.zero_()
-        capi.integrate_set_depth_tiles(tiles)
         flags = 64
         if mode == "ahead":
-            capi.integrate_classify(H, W, intr, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, slack_scale=slack, flags=64, depth_max=dmax, stream=s)
+            capi.integrate_classify_ex(H, W, intr, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, capi.integrate_opts(flags=64, depth_tiles=tiles), slack_scale=slack, depth_max=dmax, stream=s)
             flags |= 4 | 1
         elif mode == "walk":
             flags |= 32
-        capi._lib.xs_integrate_set_timing_events(ev[0], ev[1])
-        capi.integrate_scaled_ex(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, flags, threshold=threshold,
-                                 updated=counter, depth_max=dmax, workspace=ws, stream=s)
-        capi._lib.xs_integrate_set_timing_events(None, None)
-        capi.integrate_set_depth_tiles(None)
+        o = capi.integrate_opts(flags=flags, depth_tiles=tiles, start_event=ev[0], stop_event=ev[1])
+        capi.integrate_scaled_ex2(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, o, threshold=threshold,
+                                  updated=counter, depth_max=dmax, workspace=ws, stream=s)
         torch.cuda.synchronize()
-        classes = [int(x) for x in ws[192:220].view(torch.int32).cpu().numpy()]
+        head = ws[192:232].view(torch.int32).cpu().numpy()
+        classes = [int(x) for x in head[:7]]; vcount = 0
         dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0
         if k >= 4:
             times.append(dt.value * 1e3); Us.append(int(counter.item()))
     U, t = np.median(Us), np.median(times)
-    print(f"n {n} {mode:6s} thr {threshold}: U {U:.0f}  kernel {t:.1f} us (min {min(times):.1f})  {24 * U / t / 1e6:.2f} TB/s algorithmic;  boxes free / nothing / walk "
-          f"{classes[0:3]}  planes walked {classes[3]}  edge planes {classes[6]}", flush=True)
+    print(f"n {n} {mode:6s}{' +hint' if hint else '      '} thr {threshold}: U {U:.0f}  kernel {t:.1f} us (min {min(times):.1f})  {24 * U / t / 1e6:.2f} TB/s algorithmic;  boxes free / nothing / walk "
+          f"{classes[0:3]}  planes walked {classes[3]}  edge planes {classes[6]}  workgroups with work {vcount}", flush=True)
     return value, weight, grad
 
 
 if __name__ == "__main__":
+    import os
     sizes = [int(v) for v in sys.argv[1:]] or [512, 1024]
+    quick = os.environ.get("PROBE_QUICK")          # A/B sweeps: the two pipeline-like modes only, no comparison against the walk
     for n in sizes:
+        if quick:
+            run(n, "own", hint=True); run(n, "ahead", hint=True)
+            torch.cuda.empty_cache()
+            continue
         ref = None
-        for mode in ("walk", "own", "ahead"):
-            out = run(n, mode)
+        for mode, hint in (("walk", False), ("own", False), ("own", True), ("ahead", False), ("ahead", True)):
+            out = run(n, mode, hint=hint)
             if ref is None: ref = [t.clone() for t in out]
             else:
                 same = all(bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(ref, out))
@@ -71,4 +75,5 @@ if __name__ == "__main__":
             del out
         del ref
         torch.cuda.empty_cache()
-    run(512, "walk", threshold=0.02); run(512, "own", threshold=0.02); run(512, "ahead", threshold=0.02)
+    if not quick:
+        run(512, "walk", threshold=0.02); run(512, "own", threshold=0.02, hint=True); run(512, "ahead", threshold=0.02, hint=True)

@@ -1,10 +1,10 @@
-"""GPU box, repository root, library built with -DXS_PROBE_WG_TIMES: when every workgroup of the S1 integrate kernel begins and ends
+"""GPU box, repository root, library built with -DXS_EXPERIMENTS -DXS_WG_TIMES (profiles/tools/probe_wg_times.sh; XS_PROBE_N = volume edge, default 512): when every workgroup of the S1 integrate kernel begins and ends
 (100 MHz wall clock), by the class of its box.  python profiles/tools/probe_wg_times.py"""
-import importlib, sys
+import importlib, os, sys
 sys.path.insert(0, '.')
 import numpy as np, torch
 capi = importlib.import_module('x-slam_amd.capi'); synth = importlib.import_module('x-slam_amd.synth')
-H, W, n = synth.HEIGHT, synth.WIDTH, 512
+H, W, n = synth.HEIGHT, synth.WIDTH, int(os.environ.get("XS_PROBE_N", "512"))
 prm = synth.s1_params(n); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel_size"])); trunc = synth.tranc_dist(prm)
 value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
 grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
@@ -14,7 +14,7 @@ nws = capi.integrate_workspace_bytes(res)
 ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
 intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
 s = torch.cuda.current_stream()
-nb = 16 * 64 * 64
+nb = (n // 32) * (n // 8) * (n // 8)
 list_bytes = (256 + nb * 4 * 4 + 255) // 256 * 256          # workspace_list_bytes: bricks of 2 planes -> 4x the 8-plane count
 class_bytes = (nb * 4 * 4 * 4 + 255) // 256 * 256      # a 32-bit word per box, four boxes per (2-plane) brick
 off = list_bytes + class_bytes + (1 << 18)
@@ -24,7 +24,9 @@ for k in range(12):
     T = synth.s1_transforms(k, prm)
     capi.integrate_scaled(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
-nwalk, nother = capi.integrate_listed(ws); count = nwalk + nother
+nwalk, nother = capi.integrate_listed(ws); listed = nwalk + nother
+count = min(listed, 8192)     # (a launch has 8 192 workgroups: with more bricks listed a workgroup takes a second one; its record then covers both)
+print(f"bricks listed {listed} ({nwalk} with planes to walk)")
 rec = ws[off:off + 8192 * 4 * 16].view(torch.int32).cpu().numpy().astype(np.int64).reshape(8192, 4, 4) & 0xffffffff
 t0 = rec[..., 0].min()
 b = (rec[..., 0] - t0) * 0.01; e = (rec[..., 1] - t0) * 0.01

@@ -70,7 +70,7 @@ public:
     bool integrate_classify_predicted = false;
     bool list_predicted_ = false;              // the list that is ready was classified for a predicted pose (this frame's SurfaceMeasure)
     int integrate_classify_early = 0;          // YAML integrate_classify_early: that many ICP iterations before the last (a pose that many more updates old)
-    long long list_cover_counts_[4] = {0, 0, 0, 0};   // what xs_integrate_list_covers said of the lists classified ahead (XS_KF_DEBUG_COVERS prints them)
+    long long list_cover_counts_[4] = {0, 0, 0, 0};   // what xs_integrate_list_covers said of the lists classified ahead (xs_kf_list_cover_counts)
     // the integrate kernel itself enqueued behind that classification, handed the final pose through a mailbox of its own and a one-wave gate
     // kernel (YAML integrate_post_pose, default FALSE; needs integrate_classify_ahead and a mailbox in device memory).  Round 3, first form: all
     // three launches went in one ICP iteration early (YAML integrate_post_early) — 16 % of the frames were then not covered by the planes of a

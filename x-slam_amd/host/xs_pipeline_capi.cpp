@@ -257,6 +257,9 @@ void xs_kf_debug_fail_icp_iteration(void *kf, int n) { ((KF *)kf)->debug_fail_ic
 void xs_kf_debug_post_delay(void *kf, int min_us, int max_us) { ((KF *)kf)->debug_post_delay_us_[0] = min_us; ((KF *)kf)->debug_post_delay_us_[1] = max_us; }
 void xs_kf_rebuild_sign_map(void *kf) { ((KF *)kf)->RebuildSignMap(); }
 long long xs_kf_composite_bytes(void *kf) { return ((KF *)kf)->composite_bytes_; }
+void xs_kf_list_cover_counts(void *kf, long long *counts4) {
+    if (counts4) for (int i = 0; i < 4; ++i) counts4[i] = ((KF *)kf)->list_cover_counts_[i];
+}
 void xs_kf_posted_integrate_counts(void *kf, long long *accepted, long long *refused) {
     if (accepted) *accepted = ((KF *)kf)->posted_accepted_;
     if (refused) *refused = ((KF *)kf)->posted_refused_;

@@ -59,6 +59,7 @@ _SIGS = {
     "xs_kf_rebuild_sign_map": (None, [_vp]),
     "xs_kf_hint_next_frame": (None, [_vp, _vp, _sz]),
     "xs_kf_posted_integrate_counts": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "xs_kf_list_cover_counts": (None, [_vp, C.POINTER(C.c_longlong)]),
     "xs_kf_cumulative_counters": (None, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
@@ -290,6 +291,12 @@ class KinectFusion:
     def composite_bytes(self):
         """Shard mode: bytes this rank received through the raycast composite's collectives so far (see xs_kf_composite_bytes)."""
         return int(_lib.xs_kf_composite_bytes(self.h))
+
+    def list_cover_counts(self):
+        """Frames whose list / box classes decided ahead held for the final pose: {"neither": n, "list_only": n, "both": n}."""
+        c = (C.c_longlong * 4)()
+        _lib.xs_kf_list_cover_counts(self.h, c)
+        return {"neither": int(c[0]), "list_only": int(c[1]), "both": int(c[3])}
 
     def posted_integrate_counts(self):
         """(accepted, refused) posted integrate launches so far (integrate_post_pose)."""
