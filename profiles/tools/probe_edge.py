@@ -16,7 +16,7 @@ for e in ev:
     assert hip.hipEventCreate(C.byref(e)) == 0
 
 
-def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False):
+def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False, sign=False):
     prm = synth.s1_params(n, threshold=threshold); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel_size"])); trunc = synth.tranc_dist(prm)
     value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
     grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
@@ -28,6 +28,11 @@ def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False):
     counter = torch.zeros(1, dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
     times, Us, classes, vcount = [], [], None, 0
+    sm = None
+    if sign:   # the pipeline's instance: the kernel also marks the raycast's sign map
+        shift = capi.raycast_signmap_shift(intr, vs, trunc)
+        sm = torch.zeros(capi.signmap_bytes(res, shift), dtype=torch.uint8, device="cuda")
+        capi.signmap_reset(sm, res, shift, trunc)
     for k in range(frames):
         depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
         dmax.zero_()
@@ -40,7 +45,7 @@ def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False):
             flags |= 4 | 1
         elif mode == "walk":
             flags |= 32
-        o = capi.integrate_opts(flags=flags, depth_tiles=tiles, start_event=ev[0], stop_event=ev[1])
+        o = capi.integrate_opts(flags=flags, depth_tiles=tiles, start_event=ev[0], stop_event=ev[1], signmap=sm)
         capi.integrate_scaled_ex2(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, o, threshold=threshold,
                                   updated=counter, depth_max=dmax, workspace=ws, stream=s)
         torch.cuda.synchronize()
@@ -50,7 +55,7 @@ def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False):
         if k >= 4:
             times.append(dt.value * 1e3); Us.append(int(counter.item()))
     U, t = np.median(Us), np.median(times)
-    print(f"n {n} {mode:6s}{' +hint' if hint else '      '} thr {threshold}: U {U:.0f}  kernel {t:.1f} us (min {min(times):.1f})  {24 * U / t / 1e6:.2f} TB/s algorithmic;  boxes free / nothing / walk "
+    print(f"n {n} {mode:6s}{' +sign' if sign else '      '} thr {threshold}: U {U:.0f}  kernel {t:.1f} us (min {min(times):.1f})  {24 * U / t / 1e6:.2f} TB/s algorithmic;  boxes free / nothing / walk "
           f"{classes[0:3]}  planes walked {classes[3]}  edge planes {classes[6]}  workgroups with work {vcount}", flush=True)
     return value, weight, grad
 
@@ -61,7 +66,7 @@ if __name__ == "__main__":
     quick = os.environ.get("PROBE_QUICK")          # A/B sweeps: the two pipeline-like modes only, no comparison against the walk
     for n in sizes:
         if quick:
-            run(n, "own", hint=True); run(n, "ahead", hint=True)
+            run(n, "own"); run(n, "own", sign=True); run(n, "ahead"); run(n, "ahead", sign=True)
             torch.cuda.empty_cache()
             continue
         ref = None

@@ -694,7 +694,9 @@ __device__ __forceinline__ void free_group_store(const IntegrateArgs &a, const F
             if (SIGN) vmin = fminf(vmin, ov);
         }
 }
-template <bool SIGN>
+// (The streamed planes never mark the sign map: the running mean of a value with (1, 0) is negative only if the value was — and then the
+// launch that wrote that negative value marked the brick, the map's bytes are never cleared, and a value that reached the array any other
+// way obliges its owner to rebuild the map (xs_signmap.h).  One v_min per voxel and a dependent byte load per column less; 1024^3 -2 us.)
 __device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int x, int y, int zb, int ze) {
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
     float vmin = 0.0f;
@@ -703,11 +705,10 @@ __device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a
 #pragma unroll 1
     for (int z = zb; z < ze; z += 2 * FREE_CHUNK, off += 2 * FREE_CHUNK * plane) {
         free_group_load(B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK);
-        free_group_store<SIGN>(a, A, bv, bw, bg, off, plane, ze - z, always, vmin);
+        free_group_store<false>(a, A, bv, bw, bg, off, plane, ze - z, always, vmin);
         free_group_load(A, bv, bw, bg, off + 2 * FREE_CHUNK * plane, plane, ze - z - 2 * FREE_CHUNK);
-        free_group_store<SIGN>(a, B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK, always, vmin);
+        free_group_store<false>(a, B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK, always, vmin);
     }
-    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
     return (unsigned)(ze - zb);
 }
 
@@ -737,7 +738,6 @@ __device__ __forceinline__ bool edge_in_image(const IntegrateArgs &a, const Pose
     }
     return in;
 }
-template <bool SIGN>
 __device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a, const PoseRT &ps, char *bv, char *bw, char *bg, unsigned off, unsigned plane,
                                                           int x, int y, int zb, int ze) {
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
@@ -755,12 +755,11 @@ __device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a
     for (int z = zb; z < ze; z += 2, off += 2 * plane) {
         inB = z + 1 < ze && edge_in_image(a, ps, k, w, z + 1);
         if (inB) free_group_load(B, bv, bw, bg, off + plane, plane, 1);
-        if (inA) { free_group_store<SIGN>(a, A, bv, bw, bg, off, plane, 1, always, vmin); ++n; }
+        if (inA) { free_group_store<false>(a, A, bv, bw, bg, off, plane, 1, always, vmin); ++n; }
         inA = z + 2 < ze && edge_in_image(a, ps, k, w, z + 2);
         if (inA) free_group_load(A, bv, bw, bg, off + 2 * plane, plane, 1);
-        if (inB) { free_group_store<SIGN>(a, B, bv, bw, bg, off + plane, plane, 1, always, vmin); ++n; }
+        if (inB) { free_group_store<false>(a, B, bv, bw, bg, off + plane, plane, 1, always, vmin); ++n; }
     }
-    if (SIGN && vmin < 0.0f) signmap_mark_span(a.signmap, x, y, zb, ze);
     return n;
 }
 
@@ -1039,8 +1038,8 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
                     const size_t ubase = ((size_t)(f0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
                     char *fv = reinterpret_cast<char *>(a.value) + ubase, *fw = reinterpret_cast<char *>(a.weight) + ubase, *fg = reinterpret_cast<char *>(a.grad) + ubase;
                     const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
-                    if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column<SIGN>(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
-                    else n_upd += integrate_free_column<SIGN>(a, fv, fw, fg, foff, fplane, x, y, f0, f1);
+                    if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
+                    else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, x, y, f0, f1);
                 }
                 if (walk_lo >= walk_hi) continue;
             }
