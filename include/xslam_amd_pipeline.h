@@ -119,6 +119,10 @@ void xs_kf_reset_stage_times(void *kf);
  * the last xs_kf_reset_stage_times, and their count — the period from one iteration's sums arriving to the next one's (kernel, completion
  * word, 6x6 solve, pose post).  ICP.cu:395-417 is a launch + device sync + copy per iteration.  Always on. */
 void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4);
+/* Host wall clock of a tracked frame's tail since the last xs_kf_reset_stage_times, microseconds summed over *frames frames: us4[0] the last ICP
+ * sums seen -> IntegrateFrame entered (6x6 solve, pose algebra), [1] entered -> the integrate launch call (transforms, cover test), [2] the
+ * launch call itself, [3] its return -> the raycast launch's return. */
+void xs_kf_tail_host_times(void *kf, double *us4, long long *frames);
 /* Test aids.  Start the ICP launch sequence numbers at v (exercises the 2^32 wrap of the mailbox numbers); make the determinant gate of
  * iteration n (0-based, over all levels) of the next alignment fail as for a singular system (KinectFusionReconstruction.cpp:203-210). */
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v);

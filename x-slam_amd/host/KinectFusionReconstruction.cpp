@@ -456,6 +456,7 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                 icp_level_us[slot] += std::chrono::duration<double, std::micro>(t_now - t_prev).count();
                 ++icp_level_calls[slot];
                 t_prev = t_now;
+                t_last_sums_ = t_now;
             }
             // The solve and the post come first: the enqueued launch is waiting for them.
             hostComplexICP sol[6];
@@ -801,6 +802,8 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     volume_res.y = volume_resolution.y();
     volume_res.z = volume_resolution.z();
     hipStream_t st = current_stream();
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto t_call = t_enter, t_back = t_enter;
     unsigned long long *counters = PrepareFrameCounters(st);
     // A posted integrate launch is waiting in the stream for this pose (EnqueuePostedIntegrate): if the pose's frustum lies inside the planes
     // that launch was given, post it — the launch is the frame's integrate call; else tell it to leave and take the plain path below.
@@ -875,6 +878,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
                     check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
             }
             o.flags = (split ? (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD) : 0u) | list_flag;
+            if (i == 0) t_call = std::chrono::steady_clock::now();
             check_rc(xs_integrate_scaled_ex2(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
                                              &kinect_intrinsic.fx, max_integration_weight, res, voxel_size, &device_Rv2c.data[0].x.re,
                                              &device_tv2c.x.re, tsdf_volume_d_ptr->getTsdfTruncDist(), value.ptr((int)off), weight.ptr((int)off),
@@ -882,7 +886,7 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
                                              depth_max_dev, integrate_ws_.ptr(), &o, st),
                      "integrateTsdfVolume");
             if (split) { integrate_header_clear_ = false; pending_fold_ = counters; }
-            if (i == 0) { o.start_event = nullptr; o.stop_event = nullptr; }   // (the event pair rides on the owned planes' launch only)
+            if (i == 0) { t_back = std::chrono::steady_clock::now(); o.start_event = nullptr; o.stop_event = nullptr; }   // (the event pair rides on the owned planes' launch only)
         }
     }
 
@@ -893,6 +897,12 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
     hits_counter_ = counters + 1;
     CalculatePointCloud(vmaps_g_prev_d[0], nmaps_g_prev_d[0]);
     hits_counter_ = nullptr;
+    if (frame_id > 0 && !use_gtPose && !integrated_by_post) {
+        const auto t_ray = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        tail_host_us[0] += us(t_last_sums_, t_enter); tail_host_us[1] += us(t_enter, t_call); tail_host_us[2] += us(t_call, t_back); tail_host_us[3] += us(t_back, t_ray);
+        ++tail_host_calls;
+    }
     stage_end(ST_RAYCAST);
     stage_begin(ST_RESIZE);
     ModelMapPyramid();

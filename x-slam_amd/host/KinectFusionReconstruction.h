@@ -310,6 +310,12 @@ public:
     // (kernel + completion word over PCIe + solve + post) — SURVEY 8(d): "ICP: report us per iteration".  Always on: two clock reads.
     double icp_level_us[4] = {0, 0, 0, 0};          // [3]: the frame's first iteration, which also waits for the stream to drain the previous frame's tail
     long long icp_level_calls[4] = {0, 0, 0, 0};
+    // host clock of the frame's tail (xs_kf_tail_host_times), microseconds summed since the last reset: [0] the last ICP sums seen ->
+    // IntegrateFrame entered (solve, pose algebra), [1] entered -> the integrate launch call (transforms, cover test), [2] that call itself
+    // (xs_integrate_scaled_ex2), [3] its return -> the raycast launch's return
+    double tail_host_us[4] = {0, 0, 0, 0};
+    long long tail_host_calls = 0;
+    std::chrono::steady_clock::time_point t_last_sums_{};
     // test aids: start the launch sequence numbers at `v` (the mailbox is told); make the determinant gate fail at iteration n of the
     // next PoseEstimate (-1: off)
     void DebugSetIcpSequence(unsigned long long v);

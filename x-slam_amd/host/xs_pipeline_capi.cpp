@@ -246,7 +246,13 @@ void xs_kf_reset_stage_times(void *kf) {
     if (k->profiling) k->collect_stage_times();
     k->cum_updated = 0; k->cum_hits = 0;
     for (int i = 0; i < KF::ST_COUNT; ++i) { k->stage_ms[i] = 0; k->stage_calls[i] = 0; }
-    for (int i = 0; i < 4; ++i) { k->icp_level_us[i] = 0; k->icp_level_calls[i] = 0; }
+    for (int i = 0; i < 4; ++i) { k->icp_level_us[i] = 0; k->icp_level_calls[i] = 0; k->tail_host_us[i] = 0; }
+    k->tail_host_calls = 0;
+}
+void xs_kf_tail_host_times(void *kf, double *us4, long long *frames) {
+    KF *k = (KF *)kf;
+    for (int i = 0; i < 4; ++i) if (us4) us4[i] = k->tail_host_us[i];
+    if (frames) *frames = k->tail_host_calls;
 }
 void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4) {
     KF *k = (KF *)kf;

@@ -52,6 +52,7 @@ _SIGS = {
     "xs_kf_stage_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_reset_stage_times": (None, [_vp]),
     "xs_kf_icp_iteration_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
+    "xs_kf_tail_host_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
     "xs_kf_debug_post_delay": (None, [_vp, C.c_int, C.c_int]),
@@ -277,6 +278,15 @@ class KinectFusion:
         calls = (C.c_longlong * 4)()
         _lib.xs_kf_icp_iteration_times(self.h, us.ctypes.data_as(_f64p), calls)
         return {lv: (float(us[lv]), int(calls[lv])) for lv in range(4)}
+
+    def tail_host_times(self):
+        """Mean host microseconds per frame of the tail's four host stretches since the last reset (xs_kf_tail_host_times)."""
+        us = np.zeros(4, np.float64)
+        n = C.c_longlong(0)
+        _lib.xs_kf_tail_host_times(self.h, us.ctypes.data_as(_f64p), C.byref(n))
+        k = max(int(n.value), 1)
+        return {"frames": int(n.value), "sums_seen_to_integrate_entered": round(float(us[0]) / k, 2), "entered_to_launch_call": round(float(us[1]) / k, 2),
+                "integrate_launch_call": round(float(us[2]) / k, 2), "launch_returned_to_raycast_launched": round(float(us[3]) / k, 2)}
 
     def debug_set_icp_sequence(self, v):
         _lib.xs_kf_debug_set_icp_sequence(self.h, int(v))
