@@ -263,6 +263,8 @@ private:
     DeviceArray<float> depth_max_next_;
     // the model-map pyramid inside the raycast launch (YAML raycast_builds_pyramid, default true; single GPU, three levels, sign map on)
     bool raycast_builds_pyramid = true;
+    int profile_integrate_every = 4;   // YAML profile_integrate_every: at profiling level 1 the integrate kernel's event pair rides on every n-th frame (IntegrateKernelTimedThisFrame)
+    bool IntegrateKernelTimedThisFrame() const;
     bool pyramid_in_raycast_ = false;   // this frame's raycast launch built levels 1 and 2: ModelMapPyramid has nothing to do
     bool PreparePyramidLevels();
     // shard mode, raycast composite by owner-compacted exchange (YAML shard_composite_gather, default true; false = the int32 sum of the maps)
