@@ -928,3 +928,70 @@ def test_classes_decided_ahead_are_checked_against_the_launch_pose(dev):
         assert int(cnt.item()) == U, hint
         for a, b in zip(ref, vol):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), hint
+
+
+@pytest.mark.parametrize("threshold", [0.0, 0.02])
+def test_boxes_on_the_frustums_side_stream_with_the_in_image_test_alone(dev, threshold):
+    """The EDGE class (round 5): a box whose pixel range leaves the image streams its free planes with the reference's in-image test
+    (TsdfFusion.cu:123-124) as the only per-voxel decision — a margin test on un-divided coordinates, the exact test within 1/32 px of the
+    border.  Twelve views rolled, pitched and yawed by up to 0.6 rad from inside and outside a 160^3 volume (the image border cuts boxes at
+    every angle, near the camera and far from it, all four borders), a flat wall far behind everything so that the frustum's sides run
+    through free space: volume and count against the per-voxel walk everywhere, bit for bit, classes decided with the launch's own pose
+    and decided ahead with the pose slack's pads — and the class counters show the path taken (thousands of planes) in every view."""
+    torch, capi = dev
+    n = 160
+    prm = synth.s1_params(n, threshold=threshold)
+    res = [n, n, n]
+    H, W = synth.HEIGHT, synth.WIDTH
+    rng = np.random.default_rng(0xED6E)
+    d = np.full((H, W), 4200, np.uint16)
+    d[200:280, 260:380] = 1500          # a nearer patch: a surface band inside the view too
+    depth = torch.from_numpy(d.astype(np.int16)).cuda()
+    scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    tiles = torch.zeros(capi.depth_tiles_bytes(H, W), dtype=torch.uint8, device="cuda")
+    capi.scale_depth_tiles(depth, W * 2, H, W, scaled, W * 4, dmax, tiles)
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    vs, trunc = prm["tsdf_voxel_size"], tranc_dist(prm)
+
+    def volume():
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        return v, w, g
+    seen_edge = 0
+    for trial in range(12):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = rng.uniform(0.05, 0.6)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        tv = np.array([3.84, 3.84, 1.0]) + rng.uniform(-1.5, 1.5, 3) * (1.0, 1.0, 0.8)    # camera in the volume frame (7.68 m cube), looking roughly +z
+        v2c = np.eye(4); v2c[:3, :3] = Rm.T; v2c[:3, 3] = -Rm.T @ tv
+        R = np.zeros((3, 3, 2), np.float32); R[..., 0] = v2c[:3, :3]; R[..., 1] = rng.normal(size=(3, 3)) * 1e-7
+        t = np.zeros((3, 2), np.float32); t[:, 0] = v2c[:3, 3]; t[:, 1] = rng.normal(size=3) * 1e-7
+        common = lambda vol: (scaled, W * 4, H, W, intr_of(prm), 100, res, vs, R, t, trunc, vol[0], vol[1], vol[2], n * 4)
+        ref = volume()
+        for rep in range(2):    # two frames: the second updates written voxels (running mean of state that is not zero)
+            cnt.zero_()
+            capi.integrate_scaled_ex2(*common(ref), capi.integrate_opts(flags=32), threshold=threshold, updated=cnt, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        U = int(cnt.item())
+        assert U > 50000, (trial, U)
+        for ahead in (False, True):
+            vol = volume()
+            for rep in range(2):
+                cnt.zero_()
+                flags = 64
+                if ahead:
+                    capi.integrate_classify_ex(H, W, intr_of(prm), res, vs, R, t, trunc, ws, capi.integrate_opts(flags=64, depth_tiles=tiles), slack_scale=2.0, depth_max=dmax)
+                    flags |= 4 | 1
+                capi.integrate_scaled_ex2(*common(vol), capi.integrate_opts(flags=flags, depth_tiles=tiles), threshold=threshold, updated=cnt, depth_max=dmax, workspace=ws)
+            torch.cuda.synchronize()
+            head = ws[192:220].view(torch.int32).cpu().numpy()
+            assert int(cnt.item()) == U, (trial, ahead, int(cnt.item()), U)
+            for a, b in zip(ref, vol):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (trial, ahead)
+            seen_edge += int(head[6])
+            assert int(head[6]) > 500, (trial, ahead, head[:7])     # planes streamed with the in-image test
+    assert seen_edge > 50000
