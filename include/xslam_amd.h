@@ -102,9 +102,6 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
 #define XS_INTEGRATE_COUNT_CLASSES 64u   /* the kernel counts the wave-sized boxes it classified: 32-bit words 48 / 49 / 50 of the workspace = free / nothing to write / exact walk (cleared with the header; tests and bench figures) */
 #define XS_INTEGRATE_RECLASSIFY_BOXES 128u /* with XS_INTEGRATE_LIST_IS_READY: the brick list holds for this pose but the box classes xs_integrate_classify left do not (xs_integrate_list_covers returned 1, not 3): classify the boxes again, with this pose */
 #define XS_INTEGRATE_LIST_IS_READY 4u   /* xs_integrate_classify has produced the brick list on this stream (see there) */
-#define XS_INTEGRATE_CLASSIFY_BRICKS_ONLY 256u /* xs_integrate_classify_ex: list the bricks and stop (a rough pose + a wide slack_scale, early); the boxes' classes follow from a ... */
-#define XS_INTEGRATE_CLASSIFY_BOXES_ONLY 512u  /* ... xs_integrate_classify_ex call with this flag: the classes (and the list's order) for the list that is there, with THIS call's pose and
-                                                * slack_scale; with XS_INTEGRATE_HEADER_IS_CLEAR the header was cleared before the bricks-only call and nothing classified boxes since */
 int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                            const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,
                            int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,

@@ -1296,7 +1296,7 @@ extern "C" int xs_integrate_classify_ex(int rows, int cols, const float *intr4, 
     for (int p = 0; p < 6; ++p) a.fr.slack[p] *= slack_scale;
     bind_workspace(a, res, z1 - z0, workspace);
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & (XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_CLASSIFY_BOXES_ONLY))) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
+    if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
     // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
     // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
     static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");
@@ -1305,27 +1305,6 @@ extern "C" int xs_integrate_classify_ex(int rows, int cols, const float *intr4, 
     const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
     const bool boxes = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32 && depth_tiles;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
-    // The two halves on their own (round 5).  The brick list needs a pose that is only roughly the final one (its slack is cheap: a superset of
-    // bricks), the boxes' classes a near one (their pads cost walked planes): XS_INTEGRATE_CLASSIFY_BRICKS_ONLY lists the bricks and stops —
-    // a caller runs it at the frame's start for the previous frame's pose with a wide slack — and XS_INTEGRATE_CLASSIFY_BOXES_ONLY decides
-    // the classes of the list that is there (written by such a call on a stream this one is ordered behind) for THIS call's pose and
-    // slack: behind the last ICP launch only the second kernel is left on the chain in front of the integrate launch.
-    if (flags & XS_INTEGRATE_CLASSIFY_BRICKS_ONLY) {
-        const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-        if (opts->stop_event) hipExtLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, nullptr, (hipEvent_t)opts->stop_event, 0, a);
-        else hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
-        XS_CHECK(hipGetLastError());
-        return 0;
-    }
-    if (flags & XS_INTEGRATE_CLASSIFY_BOXES_ONLY) {
-        if (!boxes) return 0;   // (no tile table: the integrate call decides the boxes itself)
-        if (launch_box_classes(a, res, z1 - z0, workspace, depth_tiles, box_slack(a, slack_scale), st, (flags & XS_INTEGRATE_HEADER_IS_CLEAR) != 0, (hipEvent_t)opts->stop_event)) {
-            g_classes_ahead.workspace = workspace; g_classes_ahead.slack_scale = slack_scale;
-            memcpy(g_classes_ahead.R18, Rv2c18, sizeof(g_classes_ahead.R18)); memcpy(g_classes_ahead.t6, tv2c6, sizeof(g_classes_ahead.t6));
-        }
-        XS_CHECK(hipGetLastError());
-        return 0;
-    }
     // (the caller's completion event — xs_integrate_set_classify_event — rides on the dispatch)
     if (launch_classification(a, res, z1 - z0, workspace, boxes ? depth_tiles : nullptr, box_slack(a, slack_scale), st, (hipEvent_t)opts->stop_event)) {
         g_classes_ahead.workspace = workspace; g_classes_ahead.slack_scale = slack_scale;

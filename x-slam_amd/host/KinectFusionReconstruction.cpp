@@ -21,7 +21,6 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipEventCreateWithFlags(&integrate_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&scale_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&classify_done_, hipEventDisableTiming));
-    hipSafeCall(hipEventCreateWithFlags(&bricks_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&tail_done_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&surface_done_next_, hipEventDisableTiming));
     hipSafeCall(hipEventCreateWithFlags(&scale_done_next_, hipEventDisableTiming));
@@ -45,7 +44,6 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (scale_done_next_) (void)hipEventDestroy(scale_done_next_);
     if (scale_done_) (void)hipEventDestroy(scale_done_);
     if (classify_done_) (void)hipEventDestroy(classify_done_);
-    if (bricks_done_) (void)hipEventDestroy(bricks_done_);
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (gather_counts_host_) (void)hipHostFree(gather_counts_host_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
@@ -128,8 +126,6 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     integrate_classify_beside_icp = config.as<bool>("integrate_classify_beside_icp", false);
     integrate_classify_early = std::max(0, config.as<int>("integrate_classify_early", 0));
     integrate_classify_predicted = config.as<bool>("integrate_classify_predicted", false);
-    integrate_list_early = config.as<bool>("integrate_list_early", true);
-    integrate_list_slack = std::max(1.0f, config.as<float>("integrate_list_slack", 8.0f));
     integrate_classify_slack = std::max(1.0f, config.as<float>("integrate_classify_slack", 2.0f));
     integrate_post_pose = config.as<bool>("integrate_post_pose", false);
     integrate_post_early = config.as<bool>("integrate_post_early", false);
@@ -669,12 +665,10 @@ void KinectFusionReconstruction::ClassifyAhead(const Matrix3frm &Rcurr, const Ve
     // integrate_classify_beside_icp (off by default: measured, no gain — see the header): on the auxiliary stream instead; everything the two
     // classification kernels read — the scaled depth's maximum, the tile table, the cleared header — was written on that stream.  The integrate
     // launch then waits for their completion event.
-    const bool beside = integrate_classify_beside_icp && aux_stream_ && integrate_header_clear_ && !early_list_ready_;
+    const bool beside = integrate_classify_beside_icp && aux_stream_ && integrate_header_clear_;
     hipStream_t st = beside ? aux_stream_ : current_stream();
     // the scaled depth's maximum and the cleared header come from the auxiliary stream
     if (!beside && scale_recorded_ && hipEventQuery(scale_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, scale_done_, 0));
-    // (... and so does the early brick list: long done — its event rides on its own dispatch, a wait packet only if it is not)
-    if (early_list_ready_ && hipEventQuery(bricks_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, bricks_done_, 0));
     EnqueueClassification(st, beside);
     EnqueuePostedIntegrate();
 }
@@ -685,11 +679,6 @@ void KinectFusionReconstruction::EnqueueClassification(hipStream_t st, bool with
     xs_integrate_opts o = {};
     o.struct_bytes = sizeof(o);
     o.flags = integrate_header_clear_ ? XS_INTEGRATE_HEADER_IS_CLEAR : 0u;
-    // the brick list is there already (ListBricksEarly): only the boxes' classes and the list's order, for this pose
-    list_from_early_ = early_list_ready_ && depth_tiles_.ptr() != nullptr;
-    if (list_from_early_) o.flags = XS_INTEGRATE_CLASSIFY_BOXES_ONLY | XS_INTEGRATE_HEADER_IS_CLEAR;
-    else if (early_list_ready_) return;   // (no tile table: the early list alone; IntegrateFrame takes it)
-    early_list_ready_ = false;
     o.depth_tiles = depth_tiles_.ptr();   // the boxes' classes are decided here too, with the slack's pads (the integrate call checks its pose against them)
     o.stop_event = with_event ? classify_done_ : nullptr;
     check_rc(xs_integrate_classify_ex(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_, list_tv2c_,
@@ -707,23 +696,6 @@ void KinectFusionReconstruction::EnqueueClassification(hipStream_t st, bool with
 // the frames are covered at slack 2 and 72 % at slack 6, where the wider pads cost the integrate kernel 4 us; the others classify after
 // the final pose, i.e. later than ClassifyAhead would have: no gain (profiles/r04_ab_classify_predicted.txt).  Same volume bit for bit
 // either way (tested).
-void KinectFusionReconstruction::ListBricksEarly() {
-    early_list_ready_ = false; list_from_early_ = false;
-    if (!integrate_list_early || !integrate_classify_ahead || integrate_classify_predicted || integrate_post_pose || !integrate_split() || !integrate_header_clear_ ||
-        !aux_stream_ || world2camera_record.empty() || use_gtPose || frame_id == 0 || !icp_post_pose || !icp_mailbox_ || !icp_mailbox_in_device_ || icp_solve_on_device)
-        return;
-    SetListPose(inverse(world2camera_record.back()));   // the previous frame's pose
-    std::memcpy(early_Rv2c_, list_Rv2c_, sizeof(early_Rv2c_)); std::memcpy(early_tv2c_, list_tv2c_, sizeof(early_tv2c_));
-    const int res[3] = {volume_resolution.x(), volume_resolution.y(), volume_resolution.z()};
-    xs_integrate_opts o = {};
-    o.struct_bytes = sizeof(o);
-    o.flags = XS_INTEGRATE_CLASSIFY_BRICKS_ONLY | XS_INTEGRATE_HEADER_IS_CLEAR;
-    o.stop_event = bricks_done_;
-    check_rc(xs_integrate_classify_ex(depth_height, depth_width, &kinect_intrinsic.fx, res, voxel_size, early_Rv2c_, early_tv2c_,
-                                      tsdf_volume_d_ptr->getTsdfTruncDist(), zo0, zo1, depth_max_.ptr(), integrate_ws_.ptr(), integrate_list_slack, &o, aux_stream_),
-             "integrate brick list");
-    early_list_ready_ = true;
-}
 void KinectFusionReconstruction::ClassifyPredicted() {
     list_predicted_ = false;
     if (!integrate_classify_predicted || !integrate_classify_ahead || integrate_post_pose || !integrate_split() || !integrate_header_clear_ ||
@@ -903,26 +875,11 @@ int KinectFusionReconstruction::IntegrateFrame(const DeviceArray2D<ushort> &dept
             // header cleared and count folded on the auxiliary stream (SurfaceMeasure) when there is one call per frame
             const bool split = integrate_split() && integrate_header_clear_ && i == 0;
             unsigned list_flag = 0;
-            if (i == 0 && early_list_ready_ && !list_ready_) {   // an early brick list nobody classified boxes for (no ICP loop reached ClassifyAhead): the list, if it holds
-                early_list_ready_ = false;
-                if (hipEventQuery(bricks_done_) != hipSuccess) hipSafeCall(hipStreamWaitEvent(st, bricks_done_, 0));
-                if (xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, early_Rv2c_, early_tv2c_,
-                                             integrate_list_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re) & 1)
-                    list_flag = XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR;
-                else
-                    check_rc(xs_integrate_workspace_clear(integrate_ws_.ptr(), st), "integrate workspace");
-            }
             if (i == 0 && list_ready_) {
                 list_ready_ = false; list_predicted_ = false;
                 WaitForClassification(st);
-                int covers = xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_,
-                                                      list_tv2c_, integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re);
-                if (list_from_early_) {   // the LIST is the early one: its own pose and slack decide whether it holds; the classes' bit stays ClassifyAhead's
-                    list_from_early_ = false;
-                    const int early = xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, early_Rv2c_,
-                                                               early_tv2c_, integrate_list_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re);
-                    covers = (early & 1) ? (1 | (covers & 2)) : 0;
-                }
+                const int covers = xs_integrate_list_covers(depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx, res, voxel_size, list_Rv2c_,
+                                                            list_tv2c_, integrate_classify_slack, &device_Rv2c.data[0].x.re, &device_tv2c.x.re);
                 ++list_cover_counts_[covers & 3];
                 if (covers)   // (bit 1 clear: the list holds but the boxes' classes were padded for a nearer pose — they are decided again, the list stays)
                     list_flag = XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR | ((covers & 2) ? 0u : XS_INTEGRATE_RECLASSIFY_BOXES);
@@ -1163,7 +1120,6 @@ void KinectFusionReconstruction::SurfaceMeasure(const DeviceArray2D<ushort> &dep
     }
     list_ready_ = false;
     ClassifyPredicted();
-    ListBricksEarly();
     current_stream() = main_stream;
     // the main stream picks the maps up — without a wait packet when they are already there (the usual case once the
     // previous frame's tail is the longer of the two)

@@ -327,18 +327,6 @@ public:
 private:
     void AbandonClassifiedList();
     void WaitForClassification(hipStream_t st);
-    // The brick list at the frame's start (YAML integrate_list_early, default true; integrate_list_slack, default 8): k_classify_bricks for the
-    // PREVIOUS frame's pose with a wide frustum slack, on the auxiliary stream right behind the depth scaling — under the first, small ICP
-    // launches — so that behind the last ICP launch only the boxes' classes (for the near-final pose, slack integrate_classify_slack) are
-    // left in front of the integrate launch: 4.8 us off the tail's chain now that the host's launch call no longer is what the chain waits
-    // for (profiles/r05_ab_list_early.txt).  IntegrateFrame checks the final pose against this list's pose and slack.
-    bool integrate_list_early = true;
-    float integrate_list_slack = 8.0f;
-    bool early_list_ready_ = false;            // this frame's early brick list is in the workspace (aux stream; bricks_done_ rides on its dispatch)
-    bool list_from_early_ = false;             // list_ready_: the list is the early one (pose early_Rv2c_ / early_tv2c_), the classes ClassifyAhead's
-    float early_Rv2c_[18] = {}, early_tv2c_[6] = {};
-    hipEvent_t bricks_done_ = nullptr;
-    void ListBricksEarly();
     hipEvent_t classify_done_ = nullptr;       // completion of ClassifyAhead's launches on the auxiliary stream (rides on the last dispatch)
     bool classify_recorded_ = false;
     hipStream_t aux_stream_ = nullptr;         // surface measure of frame k+1 runs here, under raycast / pyramid of frame k
