@@ -482,14 +482,17 @@ def test_full_size_properties_512(dev):
 
 # ---- round 4: depth tiles and the brick classification (free space / nothing to write / exact walk) ----------------------------
 def tiles_numpy(scaled, tw=8, th=8):
-    """{lo, hi} per tw x th pixels of a scaled depth image, invalid pixels counting as 0 (csrc/xs_tsdf.hip, k_scale_depth)."""
+    """{lo, hi} per tw x th pixels of a scaled depth image over its VALID pixels, lo negated where the tile holds an invalid one (depth 0),
+    {-inf, 0} where it holds no valid one (csrc/xs_tsdf.hip, k_scale_depth)."""
     h, w = scaled.shape
     ty, tx = -(-h // th), -(-w // tw)
     out = np.zeros((ty, tx, 2), np.float32)
     for j in range(ty):
         for i in range(tx):
             blk = scaled[j * th:(j + 1) * th, i * tw:(i + 1) * tw]
-            out[j, i] = (blk.min(), blk.max())
+            valid = blk[blk > 0]
+            lo = np.float32(valid.min()) if valid.size else np.float32(np.inf)
+            out[j, i] = (-lo if valid.size < blk.size else lo, blk.max())
     return out
 
 
@@ -526,6 +529,7 @@ def test_depth_tile_table(dev, oracle, shape):
 
 
 def class_counts(ws):
+    """boxes wholly free / wholly empty / with planes to walk (the workspace header's first three class counters)"""
     return [int(x) for x in ws[192:204].view(__import__("torch").int32).cpu().numpy()]
 
 
@@ -995,3 +999,68 @@ def test_boxes_on_the_frustums_side_stream_with_the_in_image_test_alone(dev, thr
             seen_edge += int(head[6])
             assert int(head[6]) > 500, (trial, ahead, head[:7])     # planes streamed with the in-image test
     assert seen_edge > 50000
+
+
+@pytest.mark.parametrize("threshold", [0.0, 0.02])
+def test_boxes_that_see_invalid_pixels_stream_with_a_validity_test(dev, threshold):
+    """The SPECKLE class (round 5): a box whose pixel range holds an invalid pixel (a hole, an out-of-range patch, a speckle) among valid ones
+    that all lie far behind it streams its free planes, each voxel gated by the validity of its OWN nearest pixel (found from a
+    reciprocal-based projection; the exact projection within 1 / 2048 px of a pixel boundary) and — on the frustum's side — by the in-image
+    test.  A noisy wall with 40 holes / out-of-range patches and 0.5 % speckle seen from six rolled / pitched / yawed poses, two frames
+    each, nearest-pixel and bilinear depth: volume and count against the per-voxel walk everywhere, bit for bit; the class counters show
+    the path taken, and that few boxes are left to walk where round 4 walked nearly all of them."""
+    torch, capi = dev
+    n = 160
+    prm = synth.s1_params(n, threshold=threshold)
+    res = [n, n, n]
+    H, W = synth.HEIGHT, synth.WIDTH
+    rng = np.random.default_rng(0x5BEC)
+    base = np.full((H, W), 4200.0) + 2.0 * (rng.random((H, W)) * 2 - 1)
+    d = synth.holed(np.clip(np.rint(base), 0, 65535).astype(np.uint16), rng, n_holes=40, speckle=0.005)
+    depth = torch.from_numpy(d.astype(np.int16)).cuda()
+    scaled = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    tiles = torch.zeros(capi.depth_tiles_bytes(H, W), dtype=torch.uint8, device="cuda")
+    capi.scale_depth_tiles(depth, W * 2, H, W, scaled, W * 4, dmax, tiles)
+    ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    vs, trunc = prm["tsdf_voxel_size"], tranc_dist(prm)
+
+    def volume():
+        v = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); w = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
+        g = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
+        capi.init_volume(v, w, g, n * 4, res)
+        return v, w, g
+    for trial in range(6):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = rng.uniform(0.02, 0.5)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        tv = np.array([3.84, 3.84, 1.2]) + rng.uniform(-1.0, 1.0, 3) * (1.0, 1.0, 0.8)
+        v2c = np.eye(4); v2c[:3, :3] = Rm.T; v2c[:3, 3] = -Rm.T @ tv
+        R = np.zeros((3, 3, 2), np.float32); R[..., 0] = v2c[:3, :3]; R[..., 1] = rng.normal(size=(3, 3)) * 1e-7
+        t = np.zeros((3, 2), np.float32); t[:, 0] = v2c[:3, 3]; t[:, 1] = rng.normal(size=3) * 1e-7
+        common = lambda vol: (scaled, W * 4, H, W, intr_of(prm), 100, res, vs, R, t, trunc, vol[0], vol[1], vol[2], n * 4)
+        ref = volume()
+        for rep in range(2):
+            cnt.zero_()
+            capi.integrate_scaled_ex2(*common(ref), capi.integrate_opts(flags=32), threshold=threshold, updated=cnt, depth_max=dmax, workspace=ws)
+        torch.cuda.synchronize()
+        U = int(cnt.item())
+        assert U > 50000, (trial, U)
+        for ahead in (False, True):
+            vol = volume()
+            for rep in range(2):
+                cnt.zero_()
+                flags = 64
+                if ahead:
+                    capi.integrate_classify_ex(H, W, intr_of(prm), res, vs, R, t, trunc, ws, capi.integrate_opts(flags=64, depth_tiles=tiles), slack_scale=2.0, depth_max=dmax)
+                    flags |= 4 | 1
+                capi.integrate_scaled_ex2(*common(vol), capi.integrate_opts(flags=flags, depth_tiles=tiles), threshold=threshold, updated=cnt, depth_max=dmax, workspace=ws)
+            torch.cuda.synchronize()
+            head = ws[192:224].view(torch.int32).cpu().numpy()
+            assert int(cnt.item()) == U, (trial, ahead, int(cnt.item()), U)
+            for a, b in zip(ref, vol):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (trial, ahead)
+            boxes = int(head[0]) + int(head[1]) + int(head[2])
+            assert int(head[7]) > 2000 and int(head[2]) < 0.35 * boxes, (trial, ahead, head[:8])

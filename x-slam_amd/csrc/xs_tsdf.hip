@@ -68,12 +68,15 @@ extern "C" int xs_init_volume(float *value, int *weight, float *grad, size_t ste
 
 // ------------------------------------------------------------------------------------------
 // scaleDepthKernal (TsdfFusion.cu:68-82) + what the integrate kernel wants to know about the frame: its largest valid depth and the
-// smallest and the largest scaled depth per DEPTH_TILE x DEPTH_TILE pixel tile and per 64 x 32 pixel block of tiles ("super tile": what
-// one workgroup covers) — an invalid pixel counts as 0 in both: a tile with a hole has min 0.  A wave takes a strip of 64 pixels x
+// smallest and the largest VALID scaled depth per DEPTH_TILE x DEPTH_TILE pixel tile and per 64 x 32 pixel block of tiles ("super tile":
+// what one workgroup covers): {lo, hi}, lo NEGATED where the tile holds an invalid pixel (depth 0) — a tile with a hole or a speckle still
+// says how near its valid pixels come (round 5: boxes that see such tiles stream their free planes with a validity test instead of walking
+// them); a tile without a valid pixel is {-inf, 0}.  A wave takes a strip of 64 pixels x
 // DEPTH_TILE rows — every row a coalesced 128-byte read and 256-byte write — lane l carries its column's min / max down the rows, three
 // cross-lane steps fold the eight columns of a tile, three more the eight tiles of the strip, and LDS the workgroup's four strips.
 enum { DEPTH_TILE = 8, SUPER_W = 64, SUPER_H = 4 * DEPTH_TILE };
-struct DepthTile { float lo, hi; };   // over the tile's pixels that lie in the image
+struct DepthTile { float lo, hi; };   // over the tile's VALID pixels that lie in the image; lo < 0: |lo| is that minimum and the tile also holds an invalid pixel
+__host__ __device__ __forceinline__ float depth_tile_encode(float lo_valid, bool has_invalid) { return has_invalid ? -lo_valid : lo_valid; }
 struct DepthTiles {                   // view of the table: tiles [ty][tx], then super tiles [sy][sx]
     const DepthTile *tiles, *supers; int tiles_x, tiles_y, supers_x, supers_y;
 };
@@ -99,28 +102,32 @@ __global__ void __launch_bounds__(256) k_scale_depth(const Src *depth, size_t ds
                                                      unsigned *max_bits, DepthTile *tiles, int tiles_x, int tiles_y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, ty = blockIdx.y * 4 + wave;
-    float lo = __builtin_inff(), hi = 0.f;
+    float lo = __builtin_inff(), hi = 0.f;   // over the valid pixels
+    int inv = 0;                             // an invalid pixel seen
 #pragma unroll
     for (int r = 0; r < DEPTH_TILE; ++r) {
         const int y = ty * DEPTH_TILE + r;
         if (x < cols && y < rows) {
             const float v = scaled_depth_of<Src>(row_ptr(depth, dstep, y)[x]);
             if (scaled) row_ptr(scaled, sstep, y)[x] = v;
-            lo = fminf(lo, v); hi = fmaxf(hi, v);
+            if (v > 0.f) lo = fminf(lo, v); else inv = 1;
+            hi = fmaxf(hi, v);
         }
     }
     __shared__ float s_lo[4], s_hi[4];
+    __shared__ int s_inv[4];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); inv |= __shfl_xor(inv, off, 64);
         if (off == DEPTH_TILE / 2 && tiles && (lane & (DEPTH_TILE - 1)) == 0 && x < cols && ty < tiles_y)
-            tiles[ty * tiles_x + (x / DEPTH_TILE)] = DepthTile{lo, hi};
+            tiles[ty * tiles_x + (x / DEPTH_TILE)] = DepthTile{depth_tile_encode(lo, inv != 0), hi};
     }
-    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_inv[wave] = inv; }
     __syncthreads();
     if (threadIdx.x == 0) {
         lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])); hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
-        if (tiles) tiles[(size_t)tiles_x * tiles_y + blockIdx.y * gridDim.x + blockIdx.x] = DepthTile{lo, hi};
+        inv = s_inv[0] | s_inv[1] | s_inv[2] | s_inv[3];
+        if (tiles) tiles[(size_t)tiles_x * tiles_y + blockIdx.y * gridDim.x + blockIdx.x] = DepthTile{depth_tile_encode(lo, inv != 0), hi};
         const unsigned b = __float_as_uint(hi);  // non-negative floats order like their bit patterns
         if (max_bits && b) atomicMax(max_bits, b);
     }
@@ -220,8 +227,8 @@ struct IntegrateArgs {
     size_t probe_offset;          // XS_EXPERIMENTS + XS_WG_TIMES only: bytes from box_class to the record area
 };
 // KF_ALWAYS_STORE: write every updated voxel's three words even where the bits do not change (measurement aid)
-// KF_COUNT_CLASSES: the classification counts its boxes in the workspace header, words CLASS_COUNT_WORD + 0..3 and + 6: boxes wholly free /
-//                   wholly empty / with planes to walk, planes walked, planes streamed with the in-image test (EDGE boxes)
+// KF_COUNT_CLASSES: the classification counts its boxes in the workspace header, words CLASS_COUNT_WORD + 0..3, + 6, + 7: boxes wholly free /
+//                   wholly empty / with planes to walk, planes walked, planes streamed with the in-image test (EDGE), with the validity test (SPECKLE)
 // KF_FAR_FIRST:     the list is taken from its end (see k_integrate_bricks)
 enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };
 enum { CLASS_COUNT_WORD = 48 };
@@ -582,10 +589,16 @@ template <bool MAX> __device__ __forceinline__ float fold64(float v) {  // over 
 // profiles/r05_box_classes_emulated.txt); with the pose slack's pads on the pixel range (classes decided ahead of the final pose) a 32-voxel
 // box at 1024^3 is on an edge more often than not.  An EDGE box needs c >= EDGE_CMIN over its corners: the test's shortcut is derived
 // for voxels that are not at the camera (integrate_edge_column).
-enum : unsigned { BOX_EDGE_BIT = 1u << 17 };
+// SPECKLE (round 5): the box sees an INVALID pixel (a hole, a speckle: depth 0) among valid ones that all lie far behind it.  Its "free" planes
+// are free WHERE THE VOXEL'S OWN PIXEL IS VALID: such a voxel is written with tsdf = (1, 0) (whether the reference takes the nearest
+// pixel or interpolates — it interpolates only where all four neighbours are valid, and the result lies between them), a voxel whose
+// nearest pixel is invalid is not written (Dp = 0: TsdfFusion.cu:128-150).  What is left of the per-voxel work is finding that pixel
+// and one depth gather (integrate_valid_column); with 0.2 % of a frame's pixels invalid nearly every box sees one, and before this they
+// all walked (bench.py roofline_s2.noisy).
+enum : unsigned { BOX_EDGE_BIT = 1u << 17, BOX_SPECKLE_BIT = 1u << 18 };
 #define XS_EDGE_CMIN 0.05f
-__device__ __forceinline__ unsigned box_word(int n_free, int n_empty, int falls, bool edge = false) {
-    return (unsigned)n_free | ((unsigned)n_empty << 8) | ((unsigned)falls << 16) | (edge ? (unsigned)BOX_EDGE_BIT : 0u);
+__device__ __forceinline__ unsigned box_word(int n_free, int n_empty, int falls, bool edge = false, bool speckle = false) {
+    return (unsigned)n_free | ((unsigned)n_empty << 8) | ((unsigned)falls << 16) | (edge ? (unsigned)BOX_EDGE_BIT : 0u) | (speckle ? (unsigned)BOX_SPECKLE_BIT : 0u);
 }
 __device__ __forceinline__ float dpp_fold4min(float v) { v = fminf(v, dpp_xor1(v)); return fminf(v, dpp_xor2(v)); }
 __device__ __forceinline__ float dpp_fold4max(float v) { v = fmaxf(v, dpp_xor1(v)); return fmaxf(v, dpp_xor2(v)); }
@@ -627,20 +640,25 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
     }
     // (four rows of the range per trip, requested together — a row index past the range repeats its last row, which changes neither bound:
     // a box of the benchmark scene sees 3 x 7 tiles with the slack's pads, i.e. one trip of one round of loads where row by row took three)
-    float lo = __builtin_inff(), hi = 0.f;
+    float lo = __builtin_inff(), hi = 0.f, neg = 0.f;   // lo: over the valid pixels; neg < 0: a tile of the range holds an invalid one
     for (int ty = ty0; ty <= ty1; ty += 4) {
         const int r0 = ty * pitch, r1 = min(ty + 1, ty1) * pitch, r2 = min(ty + 2, ty1) * pitch, r3 = min(ty + 3, ty1) * pitch;
         for (int tx = tx0 + corner; tx <= tx1; tx += 8) {
             const DepthTile t0 = table[r0 + tx], t1 = table[r1 + tx], t2 = table[r2 + tx], t3 = table[r3 + tx];
-            lo = fminf(lo, fminf(fminf(t0.lo, t1.lo), fminf(t2.lo, t3.lo)));
+            lo = fminf(lo, fminf(fminf(fabsf(t0.lo), fabsf(t1.lo)), fminf(fabsf(t2.lo), fabsf(t3.lo))));
+            neg = fminf(neg, fminf(fminf(t0.lo, t1.lo), fminf(t2.lo, t3.lo)));
             hi = fmaxf(hi, fmaxf(fmaxf(t0.hi, t1.hi), fmaxf(t2.hi, t3.hi)));
         }
     }
     lo = fold8<false>(lo); hi = fold8<true>(hi);
+    const bool speckle = fold8<false>(neg) < 0.f;             // the box can see an invalid pixel
     const float band = (a.tranc_dist * 1.001f + 1e-5f) + 2e-4f;   // the walk's own band (update_voxel) + margin
     if (cmin - hi > band) return all_empty;                 // behind everything the box can see (hi = 0: nothing valid there)
-    const bool may_stream = inside || cmin >= XS_EDGE_CMIN;   // (cmin carries the pose slack: it bounds every covered pose's c)
-    if (may_stream && lo - cmax > band) return box_word(nz, 0, 0, !inside);   // in front of everything it can see (lo = 0 where a pixel is invalid)
+    // plain free space needs the whole range in the image and valid; else the free planes are streamed with the tests that are left
+    // (BOX_EDGE_BIT / BOX_SPECKLE_BIT), which are derived for voxels that are not at the camera
+    const bool tested = !inside || speckle;
+    const bool may_stream = !tested || cmin >= XS_EDGE_CMIN;   // (cmin carries the pose slack: it bounds every covered pose's c)
+    if (may_stream && lo - cmax > band) return box_word(nz, 0, 0, !inside, speckle);   // in front of everything valid it can see
     if (nz > 8) return all_walk;                            // (more planes per brick than lanes per box: a tuning configuration)
     // Plane by plane.  The four corners of the box's first plane are lanes 0 - 3 (corner bit 2 clear), of its last plane lanes 4 - 7; c moves
     // by dzc per plane at every (x, y).  Lane j takes plane j with the c range of the first plane's corners shifted j planes along.
@@ -663,7 +681,7 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
         n_empty = __builtin_ctz(~em | 0x100u);
     }
     n_free = min(n_free, nz); n_empty = min(n_empty, nz - n_free);
-    return box_word(n_free, n_empty, falls, !inside && n_free > 0);
+    return box_word(n_free, n_empty, falls, !inside && n_free > 0, speckle && n_free > 0);
 }
 // FREE box: voxels (x, y, zb .. ze - 1) of this lane's column (which lies in the volume).  A rolling pipeline over groups of FREE_CHUNK
 // planes: the next group's state is requested before the current group is updated and stored, so the wave always has reads in flight
@@ -759,6 +777,76 @@ __device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a
         inA = z + 2 < ze && edge_in_image(a, ps, k, w, z + 2);
         if (inA) free_group_load(A, bv, bw, bg, off + 2 * plane, plane, 1);
         if (inB) { free_group_store<false>(a, B, bv, bw, bg, off + plane, plane, 1, always, vmin); ++n; }
+    }
+    return n;
+}
+
+
+// SPECKLE box (and EDGE + SPECKLE): a voxel of a free plane is written iff it is in the image AND its nearest pixel is valid (BOX_SPECKLE_BIT).
+// The exact path finds that pixel from image_x = Re(px * (1 / v_c.z)) + cx, near_x = rn(image_x).  Here u = pxr * rcp(c) + cx from the same
+// real parts (edge_in_image has the argument): the two differ by < 2.5e-4 px — the exact one carries five roundings of magnitudes <= 640
+// (1.4e-4), this one v_rcp_f32's ulp, a product and a sum (1.0e-4) — so wherever u lies further than XS_NEAR_MARGIN = 1 / 2048 px from a
+// half-integer both round to the same pixel, and the ~0.2 % of voxels that lie nearer (one plane of a wave in eight) take the exact
+// voxel_pixel, wave-uniformly skipped where no lane needs it.  The in-image test is edge_in_image's (skipped for a box whose range is
+// inside the image: need_image false).  One 4-byte depth gather per voxel; the state loads go out with it, a plane ahead of the stores.
+#define XS_NEAR_MARGIN 0.00048828125f
+struct ValidSlot { float v, g, d; int w; bool in; };
+template <class Depth>
+__device__ __forceinline__ void valid_slot_request(ValidSlot &s, const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, const EdgeWindow &win, bool need_image,
+                                                   const Depth &dimg, const char *bv, const char *bw, const char *bg, unsigned off, int z, bool live) {
+    s.in = false;
+    if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    const float vgz = (z + 0.5f) * a.voxel_size;
+    const float X = (k.base[0].re + ps.R.data[0].z.re * vgz) + ps.t.x.re;
+    const float Y = (k.base[1].re + ps.R.data[1].z.re * vgz) + ps.t.y.re;
+    const float c = (k.base[2].re + ps.R.data[2].z.re * vgz) + ps.t.z.re;
+    const float pxr = X * k.fx, pyr = Y * k.fy;
+    bool in = live, unsure = false;
+    if (need_image) {
+        const float d = fminf(fminf(pxr - win.ulo * c, win.uhi * c - pxr), fminf(pyr - win.vlo * c, win.vhi * c - pyr));
+        in = live && d >= 0.0f;
+        unsure = live && !in && !(d < -2.0f * XS_EDGE_MARGIN * c);
+    }
+    const float rc = __builtin_amdgcn_rcpf(c);
+    const float u = pxr * rc + k.cx, v = pyr * rc + k.cy;
+    const float ru = rintf(u), rv = rintf(v);
+    unsure = unsure || (in && !(fabsf(u - ru) < 0.5f - XS_NEAR_MARGIN && fabsf(v - rv) < 0.5f - XS_NEAR_MARGIN));   // (NaN: unsure)
+    int nx = (int)ru, ny = (int)rv;
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
+        if (unsure) { VoxelProj p; VoxelPixel q; in = voxel_pixel(a, ps, k, z, p, q); nx = q.near_x; ny = q.near_y; }
+    }
+    s.in = in;
+    if (in) {
+        s.d = dimg.one(ny, nx);
+        s.v = *reinterpret_cast<const float *>(bv + off); s.g = *reinterpret_cast<const float *>(bg + off); s.w = *reinterpret_cast<const int *>(bw + off);
+    }
+}
+__device__ __forceinline__ unsigned valid_slot_retire(const ValidSlot &s, const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned always) {
+    if (!(s.in && s.d > 0.0f)) return 0u;   // (Dp = 0: TsdfFusion.cu:150)
+    float ov, og; int ow;
+    running_mean(a.max_weight, cfloat(1.0f, 0.0f), s.v, s.g, s.w, ov, og, ow);
+    if ((__float_as_uint(ov) ^ __float_as_uint(s.v)) | always) *reinterpret_cast<float *>(bv + off) = ov;
+    if ((unsigned)(ow ^ s.w) | always) *reinterpret_cast<int *>(bw + off) = ow;
+    if ((__float_as_uint(og) ^ __float_as_uint(s.g)) | always) *reinterpret_cast<float *>(bg + off) = og;
+    return 1u;
+}
+__device__ __forceinline__ unsigned integrate_valid_column(const IntegrateArgs &a, const PoseRT &ps, bool need_image, char *bv, char *bw, char *bg, unsigned off,
+                                                           unsigned plane, int x, int y, int zb, int ze) {
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    const VoxelCtx k = voxel_ctx(a, ps, x, y);
+    EdgeWindow w;
+    w.ulo = (2.5f + XS_EDGE_MARGIN) - k.cx; w.uhi = ((a.dcols - 0.5f) - XS_EDGE_MARGIN) - k.cx;
+    w.vlo = (2.5f + XS_EDGE_MARGIN) - k.cy; w.vhi = ((a.drows - 0.5f) - XS_EDGE_MARGIN) - k.cy;
+    const DepthGlobal dimg{a.depth, a.dstep};
+    unsigned n = 0;
+    ValidSlot A, B;
+    valid_slot_request(A, a, ps, k, w, need_image, dimg, bv, bw, bg, off, zb, true);
+#pragma unroll 1
+    for (int z = zb; z < ze; z += 2, off += 2 * plane) {
+        valid_slot_request(B, a, ps, k, w, need_image, dimg, bv, bw, bg, off + plane, z + 1, z + 1 < ze);
+        n += valid_slot_retire(A, a, bv, bw, bg, off, always);
+        valid_slot_request(A, a, ps, k, w, need_image, dimg, bv, bw, bg, off + 2 * plane, z + 2, z + 2 < ze);
+        n += valid_slot_retire(B, a, bv, bw, bg, off + plane, always);
     }
     return n;
 }
@@ -873,7 +961,8 @@ __device__ __forceinline__ unsigned classify_brick_boxes(const IntegrateArgs &a,
     if (corner == 0 && (a.kflags & KF_COUNT_CLASSES)) {   // boxes wholly free / wholly empty / with planes to walk; + the planes walked
         atomicAdd(a.brick_count + CLASS_COUNT_WORD + (nf == nz ? 0 : ne == nz ? 1 : 2), 1u);
         atomicAdd(a.brick_count + CLASS_COUNT_WORD + 3, (unsigned)(nz - nf - ne));
-        if (word & BOX_EDGE_BIT) atomicAdd(a.brick_count + CLASS_COUNT_WORD + 6, (unsigned)nf);   // planes streamed with the in-image test (words + 4, + 5: the second ListPair)
+        if (word & BOX_SPECKLE_BIT) atomicAdd(a.brick_count + CLASS_COUNT_WORD + 7, (unsigned)nf);   // planes streamed with the validity test (with or without the in-image test)
+        else if (word & BOX_EDGE_BIT) atomicAdd(a.brick_count + CLASS_COUNT_WORD + 6, (unsigned)nf);   // planes streamed with the in-image test alone (words + 4, + 5: the second ListPair)
     }
     return word | (nf + ne < nz ? 1u << 31 : 0u);
 }
@@ -1038,7 +1127,8 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
                     const size_t ubase = ((size_t)(f0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
                     char *fv = reinterpret_cast<char *>(a.value) + ubase, *fw = reinterpret_cast<char *>(a.weight) + ubase, *fg = reinterpret_cast<char *>(a.grad) + ubase;
                     const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
-                    if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
+                    if (word & BOX_SPECKLE_BIT) n_upd += integrate_valid_column(a, ps, (word & BOX_EDGE_BIT) != 0u, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box that sees an invalid pixel)
+                    else if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
                     else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, x, y, f0, f1);
                 }
                 if (walk_lo >= walk_hi) continue;
@@ -1233,7 +1323,7 @@ static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *w
     bind_classes(a, res, nz, workspace);
     // (a list classed a second time — XS_INTEGRATE_RECLASSIFY_BOXES — finds the first classification's counts there; behind a header clear the pair is zero)
     // (... and its class counters: words CLASS_COUNT_WORD .. + 6 hold the counters, the second pair between them — one fill)
-    if (!second_pair_is_clear && hipMemsetAsync(a.brick_count + CLASS_COUNT_WORD, 0, 7 * sizeof(unsigned), st) != hipSuccess) return false;
+    if (!second_pair_is_clear && hipMemsetAsync(a.brick_count + CLASS_COUNT_WORD, 0, 8 * sizeof(unsigned), st) != hipSuccess) return false;
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
     BoxOrder ord;
     ord.list = reinterpret_cast<int *>((char *)workspace + workspace_order_offset(res, nz));
