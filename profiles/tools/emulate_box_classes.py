@@ -29,10 +29,10 @@ def tile_table(depth_mm):
     d = np.where((d > 5000) | (d < 200), 0.0, d / 1000.0)
     H, W = d.shape
     ty, tx = (H + TILE - 1) // TILE, (W + TILE - 1) // TILE
-    lo = np.full((ty * TILE, tx * TILE), np.inf); hi = np.zeros((ty * TILE, tx * TILE))
-    lo[:H, :W] = d; hi[:H, :W] = d
-    lo = lo.reshape(ty, TILE, tx, TILE).min(axis=(1, 3)); hi = hi.reshape(ty, TILE, tx, TILE).max(axis=(1, 3))
-    return lo, hi
+    lo = np.full((ty * TILE, tx * TILE), np.inf); hi = np.zeros((ty * TILE, tx * TILE)); inv = np.zeros((ty * TILE, tx * TILE))
+    lo[:H, :W] = np.where(d > 0, d, np.inf); hi[:H, :W] = d; inv[:H, :W] = d == 0      # (round 5: lo over the VALID pixels + "holds an invalid one")
+    lo = lo.reshape(ty, TILE, tx, TILE).min(axis=(1, 3)); hi = hi.reshape(ty, TILE, tx, TILE).max(axis=(1, 3)); inv = inv.reshape(ty, TILE, tx, TILE).max(axis=(1, 3))
+    return lo, hi, inv
 
 
 class Rmq2d:
@@ -76,8 +76,8 @@ def classify(N, frame, shape, slack_scale, split_x=1):
     fx, fy, cx, cy = synth.FX, synth.FY, synth.CX, synth.CY
     W, H = synth.WIDTH, synth.HEIGHT
     depth = synth.s1_frame(frame)
-    lo_t, hi_t = tile_table(depth)
-    rmin, rmax = Rmq2d(lo_t, np.minimum), Rmq2d(hi_t, np.maximum)
+    lo_t, hi_t, inv_t = tile_table(depth)
+    rmin, rmax, rinv = Rmq2d(lo_t, np.minimum), Rmq2d(hi_t, np.maximum), Rmq2d(inv_t, np.maximum)
     trunc = synth.tranc_dist(prm)
     band = trunc * 1.001 + 1e-5 + 2e-4
     WX, WY, WZ = shape
@@ -126,6 +126,7 @@ def classify(N, frame, shape, slack_scale, split_x=1):
         idx = np.nonzero(seen)[0]
         tx0, tx1, ty0, ty1 = (qx0[idx] // TILE).astype(int), (qx1[idx] // TILE).astype(int), (qy0[idx] // TILE).astype(int), (qy1[idx] // TILE).astype(int)
         lo = rmin.query(ty0, ty1, tx0, tx1); hi = rmax.query(ty0, ty1, tx0, tx1)
+        ins_clean = inside[idx] & (rinv.query(ty0, ty1, tx0, tx1) == 0)    # plain free space: the range in the image AND without an invalid pixel
         # per plane: c range of the plane's four corners
         c_first_lo = cs[:4, idx].min(0); c_first_hi = cs[:4, idx].max(0)
         dzc = R[2, 2] * vs
@@ -133,7 +134,7 @@ def classify(N, frame, shape, slack_scale, split_x=1):
         pl_lo = c_first_lo[None, :] + j * dzc - dC - 1e-5; pl_hi = c_first_hi[None, :] + j * dzc + dC + 1e-5
         p_free_ok = (lo[None, :] - pl_hi > band)          # in front of everything the box can see
         p_empty = (pl_lo - hi[None, :] > band)
-        ins = inside[idx][None, :]
+        ins = ins_clean[None, :]    # ("edge" below then also counts the SPECKLE reason: scene S1's frames have no invalid pixel)
         yield dict(bz=bz, idx=idx, bx=bx[idx], by=by[idx], p_free_ok=p_free_ok, p_empty=p_empty, inside=ins, falls=falls)
 
 

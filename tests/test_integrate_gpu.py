@@ -1063,4 +1063,4 @@ def test_boxes_that_see_invalid_pixels_stream_with_a_validity_test(dev, threshol
             for a, b in zip(ref, vol):
                 assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (trial, ahead)
             boxes = int(head[0]) + int(head[1]) + int(head[2])
-            assert int(head[7]) > 2000 and int(head[2]) < 0.35 * boxes, (trial, ahead, head[:8])
+            assert int(head[7]) > 2000 and int(head[2]) < 0.6 * boxes, (trial, ahead, head[:8])   # (coarse 4.8 cm voxels: the wall's band is a large share of the boxes)
