@@ -1,6 +1,6 @@
 """GPU box, repository root: the S2 integrate launches in a fixed order for the counter passes (collect_pmc_r4.sh) — launch 0 into a freshly
 initialised volume (the first touch), then 5 launches of the same frame (the steady state of a static camera).  Prints U."""
-import importlib, json, sys
+import importlib, json, os, sys
 sys.path.insert(0, '.')
 import numpy as np, torch
 capi = importlib.import_module('x-slam_amd.capi'); synth = importlib.import_module('x-slam_amd.synth')
@@ -9,7 +9,10 @@ prm = synth.s2_params(n); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel
 value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
 grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
 capi.init_volume(value, weight, grad, n * 4, res)
-depth = torch.from_numpy(synth.render_s2().view(np.int16)).cuda()
+frame = synth.render_s2()
+if os.environ.get("S2_NOISY"):      # SURVEY 8(d)'s +-2 mm noise + holes / out-of-range patches + 0.2 % speckle (bench.py roofline_s2.noisy)
+    frame = synth.holed(synth.render_s2(noise_mm=2.0), np.random.default_rng(0xC5FD), n_holes=40, speckle=0.002)
+depth = torch.from_numpy(frame.view(np.int16)).cuda()
 scaled = torch.empty((H, W), dtype=torch.float32, device="cuda"); dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
 capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
 ws = torch.zeros(capi.integrate_workspace_bytes(res), dtype=torch.uint8, device="cuda")
