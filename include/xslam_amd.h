@@ -170,12 +170,6 @@ typedef struct xs_integrate_opts {
     unsigned mailbox_seq;            /* ... the sequence number it waits for ... */
     float mailbox_slack;             /* ... the factor the call widens the list pose's frustum planes by ... */
     void *pose_dev;                  /* ... and 128 bytes of device memory through which the gate hands the pose on */
-    /* The two-kernel form (all three set, a workspace, box classes, not a posted launch; else ignored): the streamed planes of the launch run as
-     * a kernel of their own on side_stream, beside the walked planes on the call's stream (they touch disjoint planes).  side_ready_event: a
-     * hipEvent_t that completes when the box classes are written — the stop_event xs_integrate_classify_ex was given for this list, or, where
-     * this call classifies itself, an event it may attach to its classification.  side_done_event: rides on the side kernel's dispatch —
-     * whatever reads the volume next must be ordered behind BOTH the call's stream and this event. */
-    void *side_stream, *side_ready_event, *side_done_event;
 } xs_integrate_opts;
 int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                             const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value,

@@ -11,13 +11,12 @@ import numpy as np, torch
 capi = importlib.import_module('x-slam_amd.capi'); synth = importlib.import_module('x-slam_amd.synth')
 H, W = synth.HEIGHT, synth.WIDTH
 hip = C.CDLL("libamdhip64.so")
-ev = [C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()]     # start / stop on the launch's stream; classes ready; side kernel done
+ev = [C.c_void_p(), C.c_void_p()]
 for e in ev:
     assert hip.hipEventCreate(C.byref(e)) == 0
-side_stream = torch.cuda.Stream()
 
 
-def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False, sign=False, side=False):
+def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False, sign=False):
     prm = synth.s1_params(n, threshold=threshold); res = [n, n, n]; vs = float(np.float32(prm["tsdf_voxel_size"])); trunc = synth.tranc_dist(prm)
     value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
     grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
@@ -42,25 +41,21 @@ def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False, sign=False, si
         counter.zero_()
         flags = 64
         if mode == "ahead":
-            capi.integrate_classify_ex(H, W, intr, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, capi.integrate_opts(flags=64, depth_tiles=tiles, stop_event=ev[2] if side else None), slack_scale=slack, depth_max=dmax, stream=s)
+            capi.integrate_classify_ex(H, W, intr, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, capi.integrate_opts(flags=64, depth_tiles=tiles), slack_scale=slack, depth_max=dmax, stream=s)
             flags |= 4 | 1
         elif mode == "walk":
             flags |= 32
-        o = capi.integrate_opts(flags=flags, depth_tiles=tiles, start_event=ev[0], stop_event=ev[1], signmap=sm,
-                                side_stream=side_stream if side else None, side_ready_event=ev[2] if side else None, side_done_event=ev[3] if side else None)
+        o = capi.integrate_opts(flags=flags, depth_tiles=tiles, start_event=ev[0], stop_event=ev[1], signmap=sm)
         capi.integrate_scaled_ex2(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, o, threshold=threshold,
                                   updated=counter, depth_max=dmax, workspace=ws, stream=s)
         torch.cuda.synchronize()
         head = ws[192:232].view(torch.int32).cpu().numpy()
         classes = [int(x) for x in head[:7]]; vcount = 0
         dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0
-        if side and mode != "walk":     # the launch = from the walk kernel's begin to the later of the two kernels' ends
-            d2 = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(d2), ev[0], ev[3]) == 0
-            dt.value = max(dt.value, d2.value)
         if k >= 4:
             times.append(dt.value * 1e3); Us.append(int(counter.item()))
     U, t = np.median(Us), np.median(times)
-    print(f"n {n} {mode:6s}{' +sign' if sign else '      '}{' SIDE' if side else '     '} thr {threshold}: U {U:.0f}  kernel {t:.1f} us (min {min(times):.1f})  {24 * U / t / 1e6:.2f} TB/s algorithmic;  boxes free / nothing / walk "
+    print(f"n {n} {mode:6s}{' +sign' if sign else '      '} thr {threshold}: U {U:.0f}  kernel {t:.1f} us (min {min(times):.1f})  {24 * U / t / 1e6:.2f} TB/s algorithmic;  boxes free / nothing / walk "
           f"{classes[0:3]}  planes walked {classes[3]}  edge planes {classes[6]}  workgroups with work {vcount}", flush=True)
     return value, weight, grad
 
@@ -71,12 +66,12 @@ if __name__ == "__main__":
     quick = os.environ.get("PROBE_QUICK")          # A/B sweeps: the two pipeline-like modes only, no comparison against the walk
     for n in sizes:
         if quick:
-            run(n, "own", sign=True); run(n, "own", sign=True, side=True); run(n, "ahead", sign=True); run(n, "ahead", sign=True, side=True)
+            run(n, "own"); run(n, "own", sign=True); run(n, "ahead"); run(n, "ahead", sign=True)
             torch.cuda.empty_cache()
             continue
         ref = None
         for mode, hint in (("walk", False), ("own", False), ("own", True), ("ahead", False), ("ahead", True)):
-            out = run(n, mode, side=hint)
+            out = run(n, mode, hint=hint)
             if ref is None: ref = [t.clone() for t in out]
             else:
                 same = all(bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(ref, out))

@@ -38,8 +38,7 @@ class IntegrateOpts(C.Structure):
     """xs_integrate_opts (include/xslam_amd.h): what an integrate / classify call takes besides its arguments proper."""
     _fields_ = [("struct_bytes", C.c_uint), ("flags", C.c_uint), ("depth_tiles", C.c_void_p), ("signmap", C.c_void_p),
                 ("start_event", C.c_void_p), ("stop_event", C.c_void_p), ("pose_mailbox", C.c_void_p), ("mailbox_seq", C.c_uint),
-                ("mailbox_slack", C.c_float), ("pose_dev", C.c_void_p), ("side_stream", C.c_void_p), ("side_ready_event", C.c_void_p),
-                ("side_done_event", C.c_void_p)]
+                ("mailbox_slack", C.c_float), ("pose_dev", C.c_void_p)]
 
 
 class RaycastOpts(C.Structure):
@@ -299,7 +298,7 @@ def integrate_scaled_ex(depth_scaled, scaled_step, rows, cols, intr, max_weight,
 
 
 def integrate_opts(flags=0, depth_tiles=None, signmap=None, start_event=None, stop_event=None, pose_mailbox=None, mailbox_seq=0, mailbox_slack=2.0,
-                   pose_dev=None, side_stream=None, side_ready_event=None, side_done_event=None):
+                   pose_dev=None):
     """An xs_integrate_opts for integrate_scaled_ex2 / integrate_classify_ex (tensors or raw addresses for the pointers)."""
     o = IntegrateOpts()
     o.struct_bytes = C.sizeof(IntegrateOpts)
@@ -308,9 +307,6 @@ def integrate_opts(flags=0, depth_tiles=None, signmap=None, start_event=None, st
     o.start_event = start_event.value if hasattr(start_event, "value") else start_event
     o.stop_event = stop_event.value if hasattr(stop_event, "value") else stop_event
     o.mailbox_seq, o.mailbox_slack = mailbox_seq, mailbox_slack
-    ev = lambda e: e.value if hasattr(e, "value") else e
-    o.side_stream = _stream(side_stream) if side_stream is not None else None
-    o.side_ready_event, o.side_done_event = ev(side_ready_event), ev(side_done_event)
     return o
 
 

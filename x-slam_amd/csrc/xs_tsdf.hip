@@ -1055,15 +1055,8 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
 // kernel inside the pipeline 33 -> 28 us, S2 unchanged (profiles/r04_ab_integrate_waves.txt).
 #define XS_INTEGRATE_WAVES 6
 #endif
-// PART (round 5): 0 = the whole brick (one launch); 1 = the streamed planes only (free / EDGE / SPECKLE: no walk code, so the kernel is
-// compiled for eight waves per SIMD); 2 = the walked planes only, of the bricks that have any (the ordered list's front run).  1 and 2 are the
-// two halves of a launch that runs them SIDE BY SIDE on two streams (xs_integrate_opts.side_stream): in one kernel every wave reserves the
-// walk's 80 VGPRs, six waves per SIMD cannot hold enough walks to saturate the VALU and enough streams to saturate HBM at once, and a launch of
-// several rounds (1024^3, scene S2) degenerates into a walk phase followed by a stream phase (profiles/r05_integrate_wg_times.txt).  They touch
-// disjoint planes of a box, so they need no order between them.
-template <bool BILINEAR, bool OFF32 = false, bool POSTED = false, bool SIGN = false, int PART = 0>
-__global__ void __launch_bounds__(256, PART == 1 ? 8 : XS_INTEGRATE_WAVES) k_integrate_bricks(const IntegrateArgs a) {
-    static_assert(PART == 0 || (OFF32 && !POSTED), "the two-kernel form needs box classes: 32-bit offsets, no posted pose");
+template <bool BILINEAR, bool OFF32 = false, bool POSTED = false, bool SIGN = false>
+__global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(const IntegrateArgs a) {
     PoseRT ps{a.R, a.t};
     if constexpr (POSTED) {
         // the pose k_pose_gate (the launch in front of this one) took from the mailbox: word 0 = command (0: run), words 1..24 = R, t
@@ -1082,7 +1075,6 @@ __global__ void __launch_bounds__(256, PART == 1 ? 8 : XS_INTEGRATE_WAVES) k_int
     const unsigned long long probe_t0 = wall_clock64();
 #endif
     const unsigned nwalk = a.brick_count[a.pair_word], count = nwalk + a.brick_count[a.pair_word + 1];   // (see "the list and its order")
-    const unsigned todo = PART == 2 ? nwalk : count;     // entries this launch takes
     unsigned n_upd = 0;
     const float far = far_limit(a);
     // The column clip's 20 plane scalars are used once per brick, outside the voxel loop.  Held in scalar registers for the
@@ -1090,7 +1082,7 @@ __global__ void __launch_bounds__(256, PART == 1 ? 8 : XS_INTEGRATE_WAVES) k_int
     // back — VALU slots, and this kernel is bound by VALU issue: 101 M wave instructions per S2 launch): they live in LDS.
     __shared__ ClipPlanes s_cp;
     float cp_word = 0.f;
-    if (PART != 1 && threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) cp_word = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
+    if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) cp_word = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
     // (A bit-reversed entry order for launches with fewer bricks than workgroups — so that list neighbours, the bricks of one surface, land
     // on different CUs — measured 29 -> 42 us on S1: the dispatcher deals consecutive workgroups round the CUs, so the eight workgroups of
     // a CU already take entries 256 apart; profiles/r04_integrate_wg_times.txt.)
@@ -1103,15 +1095,13 @@ __global__ void __launch_bounds__(256, PART == 1 ? 8 : XS_INTEGRATE_WAVES) k_int
     auto entry = [&](unsigned e) { return list_at(far_first ? count - 1u - e : e, nwalk, a.list_cap); };
     // the first entry and its class are requested together, in front of the barrier
     int b_next = 0, cls_next = BOX_MIXED;
-    if (first < todo) {
+    if (first < count) {
         b_next = a.brick_list[entry(first)];
         if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(first) * BOXES_PER_BRICK + threadIdx.y];
     }
-    if constexpr (PART != 1) {   // (the streamed planes need no column clip: no LDS, no barrier)
-        if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[threadIdx.x] = cp_word;
-        __syncthreads();
-    }
-    for (unsigned e = first; e < todo; e += stride) {
+    if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[threadIdx.x] = cp_word;
+    __syncthreads();
+    for (unsigned e = first; e < count; e += stride) {
         // (OFF32: the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
         // or every address derived from it would be a 64-bit vector quantity)
         if (e != first) {
@@ -1133,7 +1123,7 @@ __global__ void __launch_bounds__(256, PART == 1 ? 8 : XS_INTEGRATE_WAVES) k_int
                 const bool falls = ((word >> 16) & 1u) != 0u;
                 const int f0 = falls ? ze0 - nf : zb0, f1 = falls ? ze0 : zb0 + nf;       // free planes [f0, f1)
                 walk_lo = falls ? zb0 + ne : zb0 + nf; walk_hi = falls ? ze0 - nf : ze0 - ne;
-                if (PART != 2 && nf > 0 && x < a.X && y < a.Y) {
+                if (nf > 0 && x < a.X && y < a.Y) {
                     const size_t ubase = ((size_t)(f0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
                     char *fv = reinterpret_cast<char *>(a.value) + ubase, *fw = reinterpret_cast<char *>(a.weight) + ubase, *fg = reinterpret_cast<char *>(a.grad) + ubase;
                     const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
@@ -1141,10 +1131,10 @@ __global__ void __launch_bounds__(256, PART == 1 ? 8 : XS_INTEGRATE_WAVES) k_int
                     else if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
                     else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, x, y, f0, f1);
                 }
-                if (PART == 1 || walk_lo >= walk_hi) continue;
+                if (walk_lo >= walk_hi) continue;
             }
         }
-        if (PART != 1 && x < a.X && y < a.Y) {
+        if (x < a.X && y < a.Y) {
             const int zb0 = a.z0 + bz * a.brick_z;
             int zb = zb0, ze = min(zb + a.brick_z, a.z1);
             clip_column(s_cp, far, x, y, zb, ze);
@@ -1233,7 +1223,7 @@ static void host_frustum(IntegrateArgs &a, float slack_scale = 1.0f) {
 //   pose mailbox         see k_integrate_bricks<., ., true>: the mailbox the next XS_INTEGRATE_POSE_POSTED call's gate polls, its number, the
 //                        factor by which that call widens the frustum planes of the pose it is given (the list's pose), the hand-over buffer
 //   sign map             the map (xs_signmap.h) the launches mark; depth tiles: the frame's table (xs_scale_depth_tiles), null = the call builds its own
-static thread_local xs_integrate_opts g_legacy = {sizeof(xs_integrate_opts), 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 2.0f, nullptr, nullptr, nullptr, nullptr};
+static thread_local xs_integrate_opts g_legacy = {sizeof(xs_integrate_opts), 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 2.0f, nullptr};
 static thread_local void *g_legacy_class_ev = nullptr;
 extern "C" void xs_integrate_set_classify_event(void *done_event) { g_legacy_class_ev = done_event; }
 extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) { g_legacy.start_event = start_event; g_legacy.stop_event = stop_event; }
@@ -1543,23 +1533,13 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
             launch_scale_depth(depth_scaled, scaled_step, rows, cols, (float *)nullptr, (size_t)0, (float *)nullptr, own, st);
             return own;
         };
-        // the two-kernel form (streamed planes on opts->side_stream beside the walk): needs box classes and an event that says when they are
-        // written — the caller's, which rode on xs_integrate_classify_ex's last dispatch, or attached here to this call's own classification
-        const bool side = opts->side_stream && opts->side_ready_event && opts->side_done_event && use_tiles && !posted;
-        hipEvent_t own_classes_done = nullptr;
         if (!(flags & XS_INTEGRATE_LIST_IS_READY)) {   // (else: xs_integrate_classify has run on this stream for a covering pose)
             if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR))
                 XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // list pairs + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
-            const DepthTile *tt = use_tiles ? tile_table() : nullptr;
-            own_classes_done = side && tt ? (hipEvent_t)opts->side_ready_event : nullptr;
-            launch_classification(a, res, nz, workspace, tt, BoxSlack{0.f, 0.f, 0.f}, st, own_classes_done);
+            launch_classification(a, res, nz, workspace, use_tiles ? tile_table() : nullptr, BoxSlack{0.f, 0.f, 0.f}, st);
         } else if (use_tiles) {
             if (classes_ahead) bind_ordered_list(a, res, nz, workspace);
-            else if (!posted) {   // (a posted launch has no pose yet to classify with)
-                const DepthTile *tt = tile_table();
-                own_classes_done = side && tt ? (hipEvent_t)opts->side_ready_event : nullptr;
-                launch_box_classes(a, res, nz, workspace, tt, BoxSlack{0.f, 0.f, 0.f}, st, false, own_classes_done);
-            }
+            else if (!posted) launch_box_classes(a, res, nz, workspace, tile_table(), BoxSlack{0.f, 0.f, 0.f}, st, false);   // (a posted launch has no pose yet to classify with)
         }
         if (a.box_class) a.kflags &= ~(unsigned)KF_FAR_FIRST;   // the list is ordered by class
         // resident workgroups stride over the list: 256 CUs x 8
@@ -1582,15 +1562,6 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
         static const int env_lds = exp_env_int("XS_INTEGRATE_DYN_LDS", 0);   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU
-        if (side && a.box_class && off32) {
-            // side by side: the streamed planes of every listed brick on the side stream (behind the classes' event), the walked planes of the
-            // bricks that have any on this one.  side_done_event rides on the side kernel: whatever reads the volume next waits for it AND this stream.
-            hipStream_t ss = (hipStream_t)opts->side_stream;
-            XS_CHECK(hipStreamWaitEvent(ss, (hipEvent_t)opts->side_ready_event, 0));
-            hipExtLaunchKernelGGL((k_integrate_bricks<false, true, false, false, 1>), dim3(g), block, 0, ss, nullptr, (hipEvent_t)opts->side_done_event, 0, a);
-            kern = sign ? (threshold > 0.0f ? k_integrate_bricks<true, true, false, true, 2> : k_integrate_bricks<false, true, false, true, 2>)
-                        : (threshold > 0.0f ? k_integrate_bricks<true, true, false, false, 2> : k_integrate_bricks<false, true, false, false, 2>);
-        }
         if (ev0 || ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, ev0, ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, env_lds, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
