@@ -41,7 +41,10 @@ for cls, name in ((1, "free"), (2, "nothing to write"), (0, "per-voxel walk")):
         d = (work[..., 1] - work[..., 0])[m] * 0.01
         print(f"{name:18s} waves {m.sum():5d}  begin {b[:count][m].mean():6.2f} us (max {b[:count][m].max():6.2f})  duration mean {d.mean():6.2f}  p50 {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}  end max {e[:count][m].max():6.2f}")
 idle = rec[count:]
-print(f"workgroups without a brick: {len(idle)}  begin mean {((idle[..., 0] - t0) * 0.01).mean():.2f}  last end {((idle[..., 1] - t0) * 0.01).max():.2f} us")
+if len(idle):
+    print(f"workgroups without a brick: {len(idle)}  begin mean {((idle[..., 0] - t0) * 0.01).mean():.2f}  last end {((idle[..., 1] - t0) * 0.01).max():.2f} us")
+else:
+    print(f"every workgroup has work: {listed} bricks for 8192 workgroups (some take a second brick)")
 hist, edges = np.histogram(e[:count].max(axis=1), bins=12)
 print("end-time histogram of working workgroups (us):", [(round(float(a), 1), int(c)) for a, c in zip(edges[:-1], hist)])
 region = ws[256:256 + nb * 4 * 4].view(torch.int32).cpu().numpy()      # the list: walked bricks from the front of its region, the others from its back
