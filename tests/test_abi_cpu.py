@@ -245,6 +245,21 @@ def test_integration_md_shim_compiles_and_links(tmp_path):
            "-Wl,-rpath," + os.path.join(ROOT, "x-slam_amd")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    # the options-struct form shown in "Additions of round 5" compiles and links as written too (wrapped into a function that declares its names)
+    opts = [b for b in blocks if "xs_integrate_scaled_ex2(" in b and "xs_raycast_ex(" in b]
+    assert len(opts) == 1
+    (tmp_path / "OptsCaller.cpp").write_text(
+        '#include "xslam_amd.h"\n'
+        "void opts_caller(const float *scaled, size_t scaled_pitch, int rows, int cols, const float *intr4, int max_weight, const int *res, float voxel_size,\n"
+        "                 const float *Rv2c18, const float *tv2c6, float tranc_dist, float *value, int *weight, float *grad, size_t vol_pitch, float threshold,\n"
+        "                 unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, void *stream, const void *tiles, void *sign_map,\n"
+        "                 void *integrate_done, int shift, float *vmap, float *nmap, size_t map_pitch, float *vmap1, float *nmap1, size_t pitch1, float *vmap2,\n"
+        "                 float *nmap2, size_t pitch2, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6, unsigned long long *hits_dev,\n"
+        "                 float *ray_ws) {\n"
+        + opts[0] + "}\n")
+    r = subprocess.run(cmd[:cmd.index(str(tmp_path / "HipLaunchers.cpp"))] + [str(tmp_path / "OptsCaller.cpp"), "-o", str(tmp_path / "libopts.so"), "-Wl,--no-undefined",
+                       "-L" + os.path.join(ROOT, "x-slam_amd"), "-lxslam_hip", f"-L{rocm}/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     # and the argument count the document passes to every xs_ function equals the header's
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "xslam_amd.h")).read(), flags=re.S)
     nargs = {m.group(1): m.group(2).count(",") + 1 for m in re.finditer(r"\b(xs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)}
