@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the round-4 tree (git archive 048ef56 into scratch/r04, built there) against the current tree, alternating on one box:
+# GPU box: the round-4 tree (mkdir -p scratch/r04 && git archive 048ef56 | tar -x -C scratch/r04, then make in its csrc and host directories) against the current tree, alternating on one box:
 # bench.py --workload track (headline workload only), the driver's region shape (--steps 20 --warmup 5) and a longer one (--steps 60).
 cd "$(dirname "$0")/../.."
 ROOT=$PWD
