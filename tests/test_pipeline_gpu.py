@@ -875,3 +875,41 @@ def test_pipeline_on_a_sensor_like_stream_against_live_oracle(dev, oracle, thres
     assert frac_bad(np.abs(v[same] - ov[same]) <= 1e-4) <= 1e-4
     assert frac_bad(np.abs(g[same] - og[same]) <= 1e-3 * np.abs(og).max()) <= 1e-4
     kf.close()
+
+
+def test_profiling_level_one_times_every_nth_integrate_launch_and_the_tail_clocks(dev):
+    """Profiling level 1 attaches the integrate kernel's start / stop event pair to every profile_integrate_every-th frame only (its start event
+    costs the launch call ~5 us of host time on the frame's critical path): the stage counter says how many launches were timed, their
+    mean is a plausible kernel time, the voxel counters are complete all the same, and the results do not depend on the setting; level 2 times
+    every frame.  xs_kf_tail_host_times / xs_kf_list_cover_counts report something for every tracked frame."""
+    torch, pl = dev
+    prm = synth.s1_params(128)
+    frames = [upload(torch, synth.s1_frame(k)) for k in range(17)]
+    runs = {every: pl.KinectFusion(dict(prm, profile_integrate_every=every)) for every in (1, 4)}
+    for every, r in runs.items():
+        assert r.process_frame(frames[0]) == 1
+        r.set_profiling(1)
+        r.reset_stage_times()
+        for f in frames[1:]:
+            assert r.process_frame(f) == 1
+        torch.cuda.synchronize()
+        st = r.stage_times()
+        assert st["integrate"][1] == (16 if every == 1 else 4), (every, st["integrate"])
+        assert 0.002 < st["integrate"][0] / st["integrate"][1] < 0.2
+        th = r.tail_host_times()
+        assert th["frames"] == 16 and 0.0 < th["integrate_launch_call"] < 200.0 and th["sums_seen_to_integrate_entered"] > 0.0
+        held = r.list_cover_counts()
+        assert held["neither"] + held["list_only"] + held["both"] == 16
+        assert r.cumulative_counters()[0] > 16 * 1000
+    a, b = runs[1], runs[4]
+    assert np.array_equal(a.world2camera(), b.world2camera()) and a.cumulative_counters() == b.cumulative_counters()
+    for u, v in zip(a.volume(), b.volume()):
+        assert np.array_equal(u, v)
+    b.set_profiling(2)
+    b.reset_stage_times()
+    for f in frames[:4]:
+        assert b.process_frame(f) == 1
+    torch.cuda.synchronize()
+    assert b.stage_times()["integrate"][1] == 4
+    for r in runs.values():
+        r.close()
