@@ -386,7 +386,7 @@ def test_integrate_size_independent_properties_512(dev):
 
 def test_frustum_filling_scene_512_classes_and_order_against_the_walk_everywhere(dev):
     """Scene S2 (the frustum fills the volume: 23 000 listed bricks at 512^3 — the launch on which integrate is HBM-bound, and the one
-    whose list is ordered with a reservation per 64 bricks): three launches with the boxes' classes and the ordered list against the
+    whose list is ordered with a reservation per 32 bricks): three launches with the boxes' classes and the ordered list against the
     per-voxel walk of every listed voxel (XS_INTEGRATE_NO_TILES), volumes and counts bit for bit; the ordered list holds the listed
     bricks once each, those with planes to walk in front."""
     torch, capi = dev

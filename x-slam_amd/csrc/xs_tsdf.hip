@@ -999,13 +999,18 @@ __device__ __forceinline__ void list_append(const IntegrateArgs &a, unsigned *pa
 
 // The boxes' classes for the list k_classify_bricks left (the primary pair and region), and the list again in the order
 // k_integrate_bricks takes it (the second pair and region: ord).  Eight lanes per box, 8 bricks per workgroup and trip; a reservation
-// per 8 bricks while the launch is small, per 64 beyond (S2's 23 000 bricks then take 360 atomics instead of 2 900; ~12 ns each on one
+// per 8 bricks while the launch is small, per ORDER_BATCH = 32 beyond (S2's 23 000 bricks then take 720 atomics instead of 2 900; ~12 ns each on one
 // address).  Batches are runs of list neighbours and arrive roughly in list order, so each run of the ordered list keeps the plane order
 // of the first — which matters: the same bricks dealt round the workgroups of a fused kernel (frustum test + classes in one launch, no
 // faster: 12.5 us against 3.8 + 8.4) came out in an order that made the S2 launch 9 % slower (profiles/r04_ab_classify_fused.txt).
 // The second pair is zero when the kernel starts (the launcher clears it).
 struct BoxOrder { int *list; };
-enum { ORDER_BATCH = 64 };
+#ifndef XS_ORDER_BATCH
+#define XS_ORDER_BATCH 32   // bricks per reservation beyond 4 096 listed ones.  A workgroup takes its batch in rounds of 8 bricks (8 lanes per box, 4 boxes): 64
+                            // was eight dependent rounds (18 us at 1024^3's 12.5 K bricks), 32 is four — 1024^3 tracking +0.5-1 %, scene S2's whole call
+                            // 0.173 -> 0.169 ms; 16 doubles the same-address atomics again and loses (profiles/r05_ab_order_batch.txt)
+#endif
+enum { ORDER_BATCH = XS_ORDER_BATCH };
 __global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl, const BoxOrder ord) {
     const unsigned nwalk = a.brick_count[PAIR_PRIMARY], count = nwalk + a.brick_count[PAIR_PRIMARY + 1];
     const int tid = (int)threadIdx.x, corner = tid & 7, box = (tid >> 3) & (BOXES_PER_BRICK - 1), slot = tid >> 5;
