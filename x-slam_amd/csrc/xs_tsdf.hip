@@ -907,7 +907,10 @@ __global__ void __launch_bounds__(256) k_integrate(const IntegrateArgs a) {
 // and 16x16 ones stream a quarter slower: profiles/tools/ab_brick_shape.sh).  The voxels that can be
 // written (a few % of an ICL-like volume) are thereby spread over every CU instead of being
 // concentrated in the few columns that cross the frustum.
-__global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) {
+// (round 5: one reservation per WORKGROUP of 1 024 threads instead of one per wave — same-address atomics are served one at a time, ~12 ns
+// each, and the listed bricks of a 1024^3 frustum sit in ~600 waves: 7 of the kernel's 8.9 us; entries stay in thread order, i.e. plane order)
+enum { CLASSIFY_BRICKS_BLOCK = 1024 };
+__global__ void __launch_bounds__(CLASSIFY_BRICKS_BLOCK) k_classify_bricks(const IntegrateArgs a) {
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = false;
@@ -918,13 +921,19 @@ __global__ void __launch_bounds__(256) k_classify_bricks(const IntegrateArgs a) 
         active = box_may_pass(f, x0, min(x0 + BRICK_X, a.X), y0, min(y0 + BRICK_Y, a.Y), z0, min(z0 + a.brick_z, a.z1));
     }
     const unsigned long long m = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == 0 && m) base = atomicAdd(a.brick_count, (unsigned)__popcll(m));
-    base = __shfl((int)base, 0, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned s_n[CLASSIFY_BRICKS_BLOCK / 64], s_base;
+    if (lane == 0) s_n[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { const unsigned n = s_n[w]; s_n[w] = total; total += n; }   // exclusive prefix: each wave's place
+        s_base = total ? atomicAdd(a.brick_count, total) : 0u;
+    }
+    __syncthreads();
     if (active) {  // packed (bx, by, bz), 10 bits each: the consumer decodes with shifts
         const int bx = b % a.bricks_x, by = (b / a.bricks_x) % a.bricks_y, bz = b / (a.bricks_x * a.bricks_y);
-        a.brick_list[base + __popcll(m & ((1ull << lane) - 1ull))] = bx | (by << 10) | (bz << 20);
+        a.brick_list[s_base + s_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = bx | (by << 10) | (bz << 20);
     }
 }
 
@@ -1011,6 +1020,7 @@ struct BoxOrder { int *list; };
                             // 0.173 -> 0.169 ms; 16 doubles the same-address atomics again and loses (profiles/r05_ab_order_batch.txt)
 #endif
 enum { ORDER_BATCH = XS_ORDER_BATCH };
+// (1 024-thread workgroups — a batch of 32 in ONE round — measured 14.5 us against 15.1 at 1024^3: the rounds are not what the kernel waits for.)
 __global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, const BoxSlack sl, const BoxOrder ord) {
     const unsigned nwalk = a.brick_count[PAIR_PRIMARY], count = nwalk + a.brick_count[PAIR_PRIMARY + 1];
     const int tid = (int)threadIdx.x, corner = tid & 7, box = (tid >> 3) & (BOXES_PER_BRICK - 1), slot = tid >> 5;
@@ -1343,8 +1353,8 @@ static bool launch_box_classes(IntegrateArgs &a, const int *res, int nz, void *w
 static bool launch_classification(IntegrateArgs &a, const int *res, int nz, void *workspace, const DepthTile *tiles, const BoxSlack &sl, hipStream_t st,
                                   hipEvent_t done = nullptr) {
     const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-    if (done && !tiles) hipExtLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, nullptr, done, 0, a);
-    else hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, 256)), dim3(256), 0, st, a);
+    if (done && !tiles) hipExtLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, CLASSIFY_BRICKS_BLOCK)), dim3(CLASSIFY_BRICKS_BLOCK), 0, st, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(k_classify_bricks, dim3(div_up(nb, CLASSIFY_BRICKS_BLOCK)), dim3(CLASSIFY_BRICKS_BLOCK), 0, st, a);
     return launch_box_classes(a, res, nz, workspace, tiles, sl, st, true, done);
 }
 // the pose-dependent part of the arguments the classification needs (what xs_integrate_scaled_ex sets up for it)
