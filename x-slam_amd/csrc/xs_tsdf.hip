@@ -698,9 +698,8 @@ __device__ __forceinline__ void free_group_load(FreeGroup &s, const char *bv, co
             s.w[j] = *reinterpret_cast<const int *>(bw + (off + j * plane));
         }
 }
-template <bool SIGN>
 __device__ __forceinline__ void free_group_store(const IntegrateArgs &a, const FreeGroup &s, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int left,
-                                                 unsigned always, float &vmin) {
+                                                 unsigned always) {
 #pragma unroll
     for (int j = 0; j < FREE_CHUNK; ++j)
         if (j < left) {
@@ -709,23 +708,21 @@ __device__ __forceinline__ void free_group_store(const IntegrateArgs &a, const F
             if ((__float_as_uint(ov) ^ __float_as_uint(s.v[j])) | always) *reinterpret_cast<float *>(bv + (off + j * plane)) = ov;
             if ((unsigned)(ow ^ s.w[j]) | always) *reinterpret_cast<int *>(bw + (off + j * plane)) = ow;
             if ((__float_as_uint(og) ^ __float_as_uint(s.g[j])) | always) *reinterpret_cast<float *>(bg + (off + j * plane)) = og;
-            if (SIGN) vmin = fminf(vmin, ov);
         }
 }
 // (The streamed planes never mark the sign map: the running mean of a value with (1, 0) is negative only if the value was — and then the
 // launch that wrote that negative value marked the brick, the map's bytes are never cleared, and a value that reached the array any other
 // way obliges its owner to rebuild the map (xs_signmap.h).  One v_min per voxel and a dependent byte load per column less; 1024^3 -2 us.)
-__device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int x, int y, int zb, int ze) {
+__device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int zb, int ze) {
     const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
-    float vmin = 0.0f;
     FreeGroup A, B;
     free_group_load(A, bv, bw, bg, off, plane, ze - zb);
 #pragma unroll 1
     for (int z = zb; z < ze; z += 2 * FREE_CHUNK, off += 2 * FREE_CHUNK * plane) {
         free_group_load(B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK);
-        free_group_store<false>(a, A, bv, bw, bg, off, plane, ze - z, always, vmin);
+        free_group_store(a, A, bv, bw, bg, off, plane, ze - z, always);
         free_group_load(A, bv, bw, bg, off + 2 * FREE_CHUNK * plane, plane, ze - z - 2 * FREE_CHUNK);
-        free_group_store<false>(a, B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK, always, vmin);
+        free_group_store(a, B, bv, bw, bg, off + FREE_CHUNK * plane, plane, ze - z - FREE_CHUNK, always);
     }
     return (unsigned)(ze - zb);
 }
@@ -763,7 +760,6 @@ __device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a
     EdgeWindow w;
     w.ulo = (2.5f + XS_EDGE_MARGIN) - k.cx; w.uhi = ((a.dcols - 0.5f) - XS_EDGE_MARGIN) - k.cx;
     w.vlo = (2.5f + XS_EDGE_MARGIN) - k.cy; w.vhi = ((a.drows - 0.5f) - XS_EDGE_MARGIN) - k.cy;
-    float vmin = 0.0f;
     unsigned n = 0;
     // the free column's rolling pipeline, one plane per group: the next plane's test and state request go out before this plane's stores
     FreeGroup A, B;
@@ -773,10 +769,10 @@ __device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a
     for (int z = zb; z < ze; z += 2, off += 2 * plane) {
         inB = z + 1 < ze && edge_in_image(a, ps, k, w, z + 1);
         if (inB) free_group_load(B, bv, bw, bg, off + plane, plane, 1);
-        if (inA) { free_group_store<false>(a, A, bv, bw, bg, off, plane, 1, always, vmin); ++n; }
+        if (inA) { free_group_store(a, A, bv, bw, bg, off, plane, 1, always); ++n; }
         inA = z + 2 < ze && edge_in_image(a, ps, k, w, z + 2);
         if (inA) free_group_load(A, bv, bw, bg, off + 2 * plane, plane, 1);
-        if (inB) { free_group_store<false>(a, B, bv, bw, bg, off + plane, plane, 1, always, vmin); ++n; }
+        if (inB) { free_group_store(a, B, bv, bw, bg, off + plane, plane, 1, always); ++n; }
     }
     return n;
 }
@@ -1144,7 +1140,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
                     const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
                     if (word & BOX_SPECKLE_BIT) n_upd += integrate_valid_column(a, ps, (word & BOX_EDGE_BIT) != 0u, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box that sees an invalid pixel)
                     else if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
-                    else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, x, y, f0, f1);
+                    else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, f0, f1);
                 }
                 if (walk_lo >= walk_hi) continue;
             }
