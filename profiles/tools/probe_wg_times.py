@@ -15,22 +15,37 @@ ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
 intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
 s = torch.cuda.current_stream()
 nb = (n // 32) * (n // 8) * (n // 8)
-list_bytes = (256 + nb * 4 * 4 + 255) // 256 * 256          # workspace_list_bytes: bricks of 2 planes -> 4x the 8-plane count
+LIST0 = 256 + 8192 * 4                                       # header + the update counts' room (WS_LIST_OFFSET)
+list_bytes = (LIST0 + nb * 4 * 4 + 255) // 256 * 256          # workspace_list_bytes: bricks of 2 planes -> 4x the 8-plane count
 class_bytes = (nb * 4 * 4 * 4 + 255) // 256 * 256      # a 32-bit word per box, four boxes per (2-plane) brick
 off = list_bytes + class_bytes + (1 << 18)
+import ctypes as C
+hip = C.CDLL("libamdhip64.so")
+ev = [C.c_void_p(), C.c_void_p()]
+for e_ in ev:
+    assert hip.hipEventCreate(C.byref(e_)) == 0
 for k in range(12):
     depth = torch.from_numpy(synth.s1_frame(k).view(np.int16)).cuda()
     capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
     T = synth.s1_transforms(k, prm)
-    capi.integrate_scaled(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, depth_max=dmax, workspace=ws, stream=s)
+    o = capi.integrate_opts(flags=0, start_event=ev[0], stop_event=ev[1])
+    capi.integrate_scaled_ex2(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, o, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
+dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0
+print(f"the same launch by its event pair (begin / end timestamps of the dispatch packet): {dt.value * 1e3:.2f} us")
+if os.environ.get("XS_PROBE_EVENT_ONLY"):      # (a library without -DXS_WG_TIMES leaves no records to read)
+    sys.exit(0)
 nwalk, nother = capi.integrate_listed(ws); listed = nwalk + nother
-count = min(listed, 8192)     # (a launch has 8 192 workgroups: with more bricks listed a workgroup takes a second one; its record then covers both)
+pair2 = ws[208:216].view(torch.int32).cpu().numpy()          # the ordered list's two runs (a brick with a long walk has two entries in the first)
+entries = int(pair2[0]) + int(pair2[1])
+print(f"entries of the ordered list {entries} ({int(pair2[0])} in the front run)")
+G = int(os.environ.get("XS_BRICK_GRID", "0")) or 8192      # (an -DXS_EXPERIMENTS library sizes the grid from the same variable)
+count = min(entries, G)     # (a launch has 8 192 workgroups: with more bricks listed a workgroup takes a second one; its record then covers both)
 print(f"bricks listed {listed} ({nwalk} with planes to walk)")
-rec = ws[off:off + 8192 * 4 * 16].view(torch.int32).cpu().numpy().astype(np.int64).reshape(8192, 4, 4) & 0xffffffff
+rec = ws[off:off + G * 4 * 16].view(torch.int32).cpu().numpy().astype(np.int64).reshape(G, 4, 4) & 0xffffffff
 t0 = rec[..., 0].min()
 b = (rec[..., 0] - t0) * 0.01; e = (rec[..., 1] - t0) * 0.01
-print(f"bricks {count}; workgroups 8192; kernel span {e.max():.2f} us; last workgroup begins at {b.max():.2f} us")
+print(f"bricks {count}; workgroups {G}; kernel span {e.max():.2f} us; last workgroup begins at {b.max():.2f} us")
 work = rec[:count]
 nfree, nempty = work[..., 2] & 0xff, (work[..., 2] >> 8) & 0xff
 walked = 8 - nfree - nempty
@@ -44,11 +59,13 @@ idle = rec[count:]
 if len(idle):
     print(f"workgroups without a brick: {len(idle)}  begin mean {((idle[..., 0] - t0) * 0.01).mean():.2f}  last end {((idle[..., 1] - t0) * 0.01).max():.2f} us")
 else:
-    print(f"every workgroup has work: {listed} bricks for 8192 workgroups (some take a second brick)")
+    print(f"every workgroup has work: {listed} bricks for {G} workgroups (some take a second brick)")
 hist, edges = np.histogram(e[:count].max(axis=1), bins=12)
 print("end-time histogram of working workgroups (us):", [(round(float(a), 1), int(c)) for a, c in zip(edges[:-1], hist)])
-region = ws[256:256 + nb * 4 * 4].view(torch.int32).cpu().numpy()      # the list: walked bricks from the front of its region, the others from its back
-lst = np.array([region[e] if e < nwalk else region[len(region) - 1 - (e - nwalk)] for e in range(count)])
+_, cap, _, second_off = capi.integrate_list_layout(res)
+region = ws[second_off:second_off + cap * 4].view(torch.int32).cpu().numpy()      # the ordered list: walked bricks from the front of its region, the others from its back
+n2 = int(pair2[0])
+lst = np.array([region[e] if e < n2 else region[cap - 1 - (e - n2)] for e in range(count)])
 dur = (work[..., 1] - work[..., 0]) * 0.01
 order = np.argsort(-dur.max(axis=1))[:16]
 print("slowest workgroups: duration per wave (us), classes, lane-0 voxels written, brick (bx, by, bz)")

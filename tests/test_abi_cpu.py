@@ -37,7 +37,7 @@ def test_ctypes_tables_cover_the_headers():
     assert set(declared("xslam_amd_pipeline.h")) == set(pl._SIGS)
     assert capi.abi_version() == 1
     assert capi.icp_workspace_bytes() > 0 and capi.tsdf_reduce_workspace_bytes() > 0
-    assert capi.integrate_workspace_bytes([512, 512, 512]) == 256 + 8 * 128 * 256 * 4 + 8 * 128 * 256 * 4 * 4 + (1 << 20) + 8 * 128 * 256 * 4   # header + brick list + box classes (a word per wave-sized box) + the call's own depth-tile table + the list in the order it is taken
+    assert capi.integrate_workspace_bytes([512, 512, 512]) == 256 + 8192 * 4 + 8 * 128 * 256 * 4 + 8 * 128 * 256 * 4 * 4 + (1 << 20) + 8 * 128 * 256 * 4   # header + update counts (a word per workgroup) + brick list + box classes (a word per wave-sized box) + the call's own depth-tile table + the list in the order it is taken
     assert capi.depth_tiles_bytes(480, 640) == (60 * 80 + 15 * 10) * 8
     # host-only entry point: unpacking the 27 sums into the symmetric system (ICP.cu:419-428)
     import numpy as np

@@ -696,7 +696,29 @@ def test_bricks_with_planes_to_walk_are_taken_first(dev):
         region = host[second_off:second_off + cap * 4].view(np.int32)
         words = host[class_off:class_off + cap * 16].view(np.uint32).reshape(cap, 4)
         walked = lambda wd: (8 - (wd & 0xff).astype(np.int64) - ((wd >> 8) & 0xff).astype(np.int64)).sum(axis=1)
+        check_two_entry_bricks(region[:nwalk], words[:nwalk], region[cap - nother:])
         return region[:nwalk], region[cap - nother:][::-1], walked(words[:nwalk]), walked(words[cap - nother:])
+
+    def check_two_entry_bricks(front, wf, back):
+        """A brick one of whose boxes walks six planes or more has two neighbouring entries in the front run (a launch this small lasts as
+        long as its longest wave): the first streams the free planes and walks the half of each box's walked planes next to them, the second
+        (bit 19 in its words: nothing to stream) the other half — together the box's own word; every other brick has one entry."""
+        per_box = lambda wd: 8 - (wd & 0xff).astype(np.int64) - ((wd >> 8) & 0xff).astype(np.int64)
+        assert len(np.unique(back)) == len(back) and not set(back.tolist()) & set(front.tolist())
+        i, twice = 0, 0
+        while i < len(front):
+            if i + 1 < len(front) and front[i] == front[i + 1]:
+                a_, b_ = wf[i], wf[i + 1]
+                assert not (a_ >> 19 & 1).any() and (b_ >> 19 & 1).all()
+                wa, wb = per_box(a_), per_box(b_)
+                assert (wa + wb).max() >= 6 and (wb == (wa + wb) // 2).all()
+                assert ((a_ & 0xff) == (b_ & 0xff) - wa).all() and (((a_ >> 8) & 0xff) - wb == ((b_ >> 8) & 0xff)).all()   # the halves tile the box's walked planes
+                assert ((a_ >> 16 & 1) == (b_ >> 16 & 1)).all()
+                twice += 1; i += 2
+            else:
+                assert not (wf[i] >> 19 & 1).any() and per_box(wf[i]).max() < 6
+                i += 1
+        assert len(np.unique(front)) == len(front) - twice and twice > 0
 
     for k in (0, 5):
         depth = torch.from_numpy(synth.s1_frame(k).astype(np.int16)).cuda()
@@ -710,7 +732,7 @@ def test_bricks_with_planes_to_walk_are_taken_first(dev):
         ids = listed(host)
         front, back, w_front, w_back = ordered(host)
         assert len(front) > 0 and len(back) > 0
-        assert np.array_equal(np.sort(np.concatenate([front, back])), np.sort(ids))
+        assert np.array_equal(np.unique(np.concatenate([front, back])), np.sort(ids))
         assert (w_front > 0).all() and (w_back == 0).all()
         assert int(w_front.sum()) == int(host[204:208].view(np.int32)[0])        # header word 51: planes walked, counted as they were classified
         # a wider list classified ahead, its classes decided again for the pose itself
@@ -725,7 +747,7 @@ def test_bricks_with_planes_to_walk_are_taken_first(dev):
         wide = listed(host)
         f2, b2, w2f, w2b = ordered(host)
         assert set(ids.tolist()) <= set(wide.tolist())
-        assert np.array_equal(np.sort(np.concatenate([f2, b2])), np.sort(wide))
+        assert np.array_equal(np.unique(np.concatenate([f2, b2])), np.sort(wide))
         assert (w2f > 0).all() and (w2b == 0).all()
         # the same bricks of the frustum have planes to walk (+ bricks of the wider list the tiles cannot decide)
         assert set(front.tolist()) <= set(f2.tolist()) and not (set(f2.tolist()) - set(front.tolist())) & set(ids.tolist())

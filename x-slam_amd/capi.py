@@ -389,9 +389,10 @@ def integrate_list_layout(res, nz=None):
     r = _ia(res, 3)
     nz = int(r[2]) if nz is None else nz
     cap = -(-int(r[0]) // 32) * -(-int(r[1]) // 8) * -(-nz // 2)
-    list_bytes = (256 + cap * 4 + 255) // 256 * 256
+    first = 256 + 8192 * 4     # the header and the update counts' room (a word per workgroup of the brick kernel) lie in front
+    list_bytes = (first + cap * 4 + 255) // 256 * 256
     class_bytes = (cap * 16 + 255) // 256 * 256
-    return 256, cap, list_bytes, list_bytes + class_bytes + (1 << 20)
+    return first, cap, list_bytes, list_bytes + class_bytes + (1 << 20)
 
 
 def tsdf_reduce_workspace_bytes():

@@ -216,6 +216,7 @@ struct IntegrateArgs {
     unsigned long long *updated;  // optional device counter
     const float *depth_max;       // optional: largest valid depth of the frame (device)
     int *brick_list; unsigned *brick_count;  // work list of the two-phase path: the region the integrate kernel reads, the workspace header
+    unsigned *count_room;                    // the brick kernel's update counts, a word per workgroup (room_count_add)
     unsigned list_cap, pair_word;            // entries a list region holds; header word of the ListPair that goes with brick_list (PAIR_*)
     int bricks_x, bricks_y, bricks_z, brick_z;  // brick_z: planes per brick (runtime; BRICK_Z by default)
     unsigned kflags;              // KF_*
@@ -595,7 +596,7 @@ template <bool MAX> __device__ __forceinline__ float fold64(float v) {  // over 
 // nearest pixel is invalid is not written (Dp = 0: TsdfFusion.cu:128-150).  What is left of the per-voxel work is finding that pixel
 // and one depth gather (integrate_valid_column); with 0.2 % of a frame's pixels invalid nearly every box sees one, and before this they
 // all walked (bench.py roofline_s2.noisy).
-enum : unsigned { BOX_EDGE_BIT = 1u << 17, BOX_SPECKLE_BIT = 1u << 18 };
+enum : unsigned { BOX_EDGE_BIT = 1u << 17, BOX_SPECKLE_BIT = 1u << 18, BOX_NO_STREAM_BIT = 1u << 19 };   // NO_STREAM: see list_append (a brick in two entries)
 #define XS_EDGE_CMIN 0.05f
 __device__ __forceinline__ unsigned box_word(int n_free, int n_empty, int falls, bool edge = false, bool speckle = false) {
     return (unsigned)n_free | ((unsigned)n_empty << 8) | ((unsigned)falls << 16) | (edge ? (unsigned)BOX_EDGE_BIT : 0u) | (speckle ? (unsigned)BOX_SPECKLE_BIT : 0u);
@@ -727,6 +728,46 @@ __device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a
     return (unsigned)(ze - zb);
 }
 
+// The same column with ALL its planes requested at once (XS_FREE_DMA): by LDS-DMA (global_load_lds_dword: no destination register), a
+// plane's three rows into a 768-byte slot of the wave's room, then one wait and the planes are retired out of LDS.  The rolling pipeline
+// above keeps two planes of a wave in flight (six registers per lane; four spill next to the walk), so a wave that streams a box's eight
+// planes is four memory round trips long — 7 us of a launch whose walks take 9-14 (scene S1: the streaming workgroups wait for the slots
+// those hold, and their second round ends the launch) — where this is one.  dma_lds: the room's LDS byte address; room: the same, as a pointer.
+enum { DMA_SLOT_BYTES = 3 * 256, DMA_PLANES = 8 };
+__device__ __forceinline__ void lds_dma3(unsigned voff, const void *pv, const void *pg, const void *pw, unsigned lds) {
+    unsigned keep;
+    const unsigned l1 = lds + 256, l2 = lds + 512;
+    // M0 holds the LDS address of lane 0's word; the compiler does not preserve it around a statement, so it is saved and put back.
+    // (s_nop 4 first: a base pointer the compiler has just fetched back from a spill lane (v_readlane) needs five wait states before a
+    // vector-memory instruction reads it, and the compiler pads nothing inside a statement)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(pv), "s"(pg), "s"(pw), "s"(lds), "s"(l1), "s"(l2) : "memory");
+}
+__device__ __forceinline__ unsigned integrate_free_column_dma(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int zb, int ze,
+                                                              unsigned dma_lds, const unsigned *room) {
+    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
+    const int n = ze - zb;   // <= DMA_PLANES (the caller's test)
+    unsigned poff = off;
+#pragma unroll 1
+    for (int j = 0; j < n; ++j, poff += plane) lds_dma3(poff, bv, bg, bw, dma_lds + (unsigned)j * DMA_SLOT_BYTES);   // value | grad | weight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned lane = threadIdx.x;
+#pragma unroll 1
+    for (int j = 0; j < n; ++j, off += plane) {
+        const float v = __uint_as_float(room[j * 192 + lane]), g = __uint_as_float(room[j * 192 + 64 + lane]);
+        const int w = (int)room[j * 192 + 128 + lane];
+        float ov, og; int ow;
+        running_mean(a.max_weight, cfloat(1.0f, 0.0f), v, g, w, ov, og, ow);
+        if ((__float_as_uint(ov) ^ __float_as_uint(v)) | always) *reinterpret_cast<float *>(bv + off) = ov;
+        if ((unsigned)(ow ^ w) | always) *reinterpret_cast<int *>(bw + off) = ow;
+        if ((__float_as_uint(og) ^ __float_as_uint(g)) | always) *reinterpret_cast<float *>(bg + off) = og;
+    }
+    return (unsigned)n;
+}
 
 // EDGE box: like integrate_free_column, but a voxel is updated only if it passes the reference's in-image test (TsdfFusion.cu:123-124) —
 // the one per-voxel decision left (see BOX_EDGE_BIT).  The exact path (voxel_pixel) decides it from
@@ -863,20 +904,38 @@ __device__ __forceinline__ void block_count_add(unsigned n_upd, unsigned long lo
         if (t) atomicAdd(slots + (b % nslots), (unsigned long long)t);
     }
 }
-enum { COUNT_SLOTS = 16 };  // in the workspace header, after the brick count (8-byte words 1..16)
-__global__ void k_fold_count(unsigned long long *slots, unsigned long long *updated) {
-    // one lane per slot, device-scope exchanges: the slots were written by atomics from every XCD, and a
-    // plain load here can be served from this XCD's L2 copy of the line (every workgroup of the integrate
-    // kernel pulled it in when it read the brick count next to them) — observed as lost counts when the
-    // clear in front of the classification was removed
-    __shared__ unsigned long long s_v[COUNT_SLOTS];
-    const int i = threadIdx.x;
-    if (i < COUNT_SLOTS) s_v[i] = atomicExch(&slots[i], 0ull);
+// The brick kernel's update counts: one word per workgroup (COUNT_ROOM_WORDS of them, behind the workspace's 256-byte header), each added to
+// by the one workgroup that owns it.  Round 5: they were 16 words in ONE cache line of the header, and atomics to a line are served one at a
+// time whatever the word (~8 ns each): a launch whose 2 200 workgroups with work each add once could not end before ~3 + 2 200 x 0.008 =
+// 21 us, whatever else was done to it (bricks in two entries, a smaller grid: no change until the counts moved;
+// profiles/r05_ab_count_room.txt) — and at 1024^3 8 192 workgroups x 8 ns = 65 us of an 80 us launch.
+enum { COUNT_ROOM_WORDS = 8192, WS_HEADER_BYTES = 256, WS_LIST_OFFSET = WS_HEADER_BYTES + COUNT_ROOM_WORDS * 4 };
+__device__ __forceinline__ void room_count_add(unsigned n_upd, unsigned *room) {
+    __shared__ unsigned s_cnt[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const unsigned s = wave_sum_u32(n_upd);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = s;
     __syncthreads();
-    if (i == 0) {
-        unsigned long long t = 0;
-        for (int k = 0; k < COUNT_SLOTS; ++k) t += s_v[k];
-        if (t) atomicAdd(updated, t);
+    if (tid == 0) {
+        const unsigned t = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        if (t) atomicAdd(room + (blockIdx.x % COUNT_ROOM_WORDS), t);   // (an atomic: a grid may be larger than the room)
+    }
+}
+enum { FOLD_COUNT_BLOCK = 1024 };
+__global__ void __launch_bounds__(FOLD_COUNT_BLOCK) k_fold_count(unsigned *room, unsigned long long *updated) {
+    // device-scope exchanges (which also leave the words zero for the next launch): the words were written by atomics from every XCD,
+    // and a plain load here can be served from this XCD's L2 copy of a line an earlier fold pulled in — observed as lost counts when the
+    // counts shared a line with the brick count that every workgroup reads
+    unsigned long long t = 0;
+    for (int i = threadIdx.x; i < COUNT_ROOM_WORDS; i += FOLD_COUNT_BLOCK) t += atomicExch(room + i, 0u);
+    __shared__ unsigned long long s_v[FOLD_COUNT_BLOCK / 64];
+    t = wave_sum_u64(t);
+    if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        for (int k = 0; k < FOLD_COUNT_BLOCK / 64; ++k) all += s_v[k];
+        if (all) atomicAdd(updated, all);
     }
 }
 
@@ -974,8 +1033,21 @@ __device__ __forceinline__ unsigned classify_brick_boxes(const IntegrateArgs &a,
 // What a workgroup does with the n bricks it holds in LDS (s_brick; their boxes' words in s_word, bit 31 = planes to walk): the first
 // wave ranks them inside the two runs, reserves room for both with one atomic, and all threads write the entries and the classes.
 // Call from every thread; s_pos: n words; s_base: 2 words.
+//
+// A brick in TWO entries (split, small launches only): a wave that walks a whole box inside a surface's band is one chain of ~8 x 1 500
+// instructions, and a wave alone on its SIMD issues at half the SIMD's rate (profiles/r05_valu_issue_calibration.txt: 2.3 ns per instruction
+// against 1.2 with two waves) — a launch whose bricks are all resident at once lasts as long as that chain (17-19 us of scene S1's 21) while
+// most SIMDs hold one such wave or none.  A brick with a box that walks >= SPLIT_MIN_PLANES planes therefore takes two neighbouring entries
+// of the front run: the first streams the boxes' free planes and walks the half of each box's walked planes next to them, the second walks
+// the half next to the empty planes and does not stream (BOX_NO_STREAM_BIT).  The halves are expressed in the class words themselves: the first entry counts the second's planes as empty,
+// the second counts the first's as free-and-not-to-be-streamed; every voxel is still visited once.
+#ifndef XS_SPLIT_MIN_PLANES
+#define XS_SPLIT_MIN_PLANES 6
+#endif
+enum { SPLIT_MIN_PLANES = XS_SPLIT_MIN_PLANES, POS_OTHER_BIT = 1u << 31, POS_SPLIT_BIT = 1u << 30 };
+__device__ __forceinline__ int box_walked_planes(unsigned word, int nz) { return nz - (int)(word & 0xffu) - (int)((word >> 8) & 0xffu); }
 __device__ __forceinline__ void list_append(const IntegrateArgs &a, unsigned *pair, int *region, unsigned n, const int *s_brick, const unsigned *s_word,
-                                            unsigned *s_pos, unsigned *s_base) {
+                                            unsigned *s_pos, unsigned *s_base, bool split) {
     const unsigned tid = threadIdx.x;
     if (tid < 64u) {
         unsigned nw = 0, no = 0;
@@ -984,9 +1056,17 @@ __device__ __forceinline__ void list_append(const IntegrateArgs &a, unsigned *pa
             const unsigned k = c + tid;
             const bool live = k < n;
             const bool walk = live && ((s_word[k * 4] | s_word[k * 4 + 1] | s_word[k * 4 + 2] | s_word[k * 4 + 3]) >> 31) != 0u;
-            const unsigned long long m1 = __ballot(walk), m2 = __ballot(live && !walk);
-            if (live) s_pos[k] = walk ? nw + (unsigned)__popcll(m1 & below) : (1u << 31) | (no + (unsigned)__popcll(m2 & below));
-            nw += (unsigned)__popcll(m1); no += (unsigned)__popcll(m2);
+            bool heavy = false;
+            if (split && walk) {
+                const int nz = min(a.brick_z, a.z1 - (a.z0 + (s_brick[k] >> 20) * a.brick_z));
+                const int most = max(max(box_walked_planes(s_word[k * 4], nz), box_walked_planes(s_word[k * 4 + 1], nz)),
+                                     max(box_walked_planes(s_word[k * 4 + 2], nz), box_walked_planes(s_word[k * 4 + 3], nz)));
+                heavy = most >= SPLIT_MIN_PLANES;
+            }
+            const unsigned long long m1 = __ballot(walk), m2 = __ballot(live && !walk), mh = __ballot(heavy);
+            if (live) s_pos[k] = walk ? (nw + (unsigned)__popcll(m1 & below) + (unsigned)__popcll(mh & below)) | (heavy ? (unsigned)POS_SPLIT_BIT : 0u)
+                                      : (unsigned)POS_OTHER_BIT | (no + (unsigned)__popcll(m2 & below));
+            nw += (unsigned)__popcll(m1) + (unsigned)__popcll(mh); no += (unsigned)__popcll(m2);
         }
         if (tid == 0 && n) {
             const unsigned long long was = list_reserve(pair, nw, no);
@@ -996,8 +1076,18 @@ __device__ __forceinline__ void list_append(const IntegrateArgs &a, unsigned *pa
     __syncthreads();
     for (unsigned i = tid; i < n * BOXES_PER_BRICK; i += blockDim.x) {
         const unsigned k = i / BOXES_PER_BRICK, r = s_pos[k];
-        const unsigned pos = (r >> 31) ? a.list_cap - 1u - (s_base[1] + (r & 0x7fffffffu)) : s_base[0] + r;
-        a.box_class[(size_t)pos * BOXES_PER_BRICK + i % BOXES_PER_BRICK] = s_word[i] & 0x7fffffffu;
+        const unsigned pos = (r >> 31) ? a.list_cap - 1u - (s_base[1] + (r & 0x7fffffffu)) : s_base[0] + (r & ~(unsigned)POS_SPLIT_BIT);
+        const unsigned word = s_word[i] & 0x7fffffffu;
+        if ((r >> 31) == 0u && (r & POS_SPLIT_BIT)) {
+            const int nz = min(a.brick_z, a.z1 - (a.z0 + (s_brick[k] >> 20) * a.brick_z));
+            const int wk = box_walked_planes(word, nz), h = wk >> 1;
+            a.box_class[(size_t)pos * BOXES_PER_BRICK + i % BOXES_PER_BRICK] = word + ((unsigned)h << 8);             // the second entry's planes: not this one's
+            a.box_class[(size_t)(pos + 1u) * BOXES_PER_BRICK + i % BOXES_PER_BRICK] =
+                ((word & ~(0xffu | BOX_EDGE_BIT | BOX_SPECKLE_BIT)) | ((word & 0xffu) + (unsigned)(wk - h))) | BOX_NO_STREAM_BIT;
+            if (i % BOXES_PER_BRICK == 0) { region[pos] = s_brick[k]; region[pos + 1u] = s_brick[k]; }
+            continue;
+        }
+        a.box_class[(size_t)pos * BOXES_PER_BRICK + i % BOXES_PER_BRICK] = word;
         if (i % BOXES_PER_BRICK == 0) region[pos] = s_brick[k];
     }
 }
@@ -1010,6 +1100,9 @@ __device__ __forceinline__ void list_append(const IntegrateArgs &a, unsigned *pa
 // faster: 12.5 us against 3.8 + 8.4) came out in an order that made the S2 launch 9 % slower (profiles/r04_ab_classify_fused.txt).
 // The second pair is zero when the kernel starts (the launcher clears it).
 struct BoxOrder { int *list; };
+#ifndef XS_SPLIT_HEAVY
+#define XS_SPLIT_HEAVY 1
+#endif
 #ifndef XS_ORDER_BATCH
 #define XS_ORDER_BATCH 32   // bricks per reservation beyond 4 096 listed ones.  A workgroup takes its batch in rounds of 8 bricks (8 lanes per box, 4 boxes): 64
                             // was eight dependent rounds (18 us at 1024^3's 12.5 K bricks), 32 is four — 1024^3 tracking +0.5-1 %, scene S2's whole call
@@ -1023,6 +1116,9 @@ __global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, c
     __shared__ unsigned s_word[ORDER_BATCH * BOXES_PER_BRICK], s_pos[ORDER_BATCH], s_base[2];
     __shared__ int s_brick[ORDER_BATCH];
     const unsigned batch = count <= 4096u ? 8u : (unsigned)ORDER_BATCH;
+    // (a launch that small has every brick resident at once and lasts as long as its longest wave: list_append, "a brick in TWO entries";
+    // a brick with >= SPLIT_MIN_PLANES >= 6 planes leaves room for both entries in a region laid out for 2-plane bricks)
+    const bool split = XS_SPLIT_HEAVY != 0 && count <= 4096u && a.brick_z >= SPLIT_MIN_PLANES && SPLIT_MIN_PLANES >= 4;
     for (unsigned e0 = blockIdx.x * batch; e0 < count; e0 += gridDim.x * batch) {
         const unsigned n = min(batch, count - e0);
         for (unsigned r = 0; r < n; r += 8u) {
@@ -1036,7 +1132,7 @@ __global__ void __launch_bounds__(256) k_classify_boxes(const IntegrateArgs a, c
             }
         }
         __syncthreads();
-        list_append(a, a.brick_count + PAIR_SECOND, ord.list, n, s_brick, s_word, s_pos, s_base);
+        list_append(a, a.brick_count + PAIR_SECOND, ord.list, n, s_brick, s_word, s_pos, s_base, split);
         __syncthreads();
     }
 }
@@ -1058,6 +1154,9 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
 // (~16 us -> ~4).  The frustum planes (brick test, column clip) stay those of the pose the list was classified with, widened: they
 // only bound the voxels that take the exact tests, and the host posts only after checking that the final pose's planes lie inside
 // them (xs_integrate_pose_covered); otherwise it posts an abandon command and the launch leaves without touching the volume.
+#ifndef XS_FREE_DMA
+#define XS_FREE_DMA 0
+#endif
 #ifndef XS_INTEGRATE_WAVES
 // Workgroups per CU = waves per SIMD the brick kernel is compiled for.  8 (64 VGPRs, 78 SGPRs) was round 3's choice: with the free-space
 // path and the class look-up next to the walk the instance the pipeline runs then spills 36-48 bytes per lane, and a spill is not free
@@ -1092,6 +1191,8 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     // whole kernel they push the voxel loop's own operands out (99 spilled scalars, ~30 v_readlane per voxel to fetch them
     // back — VALU slots, and this kernel is bound by VALU issue: 101 M wave instructions per S2 launch): they live in LDS.
     __shared__ ClipPlanes s_cp;
+    __shared__ unsigned s_dma[XS_FREE_DMA ? 4 : 1][XS_FREE_DMA ? DMA_PLANES * 192 : 1];   // a wave's room: eight planes x (value | grad | weight) rows
+    const unsigned dma_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&s_dma[XS_FREE_DMA ? threadIdx.y : 0][0]);
     float cp_word = 0.f;
     if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) cp_word = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
     // (A bit-reversed entry order for launches with fewer bricks than workgroups — so that list neighbours, the bricks of one surface, land
@@ -1134,12 +1235,13 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
                 const bool falls = ((word >> 16) & 1u) != 0u;
                 const int f0 = falls ? ze0 - nf : zb0, f1 = falls ? ze0 : zb0 + nf;       // free planes [f0, f1)
                 walk_lo = falls ? zb0 + ne : zb0 + nf; walk_hi = falls ? ze0 - nf : ze0 - ne;
-                if (nf > 0 && x < a.X && y < a.Y) {
+                if (nf > 0 && !(word & BOX_NO_STREAM_BIT) && x < a.X && y < a.Y) {
                     const size_t ubase = ((size_t)(f0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
                     char *fv = reinterpret_cast<char *>(a.value) + ubase, *fw = reinterpret_cast<char *>(a.weight) + ubase, *fg = reinterpret_cast<char *>(a.grad) + ubase;
                     const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
                     if (word & BOX_SPECKLE_BIT) n_upd += integrate_valid_column(a, ps, (word & BOX_EDGE_BIT) != 0u, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box that sees an invalid pixel)
                     else if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
+                    else if (XS_FREE_DMA && f1 - f0 <= DMA_PLANES) n_upd += integrate_free_column_dma(a, fv, fw, fg, foff, fplane, f0, f1, dma_lds, s_dma[threadIdx.y]);
                     else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, f0, f1);
                 }
                 if (walk_lo >= walk_hi) continue;
@@ -1165,7 +1267,7 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
         rec[0] = (unsigned)probe_t0; rec[1] = (unsigned)wall_clock64(); rec[2] = blockIdx.x < count ? (unsigned)a.box_class[entry(blockIdx.x) * BOXES_PER_BRICK + threadIdx.y] : 99u; rec[3] = (n_upd & 0xffu) | ((__builtin_amdgcn_s_getreg(0xF814) & 0xfu) << 8) | (__builtin_amdgcn_s_getreg(0xF804) << 16);   // + XCC_ID, HW_ID (wave, SIMD, pipe, CU, SH, SE)
     }
 #endif
-    if (a.updated) block_count_add(n_upd, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, COUNT_SLOTS);
+    if (a.updated) room_count_add(n_upd, a.count_room);
 }
 
 
@@ -1244,9 +1346,9 @@ extern "C" void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mail
 extern "C" void xs_integrate_set_signmap(void *signmap) { g_legacy.signmap = signmap; }
 extern "C" void xs_integrate_set_depth_tiles(const void *tiles) { g_legacy.depth_tiles = tiles; }
 enum { TILE_ROOM_BYTES = 1 << 20 };   // the workspace's own tile table: images of up to 131 072 tiles (e.g. 4096 x 2048 pixels); larger ones take the exact walk everywhere
-// workspace: 256-byte header | brick list (int per brick) | box classes (BOXES_PER_BRICK words per list entry) | the call's own depth tiles
+// workspace: 256-byte header | the update counts' room (COUNT_ROOM_WORDS words) | brick list (int per brick) | box classes (BOXES_PER_BRICK words per list entry) | the call's own depth tiles
 static size_t workspace_bricks(const int *res, int nz) { return (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2); }   // room for 2-plane bricks
-static size_t workspace_list_bytes(const int *res, int nz) { return (256 + workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255; }
+static size_t workspace_list_bytes(const int *res, int nz) { return (WS_LIST_OFFSET + workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255; }
 static size_t workspace_class_bytes(const int *res, int nz) { return (workspace_bricks(res, nz) * BOXES_PER_BRICK * sizeof(unsigned) + 255) & ~(size_t)255; }
 // ... | the list in the order the integrate kernel takes it (k_classify_boxes), after the tile room
 static size_t workspace_order_offset(const int *res, int nz) { return workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz) + TILE_ROOM_BYTES; }
@@ -1266,12 +1368,12 @@ static thread_local ClassesAhead g_classes_ahead = {nullptr, {}, {}, 1.0f};
  * updated_dev after the integrate kernel. */
 extern "C" int xs_integrate_workspace_clear(void *workspace, void *stream) {
     if (!workspace) return xs_set_error(hipErrorInvalidValue, "xs_integrate_workspace_clear: null pointer");
-    XS_CHECK(hipMemsetAsync(workspace, 0, 256, (hipStream_t)stream));
+    XS_CHECK(hipMemsetAsync(workspace, 0, WS_LIST_OFFSET, (hipStream_t)stream));
     return 0;
 }
 extern "C" int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, void *stream) {
     if (!workspace || !updated_dev) return xs_set_error(hipErrorInvalidValue, "xs_integrate_fold_counts: null pointer");
-    hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long *>(workspace) + 1, updated_dev);
+    hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(FOLD_COUNT_BLOCK), 0, (hipStream_t)stream, reinterpret_cast<unsigned *>((char *)workspace + WS_HEADER_BYTES), updated_dev);
     XS_CHECK(hipGetLastError());
     return 0;
 }
@@ -1313,7 +1415,8 @@ static bool far_end_first(const IntegrateArgs &a) {
 // the workspace's header, primary list region and capacity
 static void bind_workspace(IntegrateArgs &a, const int *res, int nz, void *workspace) {
     a.brick_count = (unsigned *)workspace;
-    a.brick_list = (int *)((char *)workspace + 256);
+    a.count_room = (unsigned *)((char *)workspace + WS_HEADER_BYTES);
+    a.brick_list = (int *)((char *)workspace + WS_LIST_OFFSET);
     a.list_cap = (unsigned)workspace_bricks(res, nz); a.pair_word = PAIR_PRIMARY;
 }
 static void bind_classes(IntegrateArgs &a, const int *res, int nz, void *workspace) {
@@ -1397,7 +1500,7 @@ extern "C" int xs_integrate_classify_ex(int rows, int cols, const float *intr4, 
     for (int p = 0; p < 6; ++p) a.fr.slack[p] *= slack_scale;
     bind_workspace(a, res, z1 - z0, workspace);
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));
+    if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR)) XS_CHECK(hipMemsetAsync(a.brick_count, 0, WS_LIST_OFFSET, st));
     // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
     // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
     static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");
@@ -1495,7 +1598,7 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
     load_mat(Rv2c18, a.R); load_vec(tv2c6, a.t);
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.voxel_size = voxel_size; a.threshold = threshold; a.updated = updated_dev; a.depth_max = depth_max_dev;
-    a.brick_list = nullptr; a.brick_count = nullptr; a.kflags = 0;
+    a.brick_list = nullptr; a.brick_count = nullptr; a.count_room = nullptr; a.kflags = 0;
     static const bool env_always = exp_env_set("XS_INTEGRATE_ALWAYS_STORE");   // measurement aid, as the flag
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
@@ -1546,7 +1649,7 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
         };
         if (!(flags & XS_INTEGRATE_LIST_IS_READY)) {   // (else: xs_integrate_classify has run on this stream for a covering pose)
             if (!(flags & XS_INTEGRATE_HEADER_IS_CLEAR))
-                XS_CHECK(hipMemsetAsync(a.brick_count, 0, 256, st));  // list pairs + update-count slots (the whole 256-byte header: one fill, where 136 bytes take two)
+                XS_CHECK(hipMemsetAsync(a.brick_count, 0, WS_LIST_OFFSET, st));  // list pairs + the update counts' room: one fill
             launch_classification(a, res, nz, workspace, use_tiles ? tile_table() : nullptr, BoxSlack{0.f, 0.f, 0.f}, st);
         } else if (use_tiles) {
             if (classes_ahead) bind_ordered_list(a, res, nz, workspace);
@@ -1576,7 +1679,7 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
         if (ev0 || ev1) hipExtLaunchKernelGGL(kern, dim3(g), block, env_lds, st, ev0, ev1, 0, a);
         else hipLaunchKernelGGL(kern, dim3(g), block, env_lds, st, a);
         if (updated_dev && !(flags & XS_INTEGRATE_NO_FOLD))
-            hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(a.brick_count) + 1, updated_dev);
+            hipLaunchKernelGGL(k_fold_count, dim3(1), dim3(FOLD_COUNT_BLOCK), 0, st, a.count_room, updated_dev);
     } else {
         if (posted) return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: posted launch without a brick list");
         int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), zsplit = 1;
