@@ -728,46 +728,6 @@ __device__ __forceinline__ unsigned integrate_free_column(const IntegrateArgs &a
     return (unsigned)(ze - zb);
 }
 
-// The same column with ALL its planes requested at once (XS_FREE_DMA): by LDS-DMA (global_load_lds_dword: no destination register), a
-// plane's three rows into a 768-byte slot of the wave's room, then one wait and the planes are retired out of LDS.  The rolling pipeline
-// above keeps two planes of a wave in flight (six registers per lane; four spill next to the walk), so a wave that streams a box's eight
-// planes is four memory round trips long — 7 us of a launch whose walks take 9-14 (scene S1: the streaming workgroups wait for the slots
-// those hold, and their second round ends the launch) — where this is one.  dma_lds: the room's LDS byte address; room: the same, as a pointer.
-enum { DMA_SLOT_BYTES = 3 * 256, DMA_PLANES = 8 };
-__device__ __forceinline__ void lds_dma3(unsigned voff, const void *pv, const void *pg, const void *pw, unsigned lds) {
-    unsigned keep;
-    const unsigned l1 = lds + 256, l2 = lds + 512;
-    // M0 holds the LDS address of lane 0's word; the compiler does not preserve it around a statement, so it is saved and put back.
-    // (s_nop 4 first: a base pointer the compiler has just fetched back from a spill lane (v_readlane) needs five wait states before a
-    // vector-memory instruction reads it, and the compiler pads nothing inside a statement)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
-                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(pv), "s"(pg), "s"(pw), "s"(lds), "s"(l1), "s"(l2) : "memory");
-}
-__device__ __forceinline__ unsigned integrate_free_column_dma(const IntegrateArgs &a, char *bv, char *bw, char *bg, unsigned off, unsigned plane, int zb, int ze,
-                                                              unsigned dma_lds, const unsigned *room) {
-    const unsigned always = (a.kflags & KF_ALWAYS_STORE) ? 1u : 0u;
-    const int n = ze - zb;   // <= DMA_PLANES (the caller's test)
-    unsigned poff = off;
-#pragma unroll 1
-    for (int j = 0; j < n; ++j, poff += plane) lds_dma3(poff, bv, bg, bw, dma_lds + (unsigned)j * DMA_SLOT_BYTES);   // value | grad | weight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned lane = threadIdx.x;
-#pragma unroll 1
-    for (int j = 0; j < n; ++j, off += plane) {
-        const float v = __uint_as_float(room[j * 192 + lane]), g = __uint_as_float(room[j * 192 + 64 + lane]);
-        const int w = (int)room[j * 192 + 128 + lane];
-        float ov, og; int ow;
-        running_mean(a.max_weight, cfloat(1.0f, 0.0f), v, g, w, ov, og, ow);
-        if ((__float_as_uint(ov) ^ __float_as_uint(v)) | always) *reinterpret_cast<float *>(bv + off) = ov;
-        if ((unsigned)(ow ^ w) | always) *reinterpret_cast<int *>(bw + off) = ow;
-        if ((__float_as_uint(og) ^ __float_as_uint(g)) | always) *reinterpret_cast<float *>(bg + off) = og;
-    }
-    return (unsigned)n;
-}
 
 // EDGE box: like integrate_free_column, but a voxel is updated only if it passes the reference's in-image test (TsdfFusion.cu:123-124) —
 // the one per-voxel decision left (see BOX_EDGE_BIT).  The exact path (voxel_pixel) decides it from
@@ -926,8 +886,13 @@ __global__ void __launch_bounds__(FOLD_COUNT_BLOCK) k_fold_count(unsigned *room,
     // device-scope exchanges (which also leave the words zero for the next launch): the words were written by atomics from every XCD,
     // and a plain load here can be served from this XCD's L2 copy of a line an earlier fold pulled in — observed as lost counts when the
     // counts shared a line with the brick count that every workgroup reads
+    // (all of a thread's exchanges go out before the first result is used: one round trip, where a loop that adds as it goes takes eight)
+    unsigned v[COUNT_ROOM_WORDS / FOLD_COUNT_BLOCK];
+#pragma unroll
+    for (int k = 0; k < COUNT_ROOM_WORDS / FOLD_COUNT_BLOCK; ++k) v[k] = atomicExch(room + threadIdx.x + k * FOLD_COUNT_BLOCK, 0u);
     unsigned long long t = 0;
-    for (int i = threadIdx.x; i < COUNT_ROOM_WORDS; i += FOLD_COUNT_BLOCK) t += atomicExch(room + i, 0u);
+#pragma unroll
+    for (int k = 0; k < COUNT_ROOM_WORDS / FOLD_COUNT_BLOCK; ++k) t += v[k];
     __shared__ unsigned long long s_v[FOLD_COUNT_BLOCK / 64];
     t = wave_sum_u64(t);
     if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6] = t;
@@ -1154,9 +1119,6 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
 // (~16 us -> ~4).  The frustum planes (brick test, column clip) stay those of the pose the list was classified with, widened: they
 // only bound the voxels that take the exact tests, and the host posts only after checking that the final pose's planes lie inside
 // them (xs_integrate_pose_covered); otherwise it posts an abandon command and the launch leaves without touching the volume.
-#ifndef XS_FREE_DMA
-#define XS_FREE_DMA 0
-#endif
 #ifndef XS_INTEGRATE_WAVES
 // Workgroups per CU = waves per SIMD the brick kernel is compiled for.  8 (64 VGPRs, 78 SGPRs) was round 3's choice: with the free-space
 // path and the class look-up next to the walk the instance the pipeline runs then spills 36-48 bytes per lane, and a spill is not free
@@ -1191,8 +1153,6 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     // whole kernel they push the voxel loop's own operands out (99 spilled scalars, ~30 v_readlane per voxel to fetch them
     // back — VALU slots, and this kernel is bound by VALU issue: 101 M wave instructions per S2 launch): they live in LDS.
     __shared__ ClipPlanes s_cp;
-    __shared__ unsigned s_dma[XS_FREE_DMA ? 4 : 1][XS_FREE_DMA ? DMA_PLANES * 192 : 1];   // a wave's room: eight planes x (value | grad | weight) rows
-    const unsigned dma_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&s_dma[XS_FREE_DMA ? threadIdx.y : 0][0]);
     float cp_word = 0.f;
     if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) cp_word = reinterpret_cast<const float *>(&a.cp)[threadIdx.x];
     // (A bit-reversed entry order for launches with fewer bricks than workgroups — so that list neighbours, the bricks of one surface, land
@@ -1241,7 +1201,6 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
                     const unsigned foff = (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u, fplane = (unsigned)a.Y * (unsigned)a.vstep;
                     if (word & BOX_SPECKLE_BIT) n_upd += integrate_valid_column(a, ps, (word & BOX_EDGE_BIT) != 0u, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box that sees an invalid pixel)
                     else if (word & BOX_EDGE_BIT) n_upd += integrate_edge_column(a, ps, fv, fw, fg, foff, fplane, x, y, f0, f1);   // (a box on the frustum's side)
-                    else if (XS_FREE_DMA && f1 - f0 <= DMA_PLANES) n_upd += integrate_free_column_dma(a, fv, fw, fg, foff, fplane, f0, f1, dma_lds, s_dma[threadIdx.y]);
                     else n_upd += integrate_free_column(a, fv, fw, fg, foff, fplane, f0, f1);
                 }
                 if (walk_lo >= walk_hi) continue;
