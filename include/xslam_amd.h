@@ -91,7 +91,7 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
 /* xs_integrate_scaled with its two bracketing launches under the caller's control (both are tiny, but each is a dependent
  * dispatch on the stream: ~14 us of a 390 us frame).  flags: XS_INTEGRATE_HEADER_IS_CLEAR — the caller has cleared the
  * workspace header since the previous call (xs_integrate_workspace_clear, on any stream ordered before this call);
- * XS_INTEGRATE_NO_FOLD — the voxel count stays in the header's slots until the caller folds it into updated_dev
+ * XS_INTEGRATE_NO_FOLD — the voxel count stays in the workspace (a word per workgroup, behind the header) until the caller folds it into updated_dev
  * (xs_integrate_fold_counts, ordered after this call and before the next clear).  updated_dev non-NULL still enables
  * the counting.  flags = 0 is xs_integrate_scaled. */
 #define XS_INTEGRATE_HEADER_IS_CLEAR 1u
