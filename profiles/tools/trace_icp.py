@@ -21,6 +21,7 @@ for l in (2, 1, 0):
     tr = np.zeros(768 * 16, np.uint64)
     assert capi._lib.xs_debug_icp_trace(tr.ctypes.data) == 0
     where = tr.reshape(768, 16)[:blocks, 10]                      # XCC_ID << 32 | HW_ID of the workgroup's first wave
+    sub = tr.reshape(768, 16)[:blocks, 11:15].astype(np.int64)    # inside the fold (two-pass instances): pass 0 written / added, pass 1 written / added
     tr = tr.reshape(768, 16)[:blocks, :10].astype(np.int64)
     base = tr[:, 0].min()
     last = int(np.argmax(tr[:, 9]))            # only the last workgroup stamps 7..9 in this launch (older stamps are smaller)
@@ -29,6 +30,11 @@ for l in (2, 1, 0):
     for i, nme in enumerate(names):
         col = rel[:, i] if i <= 6 else rel[last:last + 1, i]
         print(f"   {nme:14s} last wg {rel[last, i]:7.2f} us   all wgs min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f}")
+    if sub.min() > 0:
+        st = np.concatenate([tr[:, 2:3], sub, tr[:, 3:4]], axis=1)
+        d = np.diff(st, axis=1) * 0.01
+        print("   inside the fold, first wave of each workgroup (median / p90 us): " + "  ".join(f"{n} {np.median(d[:, i]):.2f} / {np.percentile(d[:, i], 90):.2f}" for i, n in enumerate(
+              ["pixels -> pass 0 written", "-> pass 0 added", "-> pass 1 written", "-> pass 1 added", "-> record summed (barrier)"])))
     # the same per workgroup: how long each phase took, and how that goes with the number of workgroups sharing its CU
     cu = ((where >> 32) & 0xF) * 4096 + ((where >> 8) & 0xFF)       # (XCC, SE / SH / CU fields of HW_ID)
     _, inv, cnt = np.unique(cu, return_inverse=True, return_counts=True)

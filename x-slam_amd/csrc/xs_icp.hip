@@ -497,6 +497,7 @@ __global__ void __launch_bounds__(64 * WAVES)
             tile[(wave * PV + NS % PV) * RS + lane] = one;
             if constexpr (BAL) { if (wave < EXTRA) tile[((WAVES + wave) * PV + NS % PV) * RS + lane] = one2; }
         }
+        XS_STAMP(11 + 2 * (pass & 1));   // (trace build: this wave's products of the pass are on their way to LDS)
         __syncthreads();
         const int h = threadIdx.x % SPLIT;
 #pragma unroll
@@ -529,6 +530,7 @@ __global__ void __launch_bounds__(64 * WAVES)
             const int w = r / PV, v = r % PV;
             if (h == 0 && pass * PV + v <= NS) smem[w][pass * PV + v] = (s0 + s1) + (s2 + s3);
         }
+        XS_STAMP(12 + 2 * (pass & 1));   // (trace build: this wave's rows of the pass are added)
     }
     }
     __syncthreads();
