@@ -149,6 +149,35 @@ int xs_kf_save_checkpoint(void *kf, const char *path);
 int xs_kf_load_checkpoint(void *kf, const char *path);
 int xs_kf_save_tsdf_volume(void *kf, const char *path);
 
+/* ---- The reference's own call shape (x-slam_amd/host/reference_shape.hpp) ---------------------------------------------------------
+ * The per-frame sequence of Experiments/test_xkinect_fusion/main.cpp:46-60 + KinectFusionReconstruction.cpp:147-332 over nothing but the
+ * reference-signature launchers (bilateralFilter, pyrDown, createVMap / createNMap, estimateCombined per iteration, integrateTsdfVolume,
+ * raycast, resizeVMap / resizeNMap — x-slam_amd/host/xs_launchers.hpp) with the reference's argument lists and a stream drain wherever
+ * the reference's launcher drains the device: what swapping the library and changing nothing else gives.  Same results as xs_kf_* bit
+ * for bit (tests/test_reference_shape_gpu.py); bench.py times it as legs.reference_call_shape.  Config: the same flat YAML. */
+void *xs_refshape_create(const char *yaml_text);
+void xs_refshape_destroy(void *rs);
+/* main.cpp:50-58: DeviceArray2D<ushort>::upload of a host frame (dense rows), then ProcessFrame */
+int xs_refshape_process_frame_host(void *rs, const uint16_t *depth_host);
+/* ProcessFrame on a frame already in device memory (main.cpp:57-60 times ProcessFrame alone) */
+int xs_refshape_process_frame(void *rs, const uint16_t *depth_dev, size_t step_bytes);
+int xs_refshape_frame_id(void *rs);
+void xs_refshape_get_world2camera(void *rs, int idx, float *out32);
+int xs_refshape_download_volume(void *rs, float *value, int *weight, float *grad);
+int xs_refshape_download_map(void *rs, int which, int level, float *out);   /* as xs_kf_download_map */
+/* per ICP iteration of the last frame: the 54 sums estimateCombined returned (no inlier count: ICP.h:24-31 has none); returns #doubles */
+int xs_refshape_icp_log(void *rs, double *out, int capacity);
+/* ComputeLocalTsdf_hessian / ComputeLocalTsdf_loss through their TsdfFusion.h:48-60 signatures (PtrStepSz<ushort> depth on the device,
+ * MatD33 = 36 floats / devDComplex3 = 12 floats, or Mat33 = 9 / float3 = 3; gt_dev: X*Y*Z floats, dense).  out4 = the returned float4
+ * {loss, gradient, second derivative, count}, out2 = float2 {loss, count}.  with_volumes: the per-voxel scratch volumes of the reference's
+ * thrust vectors are filled too and copied to volumes_host (real | grad | hessian | count as int32: 4 x N^3 words; loss: real | count). */
+int xs_refshape_hessian(const uint16_t *depth_dev, size_t depth_step, int rows, int cols, const float *intr4, const int *res3, float voxel_size,
+                        const float *Rv2c36, const float *tv2c12, float tranc_dist, const float *gt_dev, int with_volumes, float *out4,
+                        float *volumes_host);
+int xs_refshape_loss(const uint16_t *depth_dev, size_t depth_step, int rows, int cols, const float *intr4, const int *res3, float voxel_size,
+                     const float *Rv2c9, const float *tv2c3, float tranc_dist, const float *gt_dev, int with_volumes, float *out2,
+                     float *volumes_host);
+
 #ifdef __cplusplus
 }
 #endif

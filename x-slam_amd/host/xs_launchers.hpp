@@ -21,7 +21,7 @@ inline void check_rc(int rc, const char *what) {
 inline void sync() { hipSafeCall(hipStreamSynchronize(current_stream())); }
 // per-process scratch the launchers need (the reference allocates gbuf / thrust vectors per call)
 struct Scratch {
-    DeviceArray<unsigned char> icp_ws, reduce_ws;
+    DeviceArray<unsigned char> icp_ws, reduce_ws, integrate_ws;
     DeviceArray<double> sums;
     static Scratch &get() { static Scratch s; return s; }
     void *icp() {
@@ -30,6 +30,12 @@ struct Scratch {
             check_rc(xs_icp_workspace_init(icp_ws.ptr(), current_stream()), "icp workspace");
         }
         return icp_ws.ptr();
+    }
+    // the integrate kernel's brick list, box classes and tile table for a volume of this size (include/xslam_amd.h: xs_integrate_workspace_bytes)
+    void *integrate(const int *res) {
+        const size_t bytes = xs_integrate_workspace_bytes(res, res[2]);
+        if (integrate_ws.size() != bytes) integrate_ws.create(bytes);
+        return integrate_ws.ptr();
     }
     void *reduce() { if (reduce_ws.size() != xs_tsdf_reduce_workspace_bytes()) reduce_ws.create(xs_tsdf_reduce_workspace_bytes()); return reduce_ws.ptr(); }
     double *sum_buf() { if (sums.size() != 64) sums.create(64); return sums.ptr(); }
@@ -45,7 +51,9 @@ inline void initVolume(PtrStep<short> /*volume: allocated but never read in the 
     xs_host::sync();
 }
 
-// TsdfFusion.h:40-45.  depthScaled is kept resident (create() is a no-op when the size is unchanged).
+// TsdfFusion.h:40-45.  depthScaled is kept resident (create() is a no-op when the size is unchanged); the two launches of
+// TsdfFusion.cu:173-201 — scaleDepthKernal, tsdfFusionKernal — with the second one walking the brick list the library keeps in the
+// per-process scratch (the same voxels bit for bit as the walk over every voxel: tests/test_integrate_gpu.py).
 inline void integrateTsdfVolume(const PtrStepSz<ushort> &depth, const Intr &intr, int max_weight, const int3 &volume_resolution,
                                 float voxel_size, const MatS33 &Rv2c, const devComplex3 &tv2c, const devComplex3 & /*tc2v*/,
                                 float tranc_dist, PtrStep<float> value_volume, PtrStep<int> weight_volume, PtrStep<float> grad_volume,
@@ -53,10 +61,12 @@ inline void integrateTsdfVolume(const PtrStepSz<ushort> &depth, const Intr &intr
                                 unsigned long long *updated_dev = nullptr, bool synchronise = true) {
     depthScaled.create(depth.rows, depth.cols);
     const int res[3] = {volume_resolution.x, volume_resolution.y, volume_resolution.z};
-    xs_host::check_rc(xs_integrate_tsdf_volume(depth.data, depth.step, depth.rows, depth.cols, &intr.fx, max_weight, res, voxel_size,
-                                               &Rv2c.data[0].x.re, &tv2c.x.re, tranc_dist, value_volume.data, weight_volume.data,
-                                               grad_volume.data, value_volume.step, depthScaled.ptr(), depthScaled.step(), threshold, 0,
-                                               res[2], updated_dev, xs_host::current_stream()), "integrateTsdfVolume");
+    hipStream_t st = xs_host::current_stream();
+    xs_host::check_rc(xs_scale_depth(depth.data, depth.step, depth.rows, depth.cols, depthScaled.ptr(), depthScaled.step(), st), "scaleDepth");
+    xs_host::check_rc(xs_integrate_scaled(depthScaled.ptr(), depthScaled.step(), depth.rows, depth.cols, &intr.fx, max_weight, res, voxel_size,
+                                          &Rv2c.data[0].x.re, &tv2c.x.re, tranc_dist, value_volume.data, weight_volume.data, grad_volume.data,
+                                          value_volume.step, threshold, 0, res[2], updated_dev, nullptr, xs_host::Scratch::get().integrate(res), st),
+                      "integrateTsdfVolume");
     if (synchronise) xs_host::sync();
 }
 

@@ -65,6 +65,17 @@ _SIGS = {
     "xs_kf_save_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_load_checkpoint": (C.c_int, [_vp, C.c_char_p]),
     "xs_kf_save_tsdf_volume": (C.c_int, [_vp, C.c_char_p]),
+    "xs_refshape_create": (_vp, [C.c_char_p]),
+    "xs_refshape_destroy": (None, [_vp]),
+    "xs_refshape_process_frame_host": (C.c_int, [_vp, _vp]),
+    "xs_refshape_process_frame": (C.c_int, [_vp, _vp, _sz]),
+    "xs_refshape_frame_id": (C.c_int, [_vp]),
+    "xs_refshape_get_world2camera": (None, [_vp, C.c_int, _f32p]),
+    "xs_refshape_download_volume": (C.c_int, [_vp, _f32p, _i32p, _f32p]),
+    "xs_refshape_download_map": (C.c_int, [_vp, C.c_int, C.c_int, _f32p]),
+    "xs_refshape_icp_log": (C.c_int, [_vp, _f64p, C.c_int]),
+    "xs_refshape_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, C.c_int, _f32p, _f32p]),
+    "xs_refshape_loss": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, C.c_int, _f32p, _f32p]),
 }
 for _n, (_r, _a) in _SIGS.items():
     _f = getattr(_lib, _n)
@@ -326,3 +337,103 @@ class KinectFusion:
 
     def save_tsdf_volume(self, path):
         _lib.xs_kf_save_tsdf_volume(self.h, path.encode())
+
+
+class ReferenceCallShape:
+    """Handle to a C++ ReferenceCallShape (x-slam_amd/host/reference_shape.hpp): the reference's own per-frame call
+    sequence over the reference-signature launchers alone, a stream drain where the reference drains the device."""
+
+    def __init__(self, params):
+        text = params if isinstance(params, str) else yaml_text(params)
+        cfg = {}
+        for line in text.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                cfg[k.strip()] = v.split("#")[0].strip()
+        self.h = _lib.xs_refshape_create(text.encode())
+        if not self.h:
+            raise ValueError("xs_refshape_create failed (missing config key?)")
+        self.res = [int(cfg[f"tsdf_size_{a}"]) for a in "xyz"]
+        self.width, self.height = int(cfg["depth_width"]), int(cfg["depth_height"])
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.xs_refshape_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process_frame(self, depth_dev, step_bytes=None):
+        ptr = depth_dev if isinstance(depth_dev, int) else depth_dev.data_ptr()
+        return _lib.xs_refshape_process_frame(self.h, ptr, step_bytes if step_bytes is not None else self.width * 2)
+
+    def process_frame_host(self, depth_u16):
+        d = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        return _lib.xs_refshape_process_frame_host(self.h, d.ctypes.data)
+
+    @property
+    def frame_id(self):
+        return _lib.xs_refshape_frame_id(self.h)
+
+    def world2camera(self, idx=-1):
+        out = np.zeros(32, np.float32)
+        _lib.xs_refshape_get_world2camera(self.h, idx, out.ctypes.data_as(_f32p))
+        return out.reshape(4, 4, 2)
+
+    def volume(self):
+        n = self.res[0] * self.res[1] * self.res[2]
+        v, w, g = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        _lib.xs_refshape_download_volume(self.h, v.ctypes.data_as(_f32p), w.ctypes.data_as(_i32p), g.ctypes.data_as(_f32p))
+        return v, w, g
+
+    def map(self, which, level):
+        rows, cols = self.height >> level, self.width >> level
+        planes = 1 if which == "depths_curr" else 3
+        out = np.zeros((planes * rows, cols, 2), np.float32)
+        assert _lib.xs_refshape_download_map(self.h, MAPS[which], level, out.ctypes.data_as(_f32p)) == 0
+        return out
+
+    def icp_log(self):
+        n = _lib.xs_refshape_icp_log(self.h, None, 0)
+        out = np.zeros(n, np.float64)
+        if n:
+            _lib.xs_refshape_icp_log(self.h, out.ctypes.data_as(_f64p), n)
+        return out.reshape(-1, 54)
+
+
+def reference_tsdf_hessian(depth_dev, rows, cols, intr4, res, voxel_size, R_dual, t_dual, tranc_dist, gt_dev, with_volumes=False):
+    """ComputeLocalTsdf_hessian through its TsdfFusion.h:48-53 signature (xs_launchers.hpp): float4 {loss, gradient, second
+    derivative, count} and, with_volumes, the per-voxel (real, grad, hessian, count) volumes."""
+    k = np.ascontiguousarray(intr4, np.float32)
+    r3 = np.ascontiguousarray(res, np.int32)
+    R = np.ascontiguousarray(R_dual, np.float32).reshape(36)
+    t = np.ascontiguousarray(t_dual, np.float32).reshape(12)
+    n = int(r3[0]) * int(r3[1]) * int(r3[2])
+    out = np.zeros(4, np.float32)
+    vols = np.zeros(4 * n if with_volumes else 1, np.float32)
+    rc = _lib.xs_refshape_hessian(depth_dev.data_ptr(), cols * 2, rows, cols, k.ctypes.data_as(_f32p), r3.ctypes.data_as(_i32p), voxel_size,
+                                  R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist, gt_dev.data_ptr(), int(with_volumes),
+                                  out.ctypes.data_as(_f32p), vols.ctypes.data_as(_f32p) if with_volumes else None)
+    assert rc == 0
+    if not with_volumes:
+        return out
+    return out, (vols[:n], vols[n:2 * n], vols[2 * n:3 * n], vols[3 * n:].view(np.int32))
+
+
+def reference_tsdf_loss(depth_dev, rows, cols, intr4, res, voxel_size, R9, t3, tranc_dist, gt_dev, with_volumes=False):
+    """ComputeLocalTsdf_loss through its TsdfFusion.h:55-60 signature: float2 {loss, count} (+ the (real, count) volumes)."""
+    k = np.ascontiguousarray(intr4, np.float32)
+    r3 = np.ascontiguousarray(res, np.int32)
+    R = np.ascontiguousarray(R9, np.float32).reshape(9)
+    t = np.ascontiguousarray(t3, np.float32).reshape(3)
+    n = int(r3[0]) * int(r3[1]) * int(r3[2])
+    out = np.zeros(2, np.float32)
+    vols = np.zeros(2 * n if with_volumes else 1, np.float32)
+    rc = _lib.xs_refshape_loss(depth_dev.data_ptr(), cols * 2, rows, cols, k.ctypes.data_as(_f32p), r3.ctypes.data_as(_i32p), voxel_size,
+                               R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist, gt_dev.data_ptr(), int(with_volumes),
+                               out.ctypes.data_as(_f32p), vols.ctypes.data_as(_f32p) if with_volumes else None)
+    assert rc == 0
+    if not with_volumes:
+        return out
+    return out, (vols[:n], vols[n:].view(np.int32))
