@@ -735,8 +735,9 @@ def test_full_size_first_frame_figures(dev, n):
 
 
 def test_full_size_1024_tracks_like_512(dev):
-    """The largest volume BASELINE names (1024^3: 4.3 GB per array, so byte offsets leave 32 bits and the raycast
-    takes its 64-bit-offset kernels): four frames of scene S1 track, the camera ends within millimetres of where the
+    """The largest volume BASELINE names (1024^3: 4 GiB per array — exactly what 32-bit byte offsets reach, so the raycast
+    still takes its 32-bit-offset kernels; the 64-bit ones are exercised by tests/test_large_volume_gpu.py on a volume of
+    1024 x 1024 x 1040): four frames of scene S1 track, the camera ends within millimetres of where the
     512^3 run puts it (the scene constrains sliding along its wall only through the sphere, and the two
     discretisations slide differently: 4 mm apart after 27 mm of motion) and has moved as far as the scene's ground
     truth says; the rays find the same surface, and the voxel count scales with the resolution (a truncation band

@@ -220,8 +220,9 @@ struct IntegrateArgs {
     unsigned list_cap, pair_word;            // entries a list region holds; header word of the ListPair that goes with brick_list (PAIR_*)
     int bricks_x, bricks_y, bricks_z, brick_z;  // brick_z: planes per brick (runtime; BRICK_Z by default)
     unsigned kflags;              // KF_*
+    float near_margin;            // pixels: how near a half-integer a streamed voxel's approximate image coordinate may come before the exact path decides (stream_margins)
     const unsigned *mailbox; unsigned mailbox_seq;   // posted pose: what k_pose_gate polls ...
-    unsigned *pose_dev;                              // ... and where it leaves {cmd, 24 floats} for k_integrate_bricks<., ., true>
+    unsigned *pose_dev;                              // ... and where it leaves {cmd, 24 floats} for k_integrate_bricks<., true>
     unsigned char *signmap;       // xs_signmap.h buffer (whole-volume launches) or null: bricks that receive a negative value are marked
     DepthTiles dt;                // per-tile depth range of the frame (k_scale_depth), for k_classify_boxes
     unsigned *box_class;          // [list entry][BOXES_PER_BRICK] box_word (k_classify_boxes) or null: every box takes the exact walk
@@ -231,7 +232,9 @@ struct IntegrateArgs {
 // KF_COUNT_CLASSES: the classification counts its boxes in the workspace header, words CLASS_COUNT_WORD + 0..3, + 6, + 7: boxes wholly free /
 //                   wholly empty / with planes to walk, planes walked, planes streamed with the in-image test (EDGE), with the validity test (SPECKLE)
 // KF_FAR_FIRST:     the list is taken from its end (see k_integrate_bricks)
-enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u };
+// KF_NO_TESTED_STREAM: the numeric shortcuts of the EDGE / SPECKLE classes are not proven for this launch (sensor too large or imaginary pose
+//                   parts too large: stream_margins): such boxes take the exact walk
+enum { KF_ALWAYS_STORE = 1u, KF_COUNT_CLASSES = 2u, KF_FAR_FIRST = 4u, KF_NO_TESTED_STREAM = 8u };
 enum { CLASS_COUNT_WORD = 48 };
 
 namespace {
@@ -658,7 +661,7 @@ __device__ __forceinline__ unsigned classify_box(const IntegrateArgs &a, const B
     // plain free space needs the whole range in the image and valid; else the free planes are streamed with the tests that are left
     // (BOX_EDGE_BIT / BOX_SPECKLE_BIT), which are derived for voxels that are not at the camera
     const bool tested = !inside || speckle;
-    const bool may_stream = !tested || cmin >= XS_EDGE_CMIN;   // (cmin carries the pose slack: it bounds every covered pose's c)
+    const bool may_stream = !tested || (cmin >= XS_EDGE_CMIN && !(a.kflags & KF_NO_TESTED_STREAM));   // (cmin carries the pose slack: it bounds every covered pose's c)
     if (may_stream && lo - cmax > band) return box_word(nz, 0, 0, !inside, speckle);   // in front of everything valid it can see
     if (nz > 8) return all_walk;                            // (more planes per brick than lanes per box: a tuning configuration)
     // Plane by plane.  The four corners of the box's first plane are lanes 0 - 3 (corner bit 2 clear), of its last plane lanes 4 - 7; c moves
@@ -782,11 +785,17 @@ __device__ __forceinline__ unsigned integrate_edge_column(const IntegrateArgs &a
 // SPECKLE box (and EDGE + SPECKLE): a voxel of a free plane is written iff it is in the image AND its nearest pixel is valid (BOX_SPECKLE_BIT).
 // The exact path finds that pixel from image_x = Re(px * (1 / v_c.z)) + cx, near_x = rn(image_x).  Here u = pxr * rcp(c) + cx from the same
 // real parts (edge_in_image has the argument): the two differ by < 2.5e-4 px — the exact one carries five roundings of magnitudes <= 640
-// (1.4e-4), this one v_rcp_f32's ulp, a product and a sum (1.0e-4) — so wherever u lies further than XS_NEAR_MARGIN = 1 / 2048 px from a
+// (1.4e-4), this one v_rcp_f32's ulp, a product and a sum (1.0e-4) — so wherever u lies further than the margin (1 / 2048 px at that size) from a
 // half-integer both round to the same pixel, and the ~0.2 % of voxels that lie nearer (one plane of a wave in eight) take the exact
-// voxel_pixel, wave-uniformly skipped where no lane needs it.  The in-image test is edge_in_image's (skipped for a box whose range is
+// voxel_pixel, wave-uniformly skipped where no lane needs it.  THOSE FIGURES ARE THE 640 x 480 SENSOR'S: every rounding above is half an ulp
+// of a magnitude up to E = max(cols + |cx|, rows + |cy|), so the margin is a launch parameter, a.near_margin = 8 ulp(E) (never below
+// 1 / 2048: E < 1024 gives exactly that), against a worst case of 4 ulp(E) by the count above and 2 ulp(E) measured over 2e7 random voxels
+// per width; and the argument drops the imaginary parts' contribution to the real part of px * (1 / v_c.z), which is
+// <= E (Im c / c)^2 + |fx Im X| |Im c| / c^2 (1e-7 px for a first-order seed of 1e-7): stream_margins bounds it with c >= XS_EDGE_CMIN from
+// the launch's pose and, where it exceeds a sixteenth of the margin or E >= 8192, sets KF_NO_TESTED_STREAM — no box is then classed EDGE or
+// SPECKLE, they walk (INTEGRATION.md "Sensor size").  The in-image test is edge_in_image's (skipped for a box whose range is
 // inside the image: need_image false).  One 4-byte depth gather per voxel; the state loads go out with it, a plane ahead of the stores.
-#define XS_NEAR_MARGIN 0.00048828125f
+#define XS_NEAR_MARGIN_MIN 0.00048828125f
 struct ValidSlot { float v, g, d; int w; bool in; };
 template <class Depth>
 __device__ __forceinline__ void valid_slot_request(ValidSlot &s, const IntegrateArgs &a, const PoseRT &ps, const VoxelCtx &k, const EdgeWindow &win, bool need_image,
@@ -807,7 +816,8 @@ __device__ __forceinline__ void valid_slot_request(ValidSlot &s, const Integrate
     const float rc = __builtin_amdgcn_rcpf(c);
     const float u = pxr * rc + k.cx, v = pyr * rc + k.cy;
     const float ru = rintf(u), rv = rintf(v);
-    unsure = unsure || (in && !(fabsf(u - ru) < 0.5f - XS_NEAR_MARGIN && fabsf(v - rv) < 0.5f - XS_NEAR_MARGIN));   // (NaN: unsure)
+    const float sure = 0.5f - a.near_margin;
+    unsure = unsure || (in && !(fabsf(u - ru) < sure && fabsf(v - rv) < sure));   // (NaN: unsure)
     int nx = (int)ru, ny = (int)rv;
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
         if (unsure) { VoxelProj p; VoxelPixel q; in = voxel_pixel(a, ps, k, z, p, q); nx = q.near_x; ny = q.near_y; }
@@ -1127,7 +1137,7 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
 // kernel inside the pipeline 33 -> 28 us, S2 unchanged (profiles/r04_ab_integrate_waves.txt).
 #define XS_INTEGRATE_WAVES 6
 #endif
-template <bool BILINEAR, bool OFF32 = false, bool POSTED = false, bool SIGN = false>
+template <bool BILINEAR, bool POSTED = false, bool SIGN = false>
 __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(const IntegrateArgs a) {
     PoseRT ps{a.R, a.t};
     if constexpr (POSTED) {
@@ -1169,25 +1179,25 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
     int b_next = 0, cls_next = BOX_MIXED;
     if (first < count) {
         b_next = a.brick_list[entry(first)];
-        if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(first) * BOXES_PER_BRICK + threadIdx.y];
+        if (a.box_class) cls_next = (int)a.box_class[entry(first) * BOXES_PER_BRICK + threadIdx.y];
     }
     if (threadIdx.y == 0 && threadIdx.x < (int)(sizeof(ClipPlanes) / 4)) reinterpret_cast<float *>(&s_cp)[threadIdx.x] = cp_word;
     __syncthreads();
     for (unsigned e = first; e < count; e += stride) {
-        // (OFF32: the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
+        // (the list was written by the classification kernel, so the compiler reads it with a vector load — back to a scalar,
         // or every address derived from it would be a 64-bit vector quantity)
         if (e != first) {
             b_next = a.brick_list[entry(e)];
-            if (OFF32 && a.box_class) cls_next = (int)a.box_class[entry(e) * BOXES_PER_BRICK + threadIdx.y];
+            if (a.box_class) cls_next = (int)a.box_class[entry(e) * BOXES_PER_BRICK + threadIdx.y];
         }
-        const int b = OFF32 ? __builtin_amdgcn_readfirstlane(b_next) : b_next;
+        const int b = __builtin_amdgcn_readfirstlane(b_next);
         const int cls_now = cls_next;
         const int bx = b & 1023, by = (b >> 10) & 1023, bz = b >> 20;
         const int t256 = (int)(threadIdx.y * 64 + threadIdx.x);
         const int lx = t256 % BRICK_X, ly = t256 / BRICK_X;
         const int x = bx * BRICK_X + lx, y = by * BRICK_Y + ly;
         int walk_lo = a.z0, walk_hi = a.z1;   // the planes this wave walks voxel by voxel (all of the brick's unless the box's word says otherwise)
-        if constexpr (OFF32) {
+        {
             if (a.box_class) {   // what k_classify_boxes found for this wave's part of the brick: free planes at one end, empty ones at the other
                 const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane(cls_now);
                 const int zb0 = a.z0 + bz * a.brick_z, ze0 = min(zb0 + a.brick_z, a.z1);
@@ -1212,11 +1222,8 @@ __global__ void __launch_bounds__(256, XS_INTEGRATE_WAVES) k_integrate_bricks(co
             clip_column(s_cp, far, x, y, zb, ze);
             zb = max(zb, walk_lo); ze = min(ze, walk_hi);
             if (zb < ze) {
-                if constexpr (OFF32) {
-                    const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
-                    n_upd += integrate_span<BILINEAR, true, SIGN>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
-                } else
-                    n_upd += integrate_span<BILINEAR, false, SIGN>(a, ps, x, y, zb, ze);
+                const size_t ubase = ((size_t)(zb0 - a.z0) * a.Y + (size_t)by * BRICK_Y) * a.vstep + (size_t)bx * BRICK_X * 4;
+                n_upd += integrate_span<BILINEAR, true, SIGN>(a, ps, x, y, zb, ze, ubase, zb0, (unsigned)ly * (unsigned)a.vstep + (unsigned)lx * 4u);
             }
         }
     }
@@ -1292,7 +1299,7 @@ static void host_frustum(IntegrateArgs &a, float slack_scale = 1.0f) {
 // xs_integrate_scaled_ex2 / xs_integrate_classify_ex take as an argument — those read no per-thread state at all.
 //   start / stop event   HIP events riding on the integrate kernel's own dispatch (after the brick classification)
 //   classify event       completion of xs_integrate_classify's launches (rides on the last dispatch): classify on one stream, integrate on another
-//   pose mailbox         see k_integrate_bricks<., ., true>: the mailbox the next XS_INTEGRATE_POSE_POSTED call's gate polls, its number, the
+//   pose mailbox         see k_integrate_bricks<., true>: the mailbox the next XS_INTEGRATE_POSE_POSTED call's gate polls, its number, the
 //                        factor by which that call widens the frustum planes of the pose it is given (the list's pose), the hand-over buffer
 //   sign map             the map (xs_signmap.h) the launches mark; depth tiles: the frame's table (xs_scale_depth_tiles), null = the call builds its own
 static thread_local xs_integrate_opts g_legacy = {sizeof(xs_integrate_opts), 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 2.0f, nullptr};
@@ -1416,6 +1423,20 @@ static bool launch_classification(IntegrateArgs &a, const int *res, int nz, void
     return launch_box_classes(a, res, nz, workspace, tiles, sl, st, true, done);
 }
 // the pose-dependent part of the arguments the classification needs (what xs_integrate_scaled_ex sets up for it)
+// Where the streamed classes' numeric shortcuts hold (valid_slot_request has the derivation): the margin for this sensor, and whether the
+// launch may class boxes EDGE / SPECKLE at all.  Needs a.drows / dcols / intr / R / t / X / Y / Z / voxel_size; host only.
+static void stream_margins(IntegrateArgs &a) {
+    const float E = fmaxf((float)a.dcols + fabsf(a.intr.cx), (float)a.drows + fabsf(a.intr.cy));
+    int e = 0;
+    (void)frexpf(E, &e);                                       // E = m 2^e, m in [0.5, 1): ulp(E) = 2^(e - 24)
+    a.near_margin = fmaxf(ldexpf(1.0f, e - 21), XS_NEAR_MARGIN_MIN);   // 8 ulp(E)
+    const double ext[3] = {(double)a.X * a.voxel_size, (double)a.Y * a.voxel_size, (double)a.Z * a.voxel_size};
+    auto im_row = [&](const cfloat3 &r, const cfloat &t) { return fabs((double)r.x.im) * ext[0] + fabs((double)r.y.im) * ext[1] + fabs((double)r.z.im) * ext[2] + fabs((double)t.im); };
+    const double imX = im_row(a.R.data[0], a.t.x), imY = im_row(a.R.data[1], a.t.y), imC = im_row(a.R.data[2], a.t.z);
+    const double cmin = XS_EDGE_CMIN;
+    const double bound = (double)E * (imC / cmin) * (imC / cmin) + fmax(fabs((double)a.intr.fx) * imX, fabs((double)a.intr.fy) * imY) * imC / (cmin * cmin);
+    if (!(E < 8192.0f) || !(bound <= (double)a.near_margin / 16.0)) a.kflags |= KF_NO_TESTED_STREAM;   // (NaN: no)
+}
 static void classify_args(IntegrateArgs &a, int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18,
                           const float *tv2c6, float tranc_dist, int z0, int z1, const float *depth_max_dev) {
     memset(&a, 0, sizeof(a));
@@ -1426,6 +1447,7 @@ static void classify_args(IntegrateArgs &a, int rows, int cols, const float *int
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.voxel_size = voxel_size; a.depth_max = depth_max_dev;
     host_frustum(a);
+    stream_margins(a);
     static const int env_bz = exp_env_int("XS_BRICK_Z", 0);  // tuning aid (as in xs_integrate_scaled_ex)
     a.brick_z = (env_bz >= 2 && env_bz <= 64) ? env_bz : BRICK_Z;
     a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(z1 - z0, a.brick_z);
@@ -1493,7 +1515,8 @@ extern "C" int xs_integrate_list_covers(int rows, int cols, const float *intr4, 
         const double room = 1.5 * ((double)slack_scale * l.fr.slack[p] - f.fr.slack[p]);
         if (!(d <= 0.9 * room)) return 0;   // (a tenth of the room left for the kernel's float evaluation of the forms)
     }
-    return box_slack_covers(l, f, res, slack_scale) ? 3 : 1;   // bit 1: the boxes' classes hold for the pose too
+    const bool tested_ok = !(f.kflags & KF_NO_TESTED_STREAM) || (l.kflags & KF_NO_TESTED_STREAM);   // (stream_margins: EDGE / SPECKLE classes need the final pose to allow them)
+    return box_slack_covers(l, f, res, slack_scale) && tested_ok ? 3 : 1;   // bit 1: the boxes' classes hold for the pose too
 }
 /* Host only: the stricter cover test a POSTED integrate launch needs — it keeps the list pose's widened planes for its column clip too, where
  * a voxel is kept when alpha + b . index >= -slack (the brick test of xs_integrate_list_covers allows 1.5 slack): 1 if every half-space of
@@ -1510,7 +1533,8 @@ extern "C" int xs_integrate_pose_covered(int rows, int cols, const float *intr4,
         const double room = (double)slack_scale * l.fr.slack[p] - f.fr.slack[p];
         if (!(d <= 0.8 * room)) return 0;   // (a fifth of the room left for the float evaluation of the forms and of the roots the clip solves them for)
     }
-    return box_slack_covers(l, f, res, slack_scale) ? 1 : 0;   // (a posted launch cannot classify again: it needs both)
+    const bool tested_ok = !(f.kflags & KF_NO_TESTED_STREAM) || (l.kflags & KF_NO_TESTED_STREAM);
+    return box_slack_covers(l, f, res, slack_scale) && tested_ok ? 1 : 0;   // (a posted launch cannot classify again: it needs both)
 }
 extern "C" int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, int max_weight,
                                    const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
@@ -1562,6 +1586,7 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
     if (env_always || (flags & XS_INTEGRATE_ALWAYS_STORE)) a.kflags |= KF_ALWAYS_STORE;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
     if (far_end_first(a)) a.kflags |= KF_FAR_FIRST;
+    stream_margins(a);
     const bool posted = (flags & XS_INTEGRATE_POSE_POSTED) != 0;
     a.mailbox = nullptr; a.mailbox_seq = 0; a.pose_dev = nullptr;
     a.dt = depth_tiles_view(nullptr, rows, cols); a.box_class = nullptr;
@@ -1578,13 +1603,13 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
     a.bricks_x = div_up(a.X, BRICK_X); a.bricks_y = div_up(a.Y, BRICK_Y); a.bricks_z = div_up(nz, a.brick_z);
     a.zchunk = nz;
     dim3 block(64, 4);
-    if (workspace && a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047) {  // packed brick ids: 10 + 10 + 11 bits
+    // The brick kernel addresses a brick's voxels as a wave-uniform base (the brick's first voxel) + one 32-bit byte offset per lane: a brick
+    // must span less than 4 GiB of an array — always, short of absurd pitches (rows of more than 128 K floats at Y = 1024); such a volume takes
+    // the column walk below.  (Round 6: the brick kernel's 64-bit-pointer instances, which no test could reach, are gone.)
+    const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32);
+    if (workspace && off32 && a.bricks_x <= 1024 && a.bricks_y <= 1024 && a.bricks_z <= 2047) {  // packed brick ids: 10 + 10 + 11 bits
         bind_workspace(a, res, nz, workspace);
         const int nb = a.bricks_x * a.bricks_y * a.bricks_z;
-        // 32-bit lane offsets from the brick's first voxel whenever a brick spans less than 4 GiB of an array (always, short of absurd
-        // pitches): no spills, the state loads take a scalar base (S1 launch 40.5 -> 39.2 us for the whole call, S2 unchanged)
-        static const char *env_k = exp_env_str("XS_INTEGRATE_KERNEL");   // experiment: "off64" = 64-bit pointers per lane
-        const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * a.vstep < (1ull << 32) && !(env_k && !strcmp(env_k, "off64"));
         const bool sign = a.signmap != nullptr;
         // the boxes' classes (free space / nothing to write / exact walk) and the list's order: those xs_integrate_classify left for this
         // list, or decided here with the launch's own pose — from the caller's tile table (xs_integrate_set_depth_tiles) or one built here,
@@ -1596,10 +1621,11 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
         if (classes_ahead && !posted) {
             IntegrateArgs l = a;
             load_mat(g_classes_ahead.R18, l.R); load_vec(g_classes_ahead.t6, l.t);
-            classes_ahead = box_slack_covers(l, a, res, g_classes_ahead.slack_scale);
+            // (classes decided for a pose whose imaginary parts passed stream_margins do not hold for one whose do not)
+            classes_ahead = box_slack_covers(l, a, res, g_classes_ahead.slack_scale) && !(a.kflags & KF_NO_TESTED_STREAM);
         }
         g_classes_ahead.workspace = nullptr;
-        const bool use_tiles = off32 && !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
+        const bool use_tiles = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
         auto tile_table = [&]() -> const DepthTile * {   // the caller's, or one built in the workspace's tile room
             if (depth_tiles || xs_depth_tiles_bytes(rows, cols) > TILE_ROOM_BYTES) return depth_tiles;
             DepthTile *own = reinterpret_cast<DepthTile *>((char *)workspace + workspace_list_bytes(res, nz) + workspace_class_bytes(res, nz));
@@ -1623,15 +1649,11 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
         // the kernel's own begin / end timestamps), so it adds no marker packets to the stream and times what
         // rocprofv3 times
         // (either event may be null: a completion event alone lets another stream wait for this kernel without a marker packet)
-        void (*kern)(const IntegrateArgs) =
-            sign ? (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true, false, true> : k_integrate_bricks<true, false, false, true>)
-                                     : (off32 ? k_integrate_bricks<false, true, false, true> : k_integrate_bricks<false, false, false, true>))
-                 : (threshold > 0.0f ? (off32 ? k_integrate_bricks<true, true> : k_integrate_bricks<true, false>)
-                                     : (off32 ? k_integrate_bricks<false, true> : k_integrate_bricks<false, false>));
+        void (*kern)(const IntegrateArgs) = sign ? (threshold > 0.0f ? k_integrate_bricks<true, false, true> : k_integrate_bricks<false, false, true>)
+                                                 : (threshold > 0.0f ? k_integrate_bricks<true> : k_integrate_bricks<false>);
         if (posted) {
-            if (!off32) return xs_set_error(hipErrorInvalidValue, "xs_integrate_scaled_ex: posted launch on a volume whose bricks span 4 GiB");
-            kern = sign ? (threshold > 0.0f ? k_integrate_bricks<true, true, true, true> : k_integrate_bricks<false, true, true, true>)
-                        : (threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>);
+            kern = sign ? (threshold > 0.0f ? k_integrate_bricks<true, true, true> : k_integrate_bricks<false, true, true>)
+                        : (threshold > 0.0f ? k_integrate_bricks<true, true> : k_integrate_bricks<false, true>);
             hipLaunchKernelGGL(k_pose_gate, dim3(1), dim3(64), 0, st, a.mailbox, a.mailbox_seq, a.pose_dev);
         }
         static const int env_lds = exp_env_int("XS_INTEGRATE_DYN_LDS", 0);   // experiment: dynamic LDS bytes per workgroup = a cap on the workgroups resident per CU

@@ -722,7 +722,7 @@ unsigned long long *KinectFusionReconstruction::PrepareFrameCounters(hipStream_t
     return frame_counters();
 }
 
-// Behind the classification: the integrate kernel itself, to take the final pose from its mailbox (k_integrate_bricks<., ., true>).  Everything
+// Behind the classification: the integrate kernel itself, to take the final pose from its mailbox (k_integrate_bricks<., true>).  Everything
 // IntegrateFrame does around its launch happens here; IntegrateFrame then only checks that the final pose is covered and posts it.
 void KinectFusionReconstruction::EnqueuePostedIntegrate() {
     if (!integrate_post_pose || !integrate_split() || !integrate_mailbox_ || !integrate_mailbox_in_device_ || !list_ready_) return;

@@ -254,7 +254,11 @@ int xs_refshape_hessian(const uint16_t *depth_dev, size_t depth_step, int rows, 
     DeviceArray2D<float> depthScaled;
     DeviceArray<float> gt_vec(const_cast<float *>(gt_dev), n), real_vec, grad_vec, hessian_vec;
     DeviceArray<int> count_vec;
-    if (with_volumes) { real_vec.create(n); grad_vec.create(n); hessian_vec.create(n); count_vec.create(n); }
+    if (with_volumes) {   // thrust's resize(voxel_num, 0) of a fresh vector (TsdfFusion.cu:293-300): the kernel writes only the voxels it counts
+        real_vec.create(n); grad_vec.create(n); hessian_vec.create(n); count_vec.create(n);
+        for (void *p : {(void *)real_vec.ptr(), (void *)grad_vec.ptr(), (void *)hessian_vec.ptr(), (void *)count_vec.ptr()})
+            hipSafeCall(hipMemsetAsync(p, 0, n * 4, current_stream()));
+    }
     MatD33 R; devDComplex3 t;
     std::memcpy(&R, Rv2c36, sizeof(R));
     std::memcpy(&t, tv2c12, sizeof(t));
@@ -274,7 +278,11 @@ int xs_refshape_loss(const uint16_t *depth_dev, size_t depth_step, int rows, int
     DeviceArray2D<float> depthScaled;
     DeviceArray<float> gt_vec(const_cast<float *>(gt_dev), n), real_vec;
     DeviceArray<int> count_vec;
-    if (with_volumes) { real_vec.create(n); count_vec.create(n); }
+    if (with_volumes) {
+        real_vec.create(n); count_vec.create(n);
+        hipSafeCall(hipMemsetAsync(real_vec.ptr(), 0, n * 4, current_stream()));
+        hipSafeCall(hipMemsetAsync(count_vec.ptr(), 0, n * 4, current_stream()));
+    }
     Mat33 R;
     std::memcpy(&R, Rv2c9, sizeof(R));
     float3 t; t.x = tv2c3[0]; t.y = tv2c3[1]; t.z = tv2c3[2];
