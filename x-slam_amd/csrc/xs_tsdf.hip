@@ -1713,7 +1713,9 @@ struct HessArgs {
     unsigned *ticket;
     double *out;          // hessian: {loss, grad, hessian, count}; loss: {loss, count}
     float *real_out, *grad_out, *hess_out; int *count_out;  // optional per-voxel volumes (same indexing as gt)
-    int tiles_x, tiles_y, tiles_z;  // (64 x 4 x zchunk) tiles; workgroups stride over them
+    int tiles_x, tiles_y, tiles_z;  // (64 x 4 x zchunk) tiles — (256 x 4 x zchunk) when wide; workgroups stride over them
+    int il;               // wide == 2: consecutive planes a workgroup takes together before its neighbours' (1, 2, 4, 8)
+    int wide;             // a lane scans four x-neighbours with 16-byte loads (X % 4 == 0 and gt 16-byte aligned): for_band_voxels_wide; 2: planes interleaved
 };
 struct HessPoseD { MatD33 R; dcfloat3 t; };
 struct HessPoseF { float R[9]; float t[3]; };
@@ -1812,6 +1814,23 @@ __device__ __forceinline__ void band_queue_take(const HessArgs &a, BandQueue &Q,
     Q.head += count;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before a later append may reuse the slots
 }
+// the queue's side of the scan: the lanes whose voxel (bit b of their mask) is in the band append it; sixty-four waiting are dealt out
+template <class F, class XYZ>
+__device__ __forceinline__ void band_queue_append(const HessArgs &a, BandQueue &Q, int wave, int lane, bool mine, XYZ &&xyz, F &&body) {
+    const unsigned long long who = __ballot(mine);
+    if (!who) return;
+    if (mine) {
+        const unsigned pos = Q.tail + __popcll(who & ((1ull << lane) - 1ull));
+        Q.q[wave][pos % BandQueue::CAP] = xyz();
+    }
+    Q.tail += (unsigned)__popcll(who);
+    if (Q.tail - Q.head >= 64u) band_queue_take(a, Q, wave, lane, 64u, body);
+}
+// The ground truth is read ONCE per launch and is larger than the 256 MiB Infinity Cache (512 MiB at 512^3, 4 GiB at 1024^3): the scan's
+// loads are NONTEMPORAL (round 6, profiles/r06_hess_scan.txt).  With the default policy every line read is allocated in the cache, and
+// allocating evicts — what the predecessor left dirty first: the same scan streamed 3.0-3.8 TB/s behind a kernel that had written 1 GiB and
+// 4.1-5.9 TB/s back to back, against 5.9-6.4 TB/s either way without allocation.
+typedef float xs_f4 __attribute__((ext_vector_type(4)));
 template <class F>
 __device__ __forceinline__ void for_band_voxels(const HessArgs &a, BandQueue &Q, int wave, int lane, int x, int y, bool in_volume, int zb, int ze,
                                                 F &&body) {
@@ -1824,26 +1843,55 @@ __device__ __forceinline__ void for_band_voxels(const HessArgs &a, BandQueue &Q,
         if (in_volume) {
 #pragma unroll
             for (int j = 0; j < ZB; ++j) {
-                const float g = (zc + j < ze) ? col[(size_t)j * plane] : 0.f;
+                const float g = (zc + j < ze) ? col[(size_t)j * plane] : 0.f;   // (the fallback for rows that are no multiple of 16 bytes: as round 5 measured it)
                 if (!(g == 0 || fabsf(g) > 0.95)) mask |= 1u << j;
             }
         }
         if (!__ballot(mask != 0)) continue;                       // free space: the usual case
-        for (int j = 0; j < ZB; ++j) {
-            const bool mine = (mask >> j) & 1u;
-            const unsigned long long who = __ballot(mine);
-            if (!who) continue;
-            if (mine) {
-                const unsigned pos = Q.tail + __popcll(who & ((1ull << lane) - 1ull));
-                Q.q[wave][pos % BandQueue::CAP] = (unsigned long long)x | ((unsigned long long)y << 21) | ((unsigned long long)(zc + j) << 42);
-            }
-            Q.tail += (unsigned)__popcll(who);
-            if (Q.tail - Q.head >= 64u) band_queue_take(a, Q, wave, lane, 64u, body);
-        }
+        for (int j = 0; j < ZB; ++j)
+            band_queue_append(a, Q, wave, lane, (mask >> j) & 1u,
+                              [&] { return (unsigned long long)x | ((unsigned long long)y << 21) | ((unsigned long long)(zc + j) << 42); }, body);
     }
 }
-// the tile walk the three kernels share: a bounded number of workgroups (each pays an L2 write-back and a ticket
-// when it retires) stride over the (64 x 4 x zchunk) tiles, one column per lane, one row of columns per wave
+// Round 6: sixteen bytes per lane.  A lane takes FOUR x-neighbours (x0 .. x0 + 3: a wave reads 1 KiB of a row per instruction, a
+// workgroup four rows) and requests eight planes at once — the same 32 registers and 32 mask bits as the column form, bit 4 j + k =
+// voxel (x0 + k, y, zc + j), dealt out through the same queue.  Scan alone (a map with one wall, nothing but the read, the band test and
+// the ballots; profiles/tools/scan_probe.hip on one MI355X): 4.4-4.6 TB/s for the column form at 512^3 (5.1-5.2 at 1024^3), 5.9 (5.4-5.9)
+// for this shape, 6.2-6.3 (6.4) for this shape with nontemporal loads; a flat sweep of the array, which knows no coordinates: 6.5 (6.7).
+template <class F>
+__device__ __forceinline__ void for_band_voxels_wide(const HessArgs &a, BandQueue &Q, int wave, int lane, int x0, int y, bool in_volume, int zfirst, int zstep, int zend,
+                                                     F &&body) {
+    // this tile's planes: zfirst, zfirst + zstep, ... below a.z1 — INTERLEAVED with the other workgroups that share its columns.  A band is
+    // a sheet a few planes thick: cut into runs of consecutive planes, a wall across z would put all of its voxels into the one run that
+    // holds it (1 workgroup in 16 at 512^3 did the whole dual-complex evaluation: 0.145 ms against 0.117); plane by plane it goes to seven.
+    constexpr int ZB = 8;
+    const size_t plane = (size_t)a.Y * a.X;
+    const int il = a.il;                                       // consecutive planes taken together (1, 2, 4 or 8); zstep counts such groups
+    auto zof = [&](int zc, int j) { return zc + (j % il) + (j / il) * il * zstep; };
+    const float *col = a.gt + (in_volume ? (size_t)(zfirst - a.z0) * plane + (size_t)y * a.X + x0 : 0);
+    for (int zc = zfirst; zc < zend; zc += ZB * zstep, col += (size_t)ZB * zstep * plane) {
+        unsigned mask = 0;
+        if (in_volume) {
+            xs_f4 v[ZB];
+#pragma unroll
+            for (int j = 0; j < ZB; ++j)
+                v[j] = (zof(zc, j) < zend) ? __builtin_nontemporal_load(reinterpret_cast<const xs_f4 *>(col + (size_t)(zof(zc, j) - zc) * plane)) : xs_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < ZB; ++j) {
+                if (!(v[j].x == 0 || fabsf(v[j].x) > 0.95)) mask |= 1u << (4 * j);
+                if (!(v[j].y == 0 || fabsf(v[j].y) > 0.95)) mask |= 2u << (4 * j);
+                if (!(v[j].z == 0 || fabsf(v[j].z) > 0.95)) mask |= 4u << (4 * j);
+                if (!(v[j].w == 0 || fabsf(v[j].w) > 0.95)) mask |= 8u << (4 * j);
+            }
+        }
+        if (!__ballot(mask != 0)) continue;                       // free space: the usual case
+        for (int b = 0; b < 32; ++b)
+            band_queue_append(a, Q, wave, lane, (mask >> b) & 1u,
+                              [&] { return (unsigned long long)(x0 + (b & 3)) | ((unsigned long long)y << 21) | ((unsigned long long)zof(zc, b >> 2) << 42); }, body);
+    }
+}
+// the tile walk the three kernels share: a bounded number of workgroups (each pays a ticket when it retires) stride over the
+// (64 x 4 x zchunk) tiles — (256 x 4 x zchunk) in the wide form — one column (four) per lane, one row of columns per wave
 template <class F>
 __device__ __forceinline__ void walk_band(const HessArgs &a, F &&body) {
     __shared__ unsigned long long s_queue[4][BandQueue::CAP];
@@ -1851,10 +1899,16 @@ __device__ __forceinline__ void walk_band(const HessArgs &a, F &&body) {
     const int lane = threadIdx.x, wave = threadIdx.y;            // blockDim = (64, 4)
     const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int x = threadIdx.x + (tile % a.tiles_x) * 64;
         const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
         const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        for_band_voxels(a, Q, wave, lane, x, y, x < a.X && y < a.Y, zb, ze, body);
+        if (a.wide) {   // (planes a.z0 + g, a.z0 + g + tiles_z, ...: g = the tile's z index)
+            const int x0 = 4 * (int)threadIdx.x + (tile % a.tiles_x) * 256;
+            if (a.wide == 2) for_band_voxels_wide(a, Q, wave, lane, x0, y, x0 < a.X && y < a.Y, a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.il, a.tiles_z, a.z1, body);
+            else for_band_voxels_wide(a, Q, wave, lane, x0, y, x0 < a.X && y < a.Y, zb, 1, ze, body);
+        } else {
+            const int x = threadIdx.x + (tile % a.tiles_x) * 64;
+            for_band_voxels(a, Q, wave, lane, x, y, x < a.X && y < a.Y, zb, ze, body);
+        }
     }
     band_queue_take(a, Q, wave, lane, Q.tail - Q.head, body);   // what is left: fewer than sixty-four
 }
@@ -2035,7 +2089,7 @@ extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_
 
 static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
                        float voxel_size, float tranc_dist, const float *gt, int z0, int z1, void *workspace, double *out_dev, dim3 &grid,
-                       void *stream) {
+                       void *stream, bool heavy_body) {
     if (!depth_scaled || !intr4 || !res || !gt || !workspace || !out_dev) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: null pointer");
     if (z0 < 0 || z1 > res[2] || z1 <= z0) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: bad slab");
     a.depth = depth_scaled; a.dstep = scaled_step; a.drows = rows; a.dcols = cols;
@@ -2043,17 +2097,29 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     a.voxel_size = voxel_size; a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist;
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
     a.gt = gt; a.ticket = (unsigned *)workspace; a.partials = (double *)((char *)workspace + 256); a.out = out_dev;
-    // One column per lane.  (Four columns per lane with 16-byte reads streamed no faster and made the Hessian
-    // kernel slower: four times the band voxels per lane, worse balance.)  Tiles of 64 x 4 columns x zchunk
-    // planes; the workgroups stride over them.  (While every workgroup paid an L2 write-back for its record, 4096 of them
-    // halved the streaming rate against 1024; the records now leave with write-through stores: block_fold_and_finish.)
+    // Tiles of 64 x 4 columns x zchunk planes, one column per lane (256 x 4 with four columns per lane: a.wide); the workgroups stride
+    // over them.  (While every workgroup paid an L2 write-back for its record, 4096 of them halved the streaming rate against 1024; the
+    // records now leave with write-through stores: block_fold_and_finish.)
     static const int env_blocks = exp_env_int("XS_HESS_BLOCKS", 0);  // tuning aid
-    int gx = div_up(a.X, 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
+    static const bool env_narrow = exp_env_set("XS_HESS_NARROW");    // A/B aid: the one-column-per-lane scan whatever the shape
+    // sixteen bytes per lane where the rows allow it (for_band_voxels_wide): X a multiple of four and the slab's first voxel 16-byte aligned
+    // Which planes a workgroup takes when the columns are split along z (volumes below 1024^2 columns): runs of consecutive planes stream
+    // fastest (eight ADJACENT planes per request: 6.1 TB/s scan alone at 512^3 against 5.7 for planes four apart), but a band is a sheet a few
+    // planes thick and a wall across z then lies in ONE workgroup's run per column — the kernels whose band voxels are expensive (dual-complex
+    // Hessian, six-pose Gauss-Newton) take the planes interleaved in pairs instead, the loss kernel takes runs (profiles/r06_hess_scan.txt).
+    static const int env_ilg = exp_env_int("XS_HESS_IL", 2);
+    a.il = (env_ilg == 1 || env_ilg == 4 || env_ilg == 8) ? env_ilg : 2;
+    static const int env_il = exp_env_int("XS_HESS_INTERLEAVE", -1);   // A/B aid: 0 = runs, 1 = interleaved, whatever the kernel
+    const bool interleave = env_il < 0 ? heavy_body : env_il != 0;
+    a.wide = (a.X % 4 == 0 && (reinterpret_cast<uintptr_t>(gt) % 16) == 0 && !env_narrow) ? (interleave ? 2 : 1) : 0;
+    int gx = div_up(a.X, a.wide ? 256 : 64), gy = div_up(a.Y, 4), nz = z1 - z0, zsplit = 1;
     // one workgroup per column of tiles while that gives 1024 .. 4096 of them (512^3: 1024, 1024^3: 4096 — measured best:
     // the Gauss-Newton pass at 1024^3 runs 15 % faster with 4096 workgroups walking one column each than with 1024 walking
     // four); fewer columns are split along z, more are strided over
     const long long cols_xy = (long long)gx * gy;
+    // (in the bare scan 4096 workgroups streamed 4 % faster than 1024; in the kernels, which pay a record and a ticket per workgroup, 8-12 % slower)
     const int cap = env_blocks > 0 && env_blocks <= XS_TSDF_REDUCE_MAX_BLOCKS ? env_blocks
+                    : a.wide ? (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy))
                     : (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy));
     while ((long long)gx * gy * zsplit < cap && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
     a.zchunk = div_up(nz, zsplit);
@@ -2079,7 +2145,7 @@ extern "C" int xs_compute_local_tsdf_hessian(const float *depth_scaled, size_t s
                                              float tranc_dist, const float *gt, float *real_out, float *grad_out, float *hess_out,
                                              int *count_out, int z0, int z1, void *workspace, double *out4_dev, void *stream) {
     HessArgs a; dim3 grid;
-    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out4_dev, grid, stream);
+    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out4_dev, grid, stream, true);
     if (rc) return rc;
     if (!Rv2c36 || !tv2c12) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_hessian: null pose");
     const bool all = real_out && grad_out && hess_out && count_out, none = !real_out && !grad_out && !hess_out && !count_out;
@@ -2108,7 +2174,7 @@ extern "C" int xs_compute_local_tsdf_loss(const float *depth_scaled, size_t scal
                                           const float *gt, float *real_out, int *count_out, int z0, int z1, void *workspace,
                                           double *out2_dev, void *stream) {
     HessArgs a; dim3 grid;
-    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out2_dev, grid, stream);
+    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out2_dev, grid, stream, false);
     if (rc) return rc;
     if (!Rv2c9 || !tv2c3) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_loss: null pose");
     if ((real_out == nullptr) != (count_out == nullptr)) return xs_set_error(hipErrorInvalidValue, "xs_compute_local_tsdf_loss: pass both volumes or none");
@@ -2131,7 +2197,7 @@ extern "C" int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scal
                                           float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0,
                                           int z1, void *workspace, double *out29_dev, void *stream) {
     HessArgs a; dim3 grid;
-    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out29_dev, grid, stream);
+    int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out29_dev, grid, stream, true);
     if (rc) return rc;
     if (!Rv2c108 || !tv2c36) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_gauss_newton_terms: null pose");
     a.real_out = nullptr; a.grad_out = nullptr; a.hess_out = nullptr; a.count_out = nullptr;
