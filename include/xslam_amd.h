@@ -343,6 +343,30 @@ int xs_raycast_compose_scatter(const void *entries_dev, long n, float *vmap, flo
 int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
                                float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0, int z1,
                                void *workspace, double *out29_dev, void *stream);
+/* ... with the loop protocol the ICP iterations have (round 6): opts NULL = plain xs_tsdf_gauss_newton_terms.
+ *   publish_host / publish_seq   host-coherent pinned memory of xs_gn_publish_bytes() bytes (hipHostMalloc, coherent + mapped): the launch's last
+ *                                workgroup stores the 29 sums there and then the 64-bit word [32] = publish_seq; the host spins on that word
+ *                                instead of hipMemcpyAsync + hipStreamSynchronize.  Use a different number for every launch on a buffer.
+ *   pose_mailbox / mailbox_seq   with Rv2c108 = tv2c36 = NULL: the launch is enqueued BEFORE its poses exist (the host is still solving the
+ *                                previous pass) and takes them from the mailbox — xs_icp_mailbox_alloc memory, written by xs_gn_post_poses with
+ *                                the same number.  xs_gn_post_poses(..., cmd = 1) makes the launch leave; so does a pose that never comes (about a
+ *                                second): nothing is summed and the publish word becomes publish_seq | 1 << 63. */
+typedef struct xs_gn_opts {
+    unsigned struct_bytes;            /* sizeof(xs_gn_opts) */
+    unsigned mailbox_seq;
+    const void *pose_mailbox;
+    double *publish_host;
+    unsigned long long publish_seq;
+} xs_gn_opts;
+int xs_tsdf_gauss_newton_terms_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
+                                  float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0, int z1,
+                                  void *workspace, double *out29_dev, const xs_gn_opts *opts, void *stream);
+size_t xs_gn_publish_bytes(void);     /* 33 doubles */
+size_t xs_gn_mailbox_bytes(void);     /* six pose mailboxes in a row (xs_icp_mailbox_alloc's 4096 bytes hold them) */
+/* host: the six seeded poses (or cmd 1 = leave) for the launch polling mailbox_host for mailbox_seq */
+void xs_gn_post_poses(void *mailbox_host, const float *Rv2c108, const float *tv2c36, unsigned mailbox_seq, int cmd);
+/* shard mode: the n <= 32 sums as they stand in device memory behind the stream's all-reduce, published like the kernel's own (word [32] = seq) */
+int xs_gn_publish_sums(const double *sums_dev, int n, double *publish_host, unsigned long long seq, void *stream);
 
 /* ---- surface extraction (export; real-valued) ------------------------------------------------ */
 size_t xs_extract_workspace_bytes(const int *res);

@@ -123,6 +123,11 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4);
  * sums seen -> IntegrateFrame entered (6x6 solve, pose algebra), [1] entered -> the integrate launch call (transforms, cover test), [2] the
  * launch call itself, [3] its return -> the raycast launch's return. */
 void xs_kf_tail_host_times(void *kf, double *us4, long long *frames);
+/* The Gauss-Newton passes xs_kf_relocalize has run since the last reset: *pass_us = host wall clock summed over *passes passes (from a loop's
+ * first kernel enqueued to its last sums seen: kernel + the record's way to the host + the 6x6 solve + the six pose inversions + the post);
+ * *kernel_ms / *kernel_calls = the kernels' own durations, of passes run with profiling on (xs_kf_set_profiling >= 1: an event pair around each).
+ * reset != 0 zeroes the four.  pass - kernel is what the host's side of a pass costs (bench.py: workloads.reloc.host_us_per_pass). */
+void xs_kf_gn_times(void *kf, double *pass_us, long long *passes, double *kernel_ms, long long *kernel_calls, int reset);
 /* Test aids.  Start the ICP launch sequence numbers at v (exercises the 2^32 wrap of the mailbox numbers); make the determinant gate of
  * iteration n (0-based, over all levels) of the next alignment fail as for a singular system (KinectFusionReconstruction.cpp:203-210). */
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v);

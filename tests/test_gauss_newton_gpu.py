@@ -225,6 +225,40 @@ def test_relocalization_loop_against_an_oracle_twin(dev, oracle):
     assert hist[-1] < 0.5 * hist[0]
 
 
+def test_relocalize_loop_protocol_changes_no_bit(dev):
+    """Round 6: the loop's passes are enqueued ahead of their poses (mailbox), their sums published to pinned memory by the kernel's last
+    workgroup, the depth scaled once per frame.  The same refinement with gn_post_pose false (every pass launched with its poses as arguments,
+    after the solve): identical camera2volume and loss history, bit for bit, over five frames; and a loop that ends early — an empty map: nothing
+    to align to on its first pass, while the second pass's kernel is already waiting for poses — tells that kernel to leave, returns failure, and
+    the next call on the same object is unaffected (no stale poses, no stale record)."""
+    torch, capi, pl = dev
+    n = 128
+    runs = {}
+    for posted in (True, False):
+        kf = pl.KinectFusion(dict(synth.s1_params(n), gn_post_pose=posted))
+        dfr = [torch.from_numpy(synth.s3_frame(k).view(np.int16)).cuda() for k in range(9)]
+        empty_fail = kf.relocalize(dfr[0], kf.camera2volume(), iterations=5)[0]      # (before any frame: the map is empty)
+        for k in range(4):
+            assert kf.process_frame(dfr[k]) == 1
+        t_true = kf.camera2volume()[..., 0].astype(np.float64)
+        out = []
+        for k in range(4, 9):
+            start = twist_matrix(np.array([0.006, -0.004, 0.005, 0.003, -0.004, 0.005]) * (1 + 0.1 * k)) @ t_true
+            c2v0 = np.zeros((4, 4, 2), np.float32); c2v0[..., 0] = start
+            ok, refined, hist = kf.relocalize(dfr[k], c2v0, iterations=5, damping=1e-3)
+            assert ok and hist[-1] < hist[0]
+            ok1, refined1, hist1 = kf.relocalize(dfr[k], c2v0, iterations=1, damping=1e-3)    # (a loop of two passes, then one without history: one pass)
+            assert ok1 and np.array_equal(hist1, hist[:2])
+            out.append((refined, hist))
+        times = kf.gn_times()
+        assert times["passes"] == 1 + 5 * (6 + 2)    # (the pass on the empty map was seen too)
+        kf.close()
+        runs[posted] = (empty_fail, out)
+    assert runs[True][0] is False and runs[False][0] is False
+    for (ra, ha), (rb, hb) in zip(runs[True][1], runs[False][1]):
+        assert np.array_equal(ra.view(np.int32), rb.view(np.int32)) and np.array_equal(ha, hb)
+
+
 def test_residual_kernels_non_cubic_volume(dev, oracle):
     """The three residual kernels (dual-complex Hessian, real loss, six-pose Gauss-Newton terms) over a 96 x 64 x 80 map —
     two columns of 64-wide tiles, the second a half one; planes that are not a multiple of the 32-plane batches — against

@@ -1714,6 +1714,8 @@ struct HessArgs {
     double *out;          // hessian: {loss, grad, hessian, count}; loss: {loss, count}
     float *real_out, *grad_out, *hess_out; int *count_out;  // optional per-voxel volumes (same indexing as gt)
     int tiles_x, tiles_y, tiles_z;  // (64 x 4 x zchunk) tiles — (256 x 4 x zchunk) when wide; workgroups stride over them
+    double *publish; unsigned long long publish_seq;   // optional, host-coherent pinned memory: the last workgroup stores the sums there + the word [32] = seq
+    const unsigned *mailbox; unsigned mailbox_seq;     // k_tsdf_gauss_newton<true>: the six poses arrive through a mailbox (xs_gn_post_poses)
     int il;               // wide == 2: consecutive planes a workgroup takes together before its neighbours' (1, 2, 4, 8)
     int wide;             // a lane scans four x-neighbours with 16-byte loads (X % 4 == 0 and gt 16-byte aligned): for_band_voxels_wide; 2: planes interleaved
 };
@@ -1721,7 +1723,8 @@ struct HessPoseD { MatD33 R; dcfloat3 t; };
 struct HessPoseF { float R[9]; float t[3]; };
 
 template <int NV>
-__device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *partials, unsigned *ticket, double *out) {
+__device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *partials, unsigned *ticket, double *out, double *publish = nullptr,
+                                                      unsigned long long publish_seq = 0) {
     constexpr int STRIDE = NV <= 8 ? 8 : 32;  // doubles per workgroup record
     __shared__ double sm[4][NV];
     __shared__ unsigned s_last;
@@ -1777,6 +1780,13 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
 #pragma unroll
             for (int gg = 1; gg < G; ++gg) t += s_red[gg][tid];
             out[tid] = t;
+            // the host's copy: system-scope stores into pinned memory by lanes of wave 0 (NV <= 64), then — once they are acknowledged — the
+            // sequence word by its first lane: a host that sees the word sees the sums (the protocol of the ICP records, xs_icp.hip)
+            if (publish) __hip_atomic_store(&publish[tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (publish && wave == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(publish) + 32, publish_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1898,13 +1908,19 @@ __device__ __forceinline__ void walk_band(const HessArgs &a, F &&body) {
     BandQueue Q{s_queue, 0u, 0u};
     const int lane = threadIdx.x, wave = threadIdx.y;            // blockDim = (64, 4)
     const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool skew = a.wide == 2 && (gridDim.x % (unsigned)a.tiles_z) == 0;   // (else consecutive rounds already land in different z groups)
+    for (int tile = blockIdx.x, round = 0; tile < ntiles; tile += gridDim.x, ++round) {
+        if (a.wide == 2) {   // z group fastest: tile = column * G + g, planes a.z0 + (g + k G) il + (0 .. il - 1)
+            const int G = a.tiles_z, column = tile / G, g = (tile % G + (skew ? round : 0)) % G;
+            const int x0 = 4 * (int)threadIdx.x + (column % a.tiles_x) * 256, y = threadIdx.y + (column / a.tiles_x) * 4;
+            for_band_voxels_wide(a, Q, wave, lane, x0, y, x0 < a.X && y < a.Y, a.z0 + g * a.il, G, a.z1, body);
+            continue;
+        }
         const int y = threadIdx.y + ((tile / a.tiles_x) % a.tiles_y) * 4;
         const int zb = a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.zchunk, ze = min(zb + a.zchunk, a.z1);
-        if (a.wide) {   // (planes a.z0 + g, a.z0 + g + tiles_z, ...: g = the tile's z index)
+        if (a.wide) {
             const int x0 = 4 * (int)threadIdx.x + (tile % a.tiles_x) * 256;
-            if (a.wide == 2) for_band_voxels_wide(a, Q, wave, lane, x0, y, x0 < a.X && y < a.Y, a.z0 + (tile / (a.tiles_x * a.tiles_y)) * a.il, a.tiles_z, a.z1, body);
-            else for_band_voxels_wide(a, Q, wave, lane, x0, y, x0 < a.X && y < a.Y, zb, 1, ze, body);
+            for_band_voxels_wide(a, Q, wave, lane, x0, y, x0 < a.X && y < a.Y, zb, 1, ze, body);
         } else {
             const int x = threadIdx.x + (tile % a.tiles_x) * 64;
             for_band_voxels(a, Q, wave, lane, x, y, x < a.X && y < a.Y, zb, ze, body);
@@ -2045,17 +2061,45 @@ __device__ __forceinline__ bool tsdf_error_c(const HessArgs &a, const MatS33 &R,
     error = (distance - gt_distance) * a.tranc_dist_inv;
     return !(fabsf(error.re) > 1);
 }
+// POSTED: the launch was enqueued before its poses existed (the host is still solving the previous pass): wave 0 polls the mailbox — six pose
+// mailboxes of xs_mailbox.h in a row, written in order, so box 5 carrying the sequence number means boxes 0 .. 4 do — and fills P from it.
+// An abandoned launch (cmd 1) or one whose poses never come publishes the sequence number with bit 63 set and leaves.
+template <bool POSTED>
 __global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, const GnPoses Pk) {
     // The six poses (144 floats) do not fit the scalar registers next to everything else, and the compiler then keeps them
     // in vector registers for the whole kernel (256 of them: one wave per SIMD).  They go through LDS instead: broadcast
     // reads where an evaluation needs them.
     __shared__ GnPoses P;
-    {
+    if constexpr (POSTED) {
+        __shared__ unsigned s_mail[xs::MAILBOX_WORDS];
+        __shared__ unsigned s_cmd;
+        if (threadIdx.y == 0) {
+            const int lane = threadIdx.x;
+            xs::mailbox_wait(a.mailbox + 5 * xs::MAILBOX_WORDS, a.mailbox_seq, s_mail, lane);
+            unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mail[1]);
+            float *dst = reinterpret_cast<float *>(&P);
+            for (int k = 0; k < 6 && cmd == 0; ++k) {   // (issued after box 5's sequence words were seen: complete payloads)
+                const unsigned w = __hip_atomic_load(a.mailbox + k * xs::MAILBOX_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned s0 = __builtin_amdgcn_readlane(w, 0), s1 = __builtin_amdgcn_readlane(w, 16);
+                if (s0 != a.mailbox_seq || s1 != a.mailbox_seq) { cmd = 2; break; }
+                const int word = lane & 31;                     // line 0 = {seq, cmd, f[0..13]}, line 1 = {seq, 0, f[14..23], pad}
+                const int f = word >= 2 && word < 16 ? word - 2 : (word >= 18 && word < 28 ? word - 4 : -1);
+                if (lane < 32 && f >= 0) dst[f < 18 ? 18 * k + f : 108 + 6 * k + (f - 18)] = __uint_as_float(w);
+            }
+            if (lane == 0) s_cmd = cmd;
+        }
+        __syncthreads();
+        if (s_cmd != 0) {
+            if (a.publish && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.publish) + 32, a.publish_seq | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    } else {
         const float *src = reinterpret_cast<const float *>(&Pk);
         float *dst = reinterpret_cast<float *>(&P);
         for (int i = threadIdx.y * 64 + threadIdx.x; i < (int)(sizeof(GnPoses) / sizeof(float)); i += 256) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
     double acc[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) acc[k] = 0.0;
@@ -2081,7 +2125,7 @@ __global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, con
         acc[27] += r * r;
         acc[28] += 1.0;
     });
-    block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out);
+    block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out, a.publish, a.publish_seq);
 }
 
 enum { XS_TSDF_REDUCE_MAX_BLOCKS = 4096 };  // workgroups per launch (they stride over the tiles); records of up to 32 doubles
@@ -2096,6 +2140,7 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     a.X = res[0]; a.Y = res[1]; a.Z = res[2]; a.z0 = z0; a.z1 = z1;
     a.voxel_size = voxel_size; a.tranc_dist = tranc_dist; a.tranc_dist_inv = 1.0f / tranc_dist;
     a.intr = Intr{intr4[0], intr4[1], intr4[2], intr4[3]};
+    a.publish = nullptr; a.publish_seq = 0; a.mailbox = nullptr; a.mailbox_seq = 0;
     a.gt = gt; a.ticket = (unsigned *)workspace; a.partials = (double *)((char *)workspace + 256); a.out = out_dev;
     // Tiles of 64 x 4 columns x zchunk planes, one column per lane (256 x 4 with four columns per lane: a.wide); the workgroups stride
     // over them.  (While every workgroup paid an L2 write-back for its record, 4096 of them halved the streaming rate against 1024; the
@@ -2103,10 +2148,10 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     static const int env_blocks = exp_env_int("XS_HESS_BLOCKS", 0);  // tuning aid
     static const bool env_narrow = exp_env_set("XS_HESS_NARROW");    // A/B aid: the one-column-per-lane scan whatever the shape
     // sixteen bytes per lane where the rows allow it (for_band_voxels_wide): X a multiple of four and the slab's first voxel 16-byte aligned
-    // Which planes a workgroup takes when the columns are split along z (volumes below 1024^2 columns): runs of consecutive planes stream
-    // fastest (eight ADJACENT planes per request: 6.1 TB/s scan alone at 512^3 against 5.7 for planes four apart), but a band is a sheet a few
-    // planes thick and a wall across z then lies in ONE workgroup's run per column — the kernels whose band voxels are expensive (dual-complex
-    // Hessian, six-pose Gauss-Newton) take the planes interleaved in pairs instead, the loss kernel takes runs (profiles/r06_hess_scan.txt).
+    // Which planes a workgroup takes: runs of consecutive planes stream fastest (eight ADJACENT planes per request: 6.1 TB/s scan alone at
+    // 512^3 against 5.7 for planes four apart), but a band is a thin sheet and a wall across z then lies in ONE workgroup's run per column — the
+    // kernels whose band voxels are expensive (dual-complex Hessian, six-pose Gauss-Newton) take four groups of planes interleaved in pairs
+    // (below), the loss kernel takes runs (profiles/r06_hess_scan.txt).
     static const int env_ilg = exp_env_int("XS_HESS_IL", 2);
     a.il = (env_ilg == 1 || env_ilg == 4 || env_ilg == 8) ? env_ilg : 2;
     static const int env_il = exp_env_int("XS_HESS_INTERLEAVE", -1);   // A/B aid: 0 = runs, 1 = interleaved, whatever the kernel
@@ -2119,11 +2164,27 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     const long long cols_xy = (long long)gx * gy;
     // (in the bare scan 4096 workgroups streamed 4 % faster than 1024; in the kernels, which pay a record and a ticket per workgroup, 8-12 % slower)
     const int cap = env_blocks > 0 && env_blocks <= XS_TSDF_REDUCE_MAX_BLOCKS ? env_blocks
+                    : a.wide == 2 ? (int)XS_TSDF_REDUCE_MAX_BLOCKS   // (one workgroup per tile up to 4096: 512^3 has 1024 tiles, 1024^3 4096)
                     : a.wide ? (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy))
                     : (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy));
-    while ((long long)gx * gy * zsplit < cap && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
-    a.zchunk = div_up(nz, zsplit);
-    a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = div_up(nz, a.zchunk);
+    if (a.wide == 2) {
+        // FOUR z groups per column of tiles, their planes interleaved in pairs (a tile: 256 x 4 columns x a quarter of the planes).  A kernel
+        // is as slow as its busiest wave, and a wave that lies IN a surface holds nothing but band voxels: a wall across z is a sheet one or
+        // two planes thick — pairs put it into two to four groups; a floor (a wall along z and x) fills whole rows of a column — with whole
+        // columns per wave (round 5: 64 x 1024 voxels at 1024^3; 256 x 1024 with four columns per lane) the box room's floor kept a few dozen
+        // waves busy long after the rest had left: 0.89 ms per Gauss-Newton pass of the relocalisation workload then, 2.0 ms with four columns per
+        // lane and whole columns, 0.81 ms now.  More, smaller groups balance better and stream worse (requests of a batch further apart:
+        // 32-plane groups 0.139 ms for the Hessian kernel at 512^3 against 0.103): profiles/r06_hess_scan.txt section 5.  Workgroup b takes
+        // tiles b, b + grid, ... of an enumeration with the z group fastest, skewed by one group per round (walk_band).
+        static const int env_zt = exp_env_int("XS_HESS_TILE_PLANES", 0);   // tuning aid: planes per group
+        int G = nz >= 64 ? 4 : (nz >= 32 ? 2 : 1);
+        if (env_zt >= 8) { G = 1; while (G * 2 * env_zt <= nz) G *= 2; }
+        a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = G; a.zchunk = div_up(nz, G);
+    } else {
+        while ((long long)gx * gy * zsplit < cap && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
+        a.zchunk = div_up(nz, zsplit);
+        a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = div_up(nz, a.zchunk);
+    }
     const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.tiles_z;
     grid = dim3((unsigned)(ntiles < cap ? ntiles : cap));
     if ((long long)grid.x * grid.y * grid.z > XS_TSDF_REDUCE_MAX_BLOCKS) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: volume too large for the reduce workspace");
@@ -2196,14 +2257,57 @@ extern "C" int xs_compute_local_tsdf_loss(const float *depth_scaled, size_t scal
 extern "C" int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
                                           float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0,
                                           int z1, void *workspace, double *out29_dev, void *stream) {
+    return xs_tsdf_gauss_newton_terms_ex(depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, Rv2c108, tv2c36, tranc_dist, gt, z0, z1, workspace,
+                                         out29_dev, nullptr, stream);
+}
+/* ... with the loop protocol of the ICP iterations (opts; NULL = none of it):
+ *   publish_host / publish_seq   host-coherent pinned memory of xs_gn_publish_bytes(): the last workgroup stores the 29 sums there and then the
+ *                                64-bit word [32] = publish_seq — the host spins on that word instead of copying and draining the stream;
+ *   pose_mailbox / mailbox_seq   Rv2c108 / tv2c36 NULL: the launch is enqueued before its poses exist and takes them from the mailbox
+ *                                (xs_icp_mailbox_alloc; xs_gn_post_poses writes it).  cmd 1 or a pose that never comes (about a second): nothing is
+ *                                summed, publish word = publish_seq | 1 << 63. */
+extern "C" int xs_tsdf_gauss_newton_terms_ex(const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
+                                             float voxel_size, const float *Rv2c108, const float *tv2c36, float tranc_dist, const float *gt, int z0,
+                                             int z1, void *workspace, double *out29_dev, const xs_gn_opts *opts, void *stream) {
+    if (opts && opts->struct_bytes != sizeof(xs_gn_opts)) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_gauss_newton_terms_ex: opts->struct_bytes is not sizeof(xs_gn_opts)");
     HessArgs a; dim3 grid;
     int rc = hess_common(a, depth_scaled, scaled_step, rows, cols, intr4, res, voxel_size, tranc_dist, gt, z0, z1, workspace, out29_dev, grid, stream, true);
     if (rc) return rc;
-    if (!Rv2c108 || !tv2c36) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_gauss_newton_terms: null pose");
+    const bool posted = opts && opts->pose_mailbox && !Rv2c108 && !tv2c36;
+    if (!posted && (!Rv2c108 || !tv2c36)) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_gauss_newton_terms: give the six poses or a mailbox");
     a.real_out = nullptr; a.grad_out = nullptr; a.hess_out = nullptr; a.count_out = nullptr;
+    if (opts) { a.publish = opts->publish_host; a.publish_seq = opts->publish_seq; }
     GnPoses P;
-    for (int k = 0; k < 6; ++k) { load_mat(Rv2c108 + 18 * k, P.R[k]); load_vec(tv2c36 + 6 * k, P.t[k]); }
-    hipLaunchKernelGGL(k_tsdf_gauss_newton, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    memset(&P, 0, sizeof(P));
+    if (posted) {
+        a.mailbox = static_cast<const unsigned *>(opts->pose_mailbox); a.mailbox_seq = opts->mailbox_seq;
+        hipLaunchKernelGGL(k_tsdf_gauss_newton<true>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    } else {
+        for (int k = 0; k < 6; ++k) { load_mat(Rv2c108 + 18 * k, P.R[k]); load_vec(tv2c36 + 6 * k, P.t[k]); }
+        hipLaunchKernelGGL(k_tsdf_gauss_newton<false>, grid, dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    }
+    XS_CHECK(hipGetLastError());
+    return 0;
+}
+extern "C" size_t xs_gn_publish_bytes(void) { return 33 * sizeof(double); }
+extern "C" size_t xs_gn_mailbox_bytes(void) { return 6 * xs::MAILBOX_WORDS * sizeof(unsigned); }
+/* Host: the six seeded poses (or a command: cmd 1 = leave) for the launch that polls `mailbox_host` for `mailbox_seq` — six mailboxes of the
+ * xs_icp_post_pose form in a row, written in order. */
+extern "C" void xs_gn_post_poses(void *mailbox_host, const float *Rv2c108, const float *tv2c36, unsigned mailbox_seq, int cmd) {
+    for (int k = 0; k < 6; ++k)
+        xs_icp_post_pose(static_cast<char *>(mailbox_host) + (size_t)k * xs::MAILBOX_WORDS * sizeof(unsigned), Rv2c108 ? Rv2c108 + 18 * k : nullptr,
+                         tv2c36 ? tv2c36 + 6 * k : nullptr, mailbox_seq, cmd);
+}
+__global__ void k_publish_sums(const double *sums, int n, double *publish, unsigned long long seq) {
+    const int tid = threadIdx.x;
+    if (tid < n) __hip_atomic_store(&publish[tid], sums[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(publish) + 32, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+/* Shard mode: the sums as they stand in device memory AFTER the stream's all-reduce, published the same way (n <= 32 doubles, then word [32] = seq). */
+extern "C" int xs_gn_publish_sums(const double *sums_dev, int n, double *publish_host, unsigned long long seq, void *stream) {
+    if (!sums_dev || !publish_host || n < 1 || n > 32) return xs_set_error(hipErrorInvalidValue, "xs_gn_publish_sums: bad argument");
+    hipLaunchKernelGGL(k_publish_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, sums_dev, n, publish_host, seq);
     XS_CHECK(hipGetLastError());
     return 0;
 }

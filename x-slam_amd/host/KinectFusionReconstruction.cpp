@@ -50,6 +50,8 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (pinned_records_) (void)hipHostFree(pinned_records_);
     if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
     if (integrate_mailbox_) (void)xs_icp_mailbox_free(integrate_mailbox_, integrate_mailbox_in_device_);
+    if (gn_mailbox_) (void)xs_icp_mailbox_free(gn_mailbox_, gn_mailbox_in_device_);
+    if (gn_publish_) (void)hipHostFree(gn_publish_);
     for (int i = 0; i < 2; ++i) {
         if (ingest_pinned_[i]) { (void)hipEventSynchronize(ingest_done_[i]); (void)hipHostFree(ingest_pinned_[i]); (void)hipEventDestroy(ingest_done_[i]); }
     }
@@ -136,6 +138,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     force_shard_composite = config.as<bool>("force_shard_composite", false);
     shard_composite_gather = config.as<bool>("shard_composite_gather", true);
     raycast_builds_pyramid = config.as<bool>("raycast_builds_pyramid", true);
+    gn_post_pose = config.as<bool>("gn_post_pose", true);
     profile_integrate_every = std::max(1, config.as<int>("profile_integrate_every", 4));
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
@@ -1222,15 +1225,9 @@ int KinectFusionReconstruction::CalculatePointCloud(MapArr &xyz_g_d, MapArr &nor
     return 0;
 }
 
-// BASELINE config 5 (see the header): one pass of xs_tsdf_gauss_newton_terms for the six seeded poses
-int KinectFusionReconstruction::GaussNewtonTerms(const DeviceArray2D<ushort> &depth_frame_d, const Matrix4cf &camera2volume, double out29[29]) {
-    if (!tsdf_volume_d_ptr) return 0;
-    DeviceArray2D<float> value = tsdf_volume_d_ptr->value();
-    hipStream_t st = current_stream();
-    depthRawScaled_d.create(depth_frame_d.rows(), depth_frame_d.cols());
-    check_rc(xs_scale_depth(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
-                            depthRawScaled_d.step(), st), "scaleDepth");
-    float R[6][18], t[6][6];
+// The six seeded volume-to-camera poses of one Gauss-Newton pass: camera2volume <- se3Exp(i h e_k) * camera2volume, k = 0 .. 5
+static void gn_seeded_poses(const xs_host::Matrix4cf &camera2volume, float R[6][18], float t[6][6]) {
+    using namespace xs_host;
     for (int k = 0; k < 6; ++k) {
         hostComplex xi[6];
         for (int i = 0; i < 6; ++i) xi[i] = hostComplex(0.f, i == k ? (float)H_ : 0.f);
@@ -1240,54 +1237,160 @@ int KinectFusionReconstruction::GaussNewtonTerms(const DeviceArray2D<ushort> &de
             t[k][2 * i] = v2c.m[i][3].real(); t[k][2 * i + 1] = v2c.m[i][3].imag();
         }
     }
+}
+// What every pass of a frame shares: the scaled depth (once per frame, not per pass) and this rank's owned planes as the dense array the
+// kernel indexes (a pitched volume is packed first); the pinned record and the mailbox of the loop protocol.
+const float *KinectFusionReconstruction::GaussNewtonPrepare(const DeviceArray2D<ushort> &depth_frame_d) {
+    hipStream_t st = current_stream();
+    DeviceArray2D<float> value = tsdf_volume_d_ptr->value();
+    depthRawScaled_d.create(depth_frame_d.rows(), depth_frame_d.cols());
+    check_rc(xs_scale_depth(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
+                            depthRawScaled_d.step(), st), "scaleDepth");
     if (gn_sums_.size() < 32) gn_sums_.create(32);
     if (gn_ws_.size() < xs_tsdf_reduce_workspace_bytes()) gn_ws_.create(xs_tsdf_reduce_workspace_bytes());
-    const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
-    // this rank's owned planes, as the dense array the kernel indexes (a pitched volume is packed first)
-    const size_t row_bytes = (size_t)res[0] * sizeof(float), plane_rows = (size_t)res[1];
+    if (!gn_publish_) {
+        hipSafeCall(hipHostMalloc((void **)&gn_publish_, xs_gn_publish_bytes(), hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(gn_publish_, 0, xs_gn_publish_bytes());
+    }
+    if (!gn_mailbox_ && gn_post_pose) check_rc(xs_icp_mailbox_alloc(&gn_mailbox_, &gn_mailbox_in_device_), "Gauss-Newton mailbox");
+    const size_t row_bytes = (size_t)volume_resolution[0] * sizeof(float), plane_rows = (size_t)volume_resolution[1];
     const float *gt = reinterpret_cast<const float *>(reinterpret_cast<const char *>(value.ptr()) + (size_t)(zo0 - zs0) * plane_rows * value.step());
     if (value.step() != row_bytes) {
         const size_t rows = (size_t)(zo1 - zo0) * plane_rows;
-        if (gn_dense_.size() < rows * res[0]) gn_dense_.create(rows * res[0]);
+        if (gn_dense_.size() < rows * volume_resolution[0]) gn_dense_.create(rows * volume_resolution[0]);
         hipSafeCall(hipMemcpy2DAsync(gn_dense_.ptr(), row_bytes, gt, value.step(), row_bytes, rows, hipMemcpyDeviceToDevice, st));
         gt = gn_dense_.ptr();
     }
-    check_rc(xs_tsdf_gauss_newton_terms(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(),
-                                        &kinect_intrinsic.fx, res, voxel_size, &R[0][0], &t[0][0], tsdf_volume_d_ptr->getTsdfTruncDist(), gt,
-                                        zo0, zo1, gn_ws_.ptr(), gn_sums_.ptr(), st), "GaussNewtonTerms");
-    if (shard_count > 1 && collective) collective(collective_user, 0, gn_sums_.ptr(), 29);
-    double h[29];
-    hipSafeCall(hipMemcpyAsync(h, gn_sums_.ptr(), sizeof(h), hipMemcpyDeviceToHost, st));
-    hipSafeCall(hipStreamSynchronize(st));
+    return gt;
+}
+// One pass enqueued: the kernel over the owned planes (poses as arguments, or — R null — from the mailbox with number mail_seq), in shard
+// mode the all-reduce of the 29 sums on the stream and then their publication; single GPU: the kernel's last workgroup publishes.  The host
+// reads the record with GaussNewtonWait(seq).
+void KinectFusionReconstruction::GaussNewtonEnqueue(const DeviceArray2D<ushort> &depth_frame_d, const float *gt, const float (*R)[18], const float (*t)[6],
+                                                    unsigned mail_seq, unsigned long long seq) {
+    hipStream_t st = current_stream();
+    const int res[3] = {volume_resolution[0], volume_resolution[1], volume_resolution[2]};
+    const bool sharded = shard_count > 1 && collective;
+    xs_gn_opts o = {};
+    o.struct_bytes = sizeof(o);
+    o.pose_mailbox = R ? nullptr : gn_mailbox_; o.mailbox_seq = mail_seq;
+    if (!sharded) { o.publish_host = gn_publish_; o.publish_seq = seq; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profiling && gn_events_.size() < 64) {   // (level 1 or 2: the kernel's own duration, for bench.py's host_us_per_pass)
+        hipSafeCall(hipEventCreate(&e0)); hipSafeCall(hipEventCreate(&e1));
+        gn_events_.push_back({e0, e1});
+        hipSafeCall(hipEventRecord(e0, st));
+    }
+    check_rc(xs_tsdf_gauss_newton_terms_ex(depthRawScaled_d.ptr(), depthRawScaled_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), &kinect_intrinsic.fx,
+                                           res, voxel_size, R ? &R[0][0] : nullptr, t ? &t[0][0] : nullptr, tsdf_volume_d_ptr->getTsdfTruncDist(), gt, zo0,
+                                           zo1, gn_ws_.ptr(), gn_sums_.ptr(), &o, st), "GaussNewtonTerms");
+    if (e1) hipSafeCall(hipEventRecord(e1, st));
+    if (sharded) {
+        collective(collective_user, 0, gn_sums_.ptr(), 29);
+        check_rc(xs_gn_publish_sums(gn_sums_.ptr(), 29, gn_publish_, seq, st), "GaussNewtonTerms");
+    }
+}
+// spins on the record's sequence word; false if the launch reported that it left without summing (abandoned, or its poses never came)
+bool KinectFusionReconstruction::GaussNewtonWait(unsigned long long seq, double out29[29]) {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(gn_publish_) + 32;
+    unsigned long long seen;
+    long spins = 0;
+    while ((seen = *flag) != seq) {
+        if (seen == (seq | (1ull << 63))) return false;
+        if (++spins > 4000000000L) { std::cout << "error::KinectFusionReconstruction, Gauss-Newton pass never published its sums" << std::endl; exit(-1); }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const double ih = 1.0 / (double)(float)H_;
-    for (int i = 0; i < 21; ++i) out29[i] = h[i] * ih * ih;
-    for (int i = 21; i < 27; ++i) out29[i] = h[i] * ih;
-    out29[27] = h[27]; out29[28] = h[28];
-    return 1;
+    for (int i = 0; i < 21; ++i) out29[i] = gn_publish_[i] * ih * ih;
+    for (int i = 21; i < 27; ++i) out29[i] = gn_publish_[i] * ih;
+    out29[27] = gn_publish_[27]; out29[28] = gn_publish_[28];
+    return true;
+}
+void KinectFusionReconstruction::GaussNewtonCollectEvents() {
+    for (auto &e : gn_events_) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { gn_kernel_ms += ms; ++gn_kernel_calls; }
+        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    gn_events_.clear();
 }
 
+// BASELINE config 5 (see the header): one pass of xs_tsdf_gauss_newton_terms for the six seeded poses
+int KinectFusionReconstruction::GaussNewtonTerms(const DeviceArray2D<ushort> &depth_frame_d, const Matrix4cf &camera2volume, double out29[29]) {
+    if (!tsdf_volume_d_ptr) return 0;
+    const float *gt = GaussNewtonPrepare(depth_frame_d);
+    float R[6][18], t[6][6];
+    gn_seeded_poses(camera2volume, R, t);
+    const unsigned long long seq = ++gn_seq_;
+    GaussNewtonEnqueue(depth_frame_d, gt, R, t, 0u, seq);
+    const bool ok = GaussNewtonWait(seq, out29);
+    GaussNewtonCollectEvents();
+    return ok ? 1 : 0;
+}
+
+// The Gauss-Newton loop with the ICP loop's protocol (round 6): the depth is scaled once per frame; a pass's sums reach the host through a
+// pinned record the kernel's last workgroup writes (no copy, no stream drain); and pass n + 1 is in the queue BEFORE the host waits for pass
+// n — its kernel resident, polling a mailbox for the six poses the host posts after the solve — so what stands between two kernels is the
+// record's way to the host, the 6x6 solve, six pose inversions and one posted write (YAML gn_post_pose, default true; single GPU with a mailbox
+// in device memory — a sharded rank enqueues pass n + 1 after the solve, its all-reduce on the stream in front of the publication).
 int KinectFusionReconstruction::RelocalizeGaussNewton(const DeviceArray2D<ushort> &depth_frame_d, Matrix4cf &camera2volume, int iterations,
                                                       float damping, std::vector<double> *loss_history) {
-    for (int it = 0; it < iterations; ++it) {
+    if (!tsdf_volume_d_ptr) return 0;
+    const int passes = iterations + (loss_history ? 1 : 0);   // (the last one only reports the loss the loop ended at)
+    if (passes <= 0) return 1;
+    const float *gt = GaussNewtonPrepare(depth_frame_d);
+    const bool ahead = gn_post_pose && shard_count == 1 && gn_mailbox_ && gn_mailbox_in_device_;
+    float R[6][18], t[6][6];
+    gn_seeded_poses(camera2volume, R, t);
+    unsigned long long seq = ++gn_seq_;
+    GaussNewtonEnqueue(depth_frame_d, gt, R, t, 0u, seq);
+    int rc = 1;
+    const auto t_begin = std::chrono::steady_clock::now();
+    int done = 0;
+    for (int p = 0; p < passes; ++p) {
+        unsigned long long next_seq = 0;
+        unsigned next_mail = 0;
+        if (ahead && p + 1 < passes) {
+            next_seq = ++gn_seq_; next_mail = ++gn_mail_seq_;
+            if (next_mail == 0) next_mail = ++gn_mail_seq_;   // (0 is the mailbox's initial content)
+            GaussNewtonEnqueue(depth_frame_d, gt, nullptr, nullptr, next_mail, next_seq);
+        }
+        auto leave = [&](int code) {   // the loop ends here: a launch that is waiting for its poses is told to leave, and has left before its buffers are reused
+            if (next_seq) {
+                xs_gn_post_poses(gn_mailbox_, nullptr, nullptr, next_mail, 1);
+                double ignore[29];
+                (void)GaussNewtonWait(next_seq, ignore);
+            }
+            rc = code;
+        };
         double s[29];
-        if (!GaussNewtonTerms(depth_frame_d, camera2volume, s)) return 0;
+        if (!GaussNewtonWait(seq, s)) { leave(0); break; }
+        ++done;
         if (loss_history) loss_history->push_back(s[28] > 0 ? s[27] / s[28] : 0.0);
-        if (s[28] < 6) return 0;  // nothing to align to
+        if (p == iterations) break;                           // the final loss pass
+        if (s[28] < 6) { leave(0); break; }                   // nothing to align to
         double A[36], b[6], x[6];
         int q = 0;
         for (int j = 0; j < 6; ++j)
             for (int k = j; k < 6; ++k, ++q) { A[j * 6 + k] = s[q]; A[k * 6 + j] = s[q]; }
         for (int k = 0; k < 6; ++k) { A[k * 6 + k] *= 1.0 + (double)damping; b[k] = -s[21 + k]; }
-        if (!solve_spd6(A, b, x)) return 0;
+        if (!solve_spd6(A, b, x)) { leave(0); break; }
         hostComplex xi[6];
         for (int k = 0; k < 6; ++k) xi[k] = hostComplex((float)x[k], 0.f);
         camera2volume = se3Exp(xi) * camera2volume;
+        if (p + 1 < passes) {
+            gn_seeded_poses(camera2volume, R, t);
+            if (next_seq) { xs_gn_post_poses(gn_mailbox_, &R[0][0], &t[0][0], next_mail, 0); seq = next_seq; }
+            else { seq = ++gn_seq_; GaussNewtonEnqueue(depth_frame_d, gt, R, t, 0u, seq); }
+        }
     }
-    if (loss_history) {
-        double s[29];
-        if (GaussNewtonTerms(depth_frame_d, camera2volume, s)) loss_history->push_back(s[28] > 0 ? s[27] / s[28] : 0.0);
-    }
-    return 1;
+    gn_pass_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    gn_passes += done;
+    GaussNewtonCollectEvents();
+    return rc;
 }
 
 // reference :334-372

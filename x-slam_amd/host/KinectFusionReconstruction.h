@@ -208,6 +208,15 @@ public:
     int GaussNewtonTerms(const DeviceArray2D<ushort> &depth_frame_d, const Matrix4cf &camera2volume, double out29[29]);
     int RelocalizeGaussNewton(const DeviceArray2D<ushort> &depth_frame_d, Matrix4cf &camera2volume, int iterations, float damping,
                               std::vector<double> *loss_history = nullptr);
+    // the loop protocol of the Gauss-Newton passes (see RelocalizeGaussNewton): YAML gn_post_pose, default true
+    bool gn_post_pose = true;
+    double gn_pass_us = 0, gn_kernel_ms = 0;       // wall clock of the passes RelocalizeGaussNewton ran (from its first kernel enqueued to its last sums seen) / kernel durations of the profiled passes
+    long long gn_passes = 0, gn_kernel_calls = 0;
+    const float *GaussNewtonPrepare(const DeviceArray2D<ushort> &depth_frame_d);
+    void GaussNewtonEnqueue(const DeviceArray2D<ushort> &depth_frame_d, const float *gt, const float (*R)[18], const float (*t)[6], unsigned mail_seq,
+                            unsigned long long seq);
+    bool GaussNewtonWait(unsigned long long seq, double out29[29]);
+    void GaussNewtonCollectEvents();
 
     // ExportPointCloud (reference :334-372, main.cpp:78-80): zero-crossing points of the TSDF with
     // normals, at most max_buffer of them; a sharded rank exports the planes it owns.
@@ -246,6 +255,12 @@ private:
     DeviceArray<double> icp_sums_;             // 27 complex sums + inlier count
     DeviceArray<unsigned char> icp_pose_;      // device-resident pose of the ICP loop (xs_icp_iterate)
     DeviceArray<double> gn_sums_;              // 29 Gauss-Newton sums (+ pad)
+    double *gn_publish_ = nullptr;             // pinned: the 29 sums + sequence word a pass publishes (xs_gn_publish_bytes)
+    void *gn_mailbox_ = nullptr;               // the six-pose mailbox of the passes enqueued ahead (xs_gn_post_poses)
+    int gn_mailbox_in_device_ = 0;
+    unsigned long long gn_seq_ = 0;
+    unsigned gn_mail_seq_ = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gn_events_;
     DeviceArray<float> gn_dense_;              // packed copy of the owned planes when the volume is pitched
     DeviceArray<unsigned char> gn_ws_;         // reduce workspace of the Gauss-Newton / Hessian kernels
     DeviceArray2D<ushort> depth_ingest_d_;     // device copy of a host frame (ProcessFrameHost)

@@ -258,6 +258,14 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4) {
     KF *k = (KF *)kf;
     for (int i = 0; i < 4; ++i) { if (us4) us4[i] = k->icp_level_us[i]; if (calls4) calls4[i] = k->icp_level_calls[i]; }
 }
+void xs_kf_gn_times(void *kf, double *pass_us, long long *passes, double *kernel_ms, long long *kernel_calls, int reset) {
+    KF *k = (KF *)kf;
+    if (pass_us) *pass_us = k->gn_pass_us;
+    if (passes) *passes = k->gn_passes;
+    if (kernel_ms) *kernel_ms = k->gn_kernel_ms;
+    if (kernel_calls) *kernel_calls = k->gn_kernel_calls;
+    if (reset) { k->gn_pass_us = 0; k->gn_passes = 0; k->gn_kernel_ms = 0; k->gn_kernel_calls = 0; }
+}
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v) { ((KF *)kf)->DebugSetIcpSequence(v); }
 void xs_kf_debug_fail_icp_iteration(void *kf, int n) { ((KF *)kf)->debug_fail_icp_iteration_ = n; }
 void xs_kf_debug_post_delay(void *kf, int min_us, int max_us) { ((KF *)kf)->debug_post_delay_us_[0] = min_us; ((KF *)kf)->debug_post_delay_us_[1] = max_us; }

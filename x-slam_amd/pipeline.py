@@ -53,6 +53,7 @@ _SIGS = {
     "xs_kf_reset_stage_times": (None, [_vp]),
     "xs_kf_icp_iteration_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_tail_host_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
+    "xs_kf_gn_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong), _f64p, C.POINTER(C.c_longlong), C.c_int]),
     "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
     "xs_kf_debug_post_delay": (None, [_vp, C.c_int, C.c_int]),
@@ -298,6 +299,13 @@ class KinectFusion:
         k = max(int(n.value), 1)
         return {"frames": int(n.value), "sums_seen_to_integrate_entered": round(float(us[0]) / k, 2), "entered_to_launch_call": round(float(us[1]) / k, 2),
                 "integrate_launch_call": round(float(us[2]) / k, 2), "launch_returned_to_raycast_launched": round(float(us[3]) / k, 2)}
+
+    def gn_times(self, reset=False):
+        """Gauss-Newton passes run by relocalize since the last reset: mean wall clock per pass and (profiling on) mean kernel duration, microseconds."""
+        pu, km = C.c_double(0), C.c_double(0)
+        n, kc = C.c_longlong(0), C.c_longlong(0)
+        _lib.xs_kf_gn_times(self.h, C.byref(pu), C.byref(n), C.byref(km), C.byref(kc), int(reset))
+        return {"passes": int(n.value), "pass_us": pu.value / max(n.value, 1), "kernel_calls": int(kc.value), "kernel_us": 1e3 * km.value / max(kc.value, 1)}
 
     def debug_set_icp_sequence(self, v):
         _lib.xs_kf_debug_set_icp_sequence(self.h, int(v))
