@@ -63,6 +63,8 @@ def run(n, mode, slack=2.0, threshold=0.0, frames=20, hint=False, sign=False):
 if __name__ == "__main__":
     import os
     sizes = [int(v) for v in sys.argv[1:]] or [512, 1024]
+    for c in (synth.FX, synth.FY):   # what the orchestrator does in AllocateBuffers: the band's / fx, / fy take the verified short division
+        capi.const_div_prepare(c)
     quick = os.environ.get("PROBE_QUICK")          # A/B sweeps: the two pipeline-like modes only, no comparison against the walk
     for n in sizes:
         if quick:
