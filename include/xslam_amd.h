@@ -60,13 +60,12 @@ int xs_scale_depth_max(const uint16_t *depth, size_t depth_step, int rows, int c
  * 8 x 8 pixel tile {float lo, hi} (an invalid pixel counts as 0).  No counterpart in the reference: the integrate kernel classifies
  * whole bricks from it (free space in front of every surface it can see: written with tsdf = (1, 0) without a projection; behind
  * everything it can see: skipped) and takes the reference's per-voxel path (TsdfFusion.cu:110-167) for the rest — same volume.
- * xs_integrate_set_depth_tiles hands the table to the following xs_integrate_scaled* calls of the calling thread (NULL: each call
- * builds its own from the scaled image, in its workspace); xs_depth_tiles builds it from an image that is already scaled. */
+ * xs_integrate_opts.depth_tiles hands the table to an xs_integrate_scaled_ex2 / xs_integrate_classify_ex call (NULL: the call builds its
+ * own from the scaled image, in its workspace); xs_depth_tiles builds it from an image that is already scaled. */
 size_t xs_depth_tiles_bytes(int rows, int cols);
 int xs_scale_depth_tiles(const uint16_t *depth, size_t depth_step, int rows, int cols, float *scaled, size_t scaled_step,
                          float *max_dev, void *tiles_dev, void *stream);
 int xs_depth_tiles(const float *scaled, size_t scaled_step, int rows, int cols, void *tiles_dev, void *stream);
-void xs_integrate_set_depth_tiles(const void *tiles_dev);
 
 /* integrateTsdfVolume(const PtrStepSz<ushort>& depth, const Intr&, int max_weight, const int3& res,
  *     float voxel_size, const MatS33& Rv2c, const devComplex3& tv2c, const devComplex3& tc2v,
@@ -97,7 +96,7 @@ int xs_integrate_scaled(const float *depth_scaled, size_t scaled_step, int rows,
 #define XS_INTEGRATE_HEADER_IS_CLEAR 1u
 #define XS_INTEGRATE_NO_FOLD 2u
 #define XS_INTEGRATE_ALWAYS_STORE 8u    /* store all three words of every updated voxel, also where their bits do not change (the default stores only words that change: same volume, fewer bytes) */
-#define XS_INTEGRATE_POSE_POSTED 16u     /* the kernel takes its pose from a mailbox (xs_integrate_set_pose_mailbox / xs_integrate_post_pose): see below */
+#define XS_INTEGRATE_POSE_POSTED 16u     /* the kernel takes its pose from a mailbox (xs_integrate_opts.pose_mailbox; posted with xs_icp_post_pose): see below */
 #define XS_INTEGRATE_NO_TILES 32u        /* every brick takes the exact per-voxel walk: no free-space / nothing-to-write classification from the depth tiles (A/B and tests; same volume either way) */
 #define XS_INTEGRATE_COUNT_CLASSES 64u   /* the kernel counts the wave-sized boxes it classified: 32-bit words 48 / 49 / 50 of the workspace = free / nothing to write / exact walk (cleared with the header; tests and bench figures) */
 #define XS_INTEGRATE_RECLASSIFY_BOXES 128u /* with XS_INTEGRATE_LIST_IS_READY: the brick list holds for this pose but the box classes xs_integrate_classify left do not (xs_integrate_list_covers returned 1, not 3): classify the boxes again, with this pose */
@@ -116,18 +115,17 @@ int xs_integrate_fold_counts(void *workspace, unsigned long long *updated_dev, v
  * image size, else clear the header again (xs_integrate_workspace_clear) and call it without.  flags of xs_integrate_classify:
  * XS_INTEGRATE_HEADER_IS_CLEAR as above.  Results are those of the plain call, bit for bit (the list is a superset; every voxel
  * still takes the exact tests with the final pose).
- * With a depth-tile table named (xs_integrate_set_depth_tiles) xs_integrate_classify also decides the boxes' classes (free space /
+ * With a depth-tile table named (xs_integrate_opts.depth_tiles) xs_integrate_classify_ex also decides the boxes' classes (free space /
  * nothing to write / per-voxel walk), padded for every pose within the slack's allowances; xs_integrate_list_covers returns 0 (the
  * list does not hold), 1 (the list holds, the classes do not: add XS_INTEGRATE_RECLASSIFY_BOXES to the call's flags) or 3 (both hold). */
 /* The integrate kernel enqueued before its pose exists (flag XS_INTEGRATE_POSE_POSTED, with XS_INTEGRATE_LIST_IS_READY | XS_INTEGRATE_HEADER_IS_CLEAR):
- * xs_integrate_set_pose_mailbox(mailbox, seq, slack_scale, pose_dev) names — for the NEXT xs_integrate_scaled_ex call of this thread — the mailbox
+ * xs_integrate_opts.pose_mailbox / mailbox_seq / mailbox_slack / pose_dev name — for an xs_integrate_scaled_ex2 call — the mailbox
  * (xs_icp_mailbox_alloc: one of its own, not the ICP loop's) that a one-wave gate kernel in front of the integrate kernel polls, the sequence number
  * it waits for, the factor the call widens the frustum planes by, and 128 bytes of device memory (pose_dev) through which the gate hands the pose on; that call is given the pose the brick list was classified with (xs_integrate_classify) and uses it for the planes only.
  * When the final pose is known: if xs_integrate_pose_covered(..., list pose, slack_scale, final pose) post it with
  * xs_icp_post_pose(mailbox, Rv2c18, tv2c6, seq, 0) — the kernel then integrates with exactly that pose, same volume as a plain call — else post
  * xs_icp_post_pose(mailbox, NULL, NULL, seq, 1): the launch leaves without touching the volume, and a plain call follows.  Every posted launch must
  * be answered by exactly one post (it gives up after ~1 s otherwise).  Sequence numbers: non-zero, increasing per mailbox. */
-void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mailbox_seq, float slack_scale, void *pose_dev);
 int xs_integrate_pose_covered(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18_list,
                               const float *tv2c6_list, float slack_scale, const float *Rv2c18, const float *tv2c6);
 int xs_integrate_classify(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
@@ -139,27 +137,22 @@ int xs_integrate_list_covers(int rows, int cols, const float *intr4, const int *
  * workspace the kernel first lists the 64x4x8-voxel bricks that can intersect the frustum and
  * then spreads them over all CUs; without one (NULL) each column walks its own clipped range. */
 size_t xs_integrate_workspace_bytes(const int *res, int nz);
-/* Event hook (per host thread): hipEvent_t pair attached to the dispatch of the integrate kernel
- * proper (after the brick classification) — the kernel's own begin / end, no marker packets on the
- * stream; either may be NULL (a stop event alone is a completion event another stream can wait on);
- * NULL, NULL disables.  Workspace path only. */
-void xs_integrate_set_timing_events(void *start_event, void *stop_event);
-/* Event hook (per host thread): hipEvent_t attached to the last dispatch of xs_integrate_classify — its completion, no marker packet —
- * for a caller that classifies on one stream and integrates on another (the orchestrator: the classification runs beside the last ICP
- * launch, on the auxiliary stream); NULL disables. */
-void xs_integrate_set_classify_event(void *done_event);
 
-/* ---- Options structs (round 5): what the per-thread setters above carry, as an argument ------------------------------------------
- * xs_integrate_scaled_ex2 / xs_integrate_classify_ex / xs_raycast_ex / xs_raycast_slab_ex / xs_resize_pyramid_ex take everything the call
- * needs in their argument lists; they read NO per-thread state, so nothing a previous call set (or an early return forgot to clear) can
- * leak into them.  The setters (xs_integrate_set_*, xs_raycast_set_*, xs_resize_pyramid_set_completion_event) remain as thin wrappers:
- * they fill one per-thread struct of the same type, which only the older entry points (xs_integrate_scaled*, xs_integrate_classify,
- * xs_raycast, xs_raycast_slab, xs_resize_pyramid) read.  Zero-initialise a struct, set struct_bytes = sizeof(it), fill what applies.
+/* ---- Options structs ---------------------------------------------------------------------------------------------------------------
+ * Everything a call takes besides its arguments proper — depth-tile table, sign map, events, pose mailbox, pyramid outputs — travels in an
+ * options struct that is an argument of the call: xs_integrate_scaled_ex2 / xs_integrate_classify_ex / xs_raycast_ex / xs_raycast_slab_ex /
+ * xs_resize_pyramid_ex.  The library keeps NO per-thread state (ABI version 2: the xs_*_set_* functions of version 1 are gone), so nothing
+ * a previous call set, or an early return forgot to clear, can leak into a call.  The entry points without a struct (xs_integrate_scaled*,
+ * xs_integrate_classify, xs_raycast, xs_raycast_slab, xs_resize_pyramid) are the same calls with an empty one.
+ * Zero-initialise a struct, set struct_bytes = sizeof(it), fill what applies.
+ *   events      hipEvent_t riding on a kernel's own dispatch (its begin / end: no marker packets on the stream); a stop event alone is a completion
+ *               event another stream can wait on.
  *
- * The library remembers, per host thread, what xs_integrate_classify* last classified (workspace, pose, slack): a following integrate call
- * with XS_INTEGRATE_LIST_IS_READY uses those box classes only after checking ITS pose against the slack they were padded for, and
- * decides the boxes again with its own pose otherwise — XS_INTEGRATE_RECLASSIFY_BOXES is a hint that saves the check, not a
- * correctness requirement (the brick LIST itself is the caller's claim: xs_integrate_list_covers). */
+ * The library remembers, per WORKSPACE, what xs_integrate_classify* last classified into it (pose, slack, slab, volume, camera, band, tile
+ * table): a following integrate call with XS_INTEGRATE_LIST_IS_READY on that workspace uses those box classes only if all of that is its
+ * own and ITS pose lies within the slack they were padded for, and decides the boxes again with its own pose otherwise —
+ * XS_INTEGRATE_RECLASSIFY_BOXES is a hint that saves the check, not a correctness requirement (the brick LIST itself is the caller's claim:
+ * xs_integrate_list_covers).  Classifying on one host thread and integrating on another is fine. */
 typedef struct xs_integrate_opts {
     unsigned struct_bytes;           /* sizeof(xs_integrate_opts) */
     unsigned flags;                  /* XS_INTEGRATE_* */
@@ -252,9 +245,7 @@ int xs_resize_nmap(const float *in, size_t in_step, int src_rows, int src_cols, 
  * separate calls.  rows0 / cols0: one plane of the level-0 maps. */
 int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
                       size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *stream);
-/* Thread-local: an event that rides on the following xs_resize_pyramid dispatches (recorded when the kernel completes, with no marker packet
- * behind it in the stream); NULL = none. */
-void xs_resize_pyramid_set_completion_event(void *event);
+/* (xs_resize_pyramid_ex, below: the same with a completion event riding on the dispatch) */
 
 /* ---- Raycast ------------------------------------------------------------------------------ */
 /* raycast(const Intr&, const MatS33& Rc2v, const devComplex3& tc2v, const MatS33& Rv2w,
@@ -267,10 +258,8 @@ int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, cons
                float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
                void *stream);
-/* Measurement hook (bench.py, SURVEY 8(d): "Raycast: report Mrays/s and steps/ray"): a device buffer of rows x cols ints that the
- * following xs_raycast calls of this thread fill with each ray's march length — the iterations the reference's loop (RayCaster.cu:222-247)
- * runs for it; NULL switches it off. */
-void xs_raycast_set_step_buffer(int *steps_dev);
+/* (Measurement hook of bench.py, SURVEY 8(d) "Raycast: report Mrays/s and steps/ray": xs_raycast_opts.steps_dev, a device buffer of
+ * rows x cols ints that xs_raycast_ex fills with each ray's march length — the iterations the reference's loop, RayCaster.cu:222-247, runs for it.) */
 
 /* ---- The sign map: where a ray's march may start (no counterpart in the reference) ---------------------------------------------
  * RayCaster.cu:222-247 evaluates every step of every ray from t = 0.2 m.  Each event that can end that loop — a sample outside the
@@ -279,7 +268,7 @@ void xs_raycast_set_step_buffer(int *steps_dev);
  * rebuild: a superset); the march (single GPU, or a rank's slab march) samples it along the ray, finds the stretch that cannot hold an event, and resumes the
  * reference's loop behind it at the float time that loop would have there (a table of its running sum) with the value it would
  * carry — the same crossing, vertex and normal bits, about a fifth of the volume reads (march kernel 48 -> 22 us on the benchmark scene).  The owner of the volume is responsible for
- * the map seeing every write: xs_integrate_* mark it when xs_integrate_set_signmap names it; after any other write into the value
+ * the map seeing every write: xs_integrate_scaled_ex2 marks it when xs_integrate_opts.signmap names it; after any other write into the value
  * array (a checkpoint, a host upload) call xs_signmap_rebuild, after xs_init_volume call xs_signmap_reset.
  *   xs_raycast_signmap_shift   the smallest brick shift the march can use for these intrinsics, voxel size and truncation distance — the
  *                        finest map, measured fastest — or 0 if none (the bricks must outgrow a wave's pixel tile at 5 m; the march at most
@@ -287,27 +276,23 @@ void xs_raycast_set_step_buffer(int *steps_dev);
  *   xs_signmap_bytes     size of the device buffer for a resolution and brick shift (2..6; 3 = 8^3 voxels), 0 if invalid
  *   xs_signmap_reset     empty map + the time table for tranc_dist (time step 0.8 * tranc_dist, RayCaster.cu:350)
  *   xs_signmap_rebuild   reset, then mark every brick of `value` that holds a negative voxel
- *   xs_integrate_set_signmap   thread-local: the map the following xs_integrate_* calls mark (slab launches mark the bricks of their own planes; NULL = none)
- *   xs_raycast_set_signmap     thread-local: the map the following xs_raycast (with a workspace) and xs_raycast_slab calls march by — a rank of a
- *                              sharded volume passes the map its own integrate calls (owned slab + halo) marked; it must
- *                              have been reset for the same tranc_dist, else xs_raycast refuses; NULL = march from t = 0.2 */
+ *   xs_integrate_opts.signmap  the map an xs_integrate_scaled_ex2 call marks (slab launches mark the bricks of their own planes; NULL = none).  EVERY
+ *                              integrate call on a volume that has a map must name it: the streamed planes of a later call do not re-mark
+ *                              what an unmarked earlier call wrote
+ *   xs_raycast_opts.signmap / signmap_shift / signmap_tranc_dist   the map an xs_raycast_ex (with a workspace) / xs_raycast_slab_ex call marches
+ *                              by — a rank of a sharded volume passes the map its own integrate calls (owned slab + halo) marked; it must
+ *                              have been reset for the same tranc_dist, else the call refuses; NULL = march from t = 0.2 */
 int xs_raycast_signmap_shift(const float *intr4, float voxel_size, float tranc_dist);
 size_t xs_signmap_bytes(const int *res, int shift);
 int xs_signmap_reset(void *signmap, const int *res, int shift, float tranc_dist, void *stream);
 int xs_signmap_rebuild(void *signmap, const int *res, int shift, float tranc_dist, const float *value, size_t vol_step, void *stream);
 int xs_signmap_rebuild_slab(void *signmap, const int *res, int shift, float tranc_dist, const float *value, size_t vol_step, int zs0, int zs1,
                             void *stream);   /* one rank's storage of a z-sharded volume: value holds planes [zs0, zs1) */
-void xs_integrate_set_signmap(void *signmap);
-void xs_raycast_set_signmap(const void *signmap, int shift, float tranc_dist);
 
 /* The one-launch form of xs_raycast (workspace + sign map) can build the model-map pyramid too — levels 1 and 2 of the vertex and of the
  * normal map, the values xs_resize_pyramid writes (resizeVMap / resizeNMap twice, Map.h:46-54): every workgroup halves its own pixel tile
- * twice, so the frame's tail loses a launch.  xs_raycast_set_pyramid names the four maps for the next xs_raycast call of the thread (NULLs:
- * none); xs_raycast_pyramid_built() tells whether that call built them (0: launch xs_resize_pyramid as before).
- * xs_raycast_set_completion_event: an event that rides on that launch's dispatch (its completion), or NULL. */
-void xs_raycast_set_pyramid(float *vmap1, float *nmap1, size_t step1, float *vmap2, float *nmap2, size_t step2);
-int xs_raycast_pyramid_built(void);
-void xs_raycast_set_completion_event(void *event);
+ * twice, so the frame's tail loses a launch.  xs_raycast_opts.pyr_* name the four maps (NULLs: none); .pyramid_built tells whether the call
+ * built them (0: launch xs_resize_pyramid as before); .completion_event rides on that launch's dispatch (its completion), or NULL. */
 
 /* Slab form for a z-sharded volume (the reference is single-GPU; per-ray semantics are those of
  * RayCaster.cu:197-310).  value / grad hold planes [zs0, zs1) = owned slab + halo (6 planes);

@@ -21,7 +21,6 @@ counter = torch.zeros(1, dtype=torch.int64, device="cuda")
 hip = C.CDLL("libamdhip64.so"); ev = [C.c_void_p(), C.c_void_p()]
 for e in ev:
     assert hip.hipEventCreate(C.byref(e)) == 0
-capi._lib.xs_integrate_set_timing_events(ev[0], ev[1])
 s = torch.cuda.current_stream()
 times, bricks, Us = [], [], []
 for k in range(24):
@@ -29,7 +28,7 @@ for k in range(24):
     capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
     T = synth.s1_transforms(k, prm)
     counter.zero_()
-    capi.integrate_scaled_ex(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, 0 if os.environ.get("XS_PROBE_NO_COUNT") else 64, updated=counter, depth_max=dmax, workspace=ws, stream=s)
+    capi.integrate_scaled_ex(scaled, W * 4, H, W, intr, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, value, weight, grad, n * 4, 0 if os.environ.get("XS_PROBE_NO_COUNT") else 64, start_event=ev[0], stop_event=ev[1], updated=counter, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
     classes = [int(x) for x in ws[192:204].view(torch.int32).cpu().numpy()]
     dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0

@@ -106,19 +106,17 @@ def main():
     sweep = lambda: sweep_buf.sum()
 
     def regime(name, flags, before=(), min_s=0.4, max_reps=400):
-        capi._lib.xs_integrate_set_timing_events(ev[0], ev[1])
         ms = []
         smi.window()
         t0 = time.perf_counter()
         while (time.perf_counter() - t0 < min_s or len(ms) < 8) and len(ms) < max_reps:
             for f in before:
                 f()
-            capi.integrate_scaled_ex(*args, flags, depth_max=dmax, workspace=ws, stream=s)
+            capi.integrate_scaled_ex(*args, flags, depth_max=dmax, workspace=ws, stream=s, start_event=ev[0], stop_event=ev[1])
             torch.cuda.synchronize()
             dt = C.c_float(0); assert hip.hipEventElapsedTime(C.byref(dt), ev[0], ev[1]) == 0
             ms.append(dt.value)
         card = smi.close_window()
-        capi._lib.xs_integrate_set_timing_events(None, None)
         ms = np.array(ms)
         med = float(np.median(ms))
         rec = {"regime": name, "launches": len(ms), "kernel_ms": {"min": round(float(ms.min()), 4), "median": round(med, 4), "max": round(float(ms.max()), 4)},

@@ -39,10 +39,7 @@ for shift in (0, 3, 4, 5):
     if shift:
         sm = torch.zeros(capi.signmap_bytes([N, N, N], shift), dtype=torch.uint8, device="cuda")
         capi.signmap_rebuild(sm, [N, N, N], shift, td, pv, step, stream=s)
-    capi.raycast_set_signmap(sm, shift, td)
-    capi.raycast_set_step_buffer(steps)
-    capi.raycast(*args, workspace=ws, stream=s)
-    capi.raycast_set_step_buffer(None)
+    capi.raycast(*args, workspace=ws, stream=s, signmap=sm, signmap_shift=shift or 3, signmap_tranc_dist=td, steps=steps)
     torch.cuda.synchronize()
     out = (ws.cpu().numpy().copy(), steps.cpu().numpy().copy())
     if ref is None:
@@ -50,8 +47,9 @@ for shift in (0, 3, 4, 5):
     same = all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(out, ref))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
+    o = capi.raycast_opts(signmap=sm, shift=shift or 3, tranc_dist=td)
     for _ in range(50):
-        capi.raycast(*args, workspace=ws, stream=s)
+        capi.raycast_ex(*args, o, workspace=ws, stream=s)
     e1.record(s)
     torch.cuda.synchronize()
     if os.environ.get("PROBE_STAGE") == "1":
@@ -62,4 +60,3 @@ for shift in (0, 3, 4, 5):
         print("   per 8x8 tile: max evaluated: mean", round(float(tiles.max(1).mean()), 1), " tiles needing > 16:", round(float((tiles.max(1) > 16).mean()), 3),
               " > 24:", round(float((tiles.max(1) > 24).mean()), 3), " > 32:", round(float((tiles.max(1) > 32).mean()), 3), flush=True)
     print(f"shift {shift}: march + crossing {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us   mean steps/ray {out[1].mean():.1f}   same bits {same}", flush=True)
-capi.raycast_set_signmap(None)

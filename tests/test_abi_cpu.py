@@ -35,7 +35,7 @@ def test_ctypes_tables_cover_the_headers():
     pl = importlib.import_module("x-slam_amd.pipeline")
     assert set(declared("xslam_amd.h")) == set(capi._SIGS)
     assert set(declared("xslam_amd_pipeline.h")) == set(pl._SIGS)
-    assert capi.abi_version() == 1
+    assert capi.abi_version() == 2
     assert capi.icp_workspace_bytes() > 0 and capi.tsdf_reduce_workspace_bytes() > 0
     assert capi.integrate_workspace_bytes([512, 512, 512]) == 256 + 8192 * 4 + 8 * 128 * 256 * 4 + 8 * 128 * 256 * 4 * 4 + (1 << 20) + 8 * 128 * 256 * 4   # header + update counts (a word per workgroup) + brick list + box classes (a word per wave-sized box) + the call's own depth-tile table + the list in the order it is taken
     assert capi.depth_tiles_bytes(480, 640) == (60 * 80 + 15 * 10) * 8
@@ -246,7 +246,7 @@ def test_integration_md_shim_compiles_and_links(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     # the options-struct form shown in "Additions of round 5" compiles and links as written too (wrapped into a function that declares its names)
-    opts = [b for b in blocks if "xs_integrate_scaled_ex2(" in b and "xs_raycast_ex(" in b]
+    opts = [b for b in blocks if "xs_integrate_scaled_ex2(" in b and "xs_raycast_ex(" in b and "integrate_done" in b]
     assert len(opts) == 1
     (tmp_path / "OptsCaller.cpp").write_text(
         '#include "xslam_amd.h"\n'
@@ -350,3 +350,25 @@ def test_sign_map_host_side_sizes_and_shifts():
     assert capi.raycast_signmap_shift(synth.intr_of(prm), 1e-4, 3e-4) == 0                          # 16 000 steps
     wide = synth.intr_of(prm) / 8.0                                                                 # a very wide lens: the tile outgrows the bricks
     assert capi.raycast_signmap_shift(wide, prm["tsdf_voxel_size"], synth.tranc_dist(prm)) in (0, 5, 6)
+
+
+def test_no_per_thread_setter_is_exported():
+    """ABI 2: libxslam_hip.so exports no xs_*_set_* function — every option travels in a struct that is an argument."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "x-slam_amd", "libxslam_hip.so")], capture_output=True, text=True, check=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if " T " in line]
+    assert len([n for n in names if n.startswith("xs_")]) > 70
+    assert [n for n in names if "_set_" in n and n.startswith("xs_") and n != "xs_set_error"] == []    # (xs_set_error: the error plumbing, no setter)
+
+
+def test_bench_fails_fast_without_a_gpu_per_rank():
+    """bench.py --gpus N on a node with fewer than N GPUs (here: none) exits at once, non-zero, with a line that says why — before any rank is
+    started, without initialising a device."""
+    import subprocess
+    import sys
+    import time
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    assert "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
+    assert time.perf_counter() - t0 < 120

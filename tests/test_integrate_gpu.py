@@ -221,9 +221,8 @@ def test_integrate_with_the_pose_posted_to_an_enqueued_launch(dev):
                 else:
                     seq = 7 if mode == "posted" else 9
                     capi.integrate_classify(Hd, Wd, k4, res, vs, T_list["Rv2c"], T_list["tv2c"], trunc, ws, slack_scale=2.0, depth_max=dmax)
-                    capi.integrate_set_pose_mailbox(mailbox, seq, 2.0, pose_dev)
                     capi.integrate_scaled_ex(*args, T_list["Rv2c"], T_list["tv2c"], *tail, 16 | 4 | 1, threshold=threshold, updated=counter, depth_max=dmax,
-                                             workspace=ws)
+                                             workspace=ws, pose_mailbox=mailbox, mailbox_seq=seq, mailbox_slack=2.0, pose_dev=pose_dev)
                     if mode == "posted":
                         capi.icp_post_pose(mailbox, T_fin["Rv2c"], T_fin["tv2c"], seq, 0)
                     else:
@@ -566,17 +565,14 @@ def test_brick_classification_is_invisible(dev, oracle, n, threshold):
             dmax.zero_(); counter.zero_()
             capi.scale_depth_tiles(depth, Ww * 2, Hh, Ww, scaled, Ww * 4, dmax, tiles)
             T = s1_transforms(k, prm)
-            capi.integrate_set_depth_tiles(None if own_tiles else tiles)
-            try:
-                for s in range(slabs):
-                    z0, z1 = bounds[s], bounds[s + 1]
-                    ws = torch.zeros(capi.integrate_workspace_bytes(res, z1 - z0), dtype=torch.uint8, device="cuda")
-                    capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 3, res, vs, T["Rv2c"], T["tv2c"], trunc, v[z0 * n:], w[z0 * n:], g[z0 * n:], n * 4,
-                                             flags | 64, threshold=threshold, z0=z0, z1=z1, updated=counter, depth_max=dmax, workspace=ws)
-                    torch.cuda.synchronize()
-                    classes += class_counts(ws)
-            finally:
-                capi.integrate_set_depth_tiles(None)
+            for s in range(slabs):
+                z0, z1 = bounds[s], bounds[s + 1]
+                ws = torch.zeros(capi.integrate_workspace_bytes(res, z1 - z0), dtype=torch.uint8, device="cuda")
+                capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 3, res, vs, T["Rv2c"], T["tv2c"], trunc, v[z0 * n:], w[z0 * n:], g[z0 * n:], n * 4,
+                                         flags | 64, threshold=threshold, z0=z0, z1=z1, updated=counter, depth_max=dmax, workspace=ws,
+                                         depth_tiles=None if own_tiles else tiles)
+                torch.cuda.synchronize()
+                classes += class_counts(ws)
             counts.append(int(counter.item()))
         return [t.cpu().numpy().reshape(-1) for t in (v, w, g)] + [counts], classes
 
@@ -646,13 +642,9 @@ def test_box_classes_decided_ahead_for_a_nearby_pose(dev, threshold):
             if not covers:
                 continue
             c = torch.zeros(1, dtype=torch.int64, device="cuda")
-            capi.integrate_set_depth_tiles(tiles)
-            try:
-                capi.integrate_classify(Hh, Ww, k4, res, vs, Rl, tl, trunc, ws, slack_scale=2.0, flags=64, depth_max=dmax)
-                capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, *vols[name], n * 4,
-                                         1 | 4 | 64 | (0 if covers & 2 else 128), threshold=threshold, updated=c, depth_max=dmax, workspace=ws)
-            finally:
-                capi.integrate_set_depth_tiles(None)
+            capi.integrate_classify(Hh, Ww, k4, res, vs, Rl, tl, trunc, ws, slack_scale=2.0, flags=64, depth_max=dmax, depth_tiles=tiles)
+            capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, *vols[name], n * 4,
+                                     1 | 4 | 64 | (0 if covers & 2 else 128), threshold=threshold, updated=c, depth_max=dmax, workspace=ws, depth_tiles=tiles)
             torch.cuda.synchronize()
             free_taken += class_counts(ws)[0]
             assert int(c.item()) == int(cp.item()) > 1000, name
@@ -736,12 +728,9 @@ def test_bricks_with_planes_to_walk_are_taken_first(dev):
         assert (w_front > 0).all() and (w_back == 0).all()
         assert int(w_front.sum()) == int(host[204:208].view(np.int32)[0])        # header word 51: planes walked, counted as they were classified
         # a wider list classified ahead, its classes decided again for the pose itself
-        capi.integrate_set_depth_tiles(tiles)
-        try:
-            capi.integrate_classify(Hh, Ww, k4, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, slack_scale=2.0, depth_max=dmax)
-            capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, v, w, g, n * 4, 1 | 4 | 128, depth_max=dmax, workspace=ws)
-        finally:
-            capi.integrate_set_depth_tiles(None)
+        capi.integrate_classify(Hh, Ww, k4, res, vs, T["Rv2c"], T["tv2c"], trunc, ws, slack_scale=2.0, depth_max=dmax, depth_tiles=tiles)
+        capi.integrate_scaled_ex(scaled, Ww * 4, Hh, Ww, k4, 100, res, vs, T["Rv2c"], T["tv2c"], trunc, v, w, g, n * 4, 1 | 4 | 128, depth_max=dmax, workspace=ws,
+                                 depth_tiles=tiles)
         torch.cuda.synchronize()
         host = ws.cpu().numpy()
         wide = listed(host)
@@ -876,8 +865,8 @@ def _one_frame_setup(torch, capi, n, k=3, threshold=0.0):
 
 def test_options_struct_entry_points_read_no_thread_state(dev):
     """xs_integrate_scaled_ex2 / xs_integrate_classify_ex take the depth tiles, the sign map and the events in their options struct and read
-    nothing the per-thread setters left: with a poisoned per-thread tile table (all zeros: every box would be called empty and nothing
-    written) they produce the plain call's volume bit for bit, with the tiles handed over in the struct or built by the call itself."""
+    nothing else (ABI 2 has no per-thread setters left): they produce the per-voxel walk's volume bit for bit with the tiles handed over in the
+    struct or built by the call itself, classified ahead or not, and classes decided from ANOTHER tile table are not trusted."""
     torch, capi = dev
     n = 128
     prm, res, T, scaled, dmax, tiles, ws, volume, common = _one_frame_setup(torch, capi, n)
@@ -887,35 +876,43 @@ def test_options_struct_entry_points_read_no_thread_state(dev):
     torch.cuda.synchronize()
     U = int(cnt.item())
     assert U > 10000
-    poison = torch.zeros_like(tiles)
-    capi.integrate_set_depth_tiles(poison)
-    try:
-        for own_tiles in (tiles, None):
-            vol = volume()
-            cnt.zero_()
-            capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=0, depth_tiles=own_tiles), updated=cnt, depth_max=dmax, workspace=ws)
-            torch.cuda.synchronize()
-            assert int(cnt.item()) == U
-            for a, b in zip(ref, vol):
-                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
-        # ... and classified ahead through the struct
+    for own_tiles in (tiles, None):
         vol = volume()
         cnt.zero_()
-        capi.integrate_classify_ex(synth.HEIGHT, synth.WIDTH, intr_of(prm), res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), ws,
-                                   capi.integrate_opts(flags=0, depth_tiles=tiles), slack_scale=2.0, depth_max=dmax)
-        capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=4 | 1, depth_tiles=tiles), updated=cnt, depth_max=dmax, workspace=ws)
+        capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=0, depth_tiles=own_tiles), updated=cnt, depth_max=dmax, workspace=ws)
         torch.cuda.synchronize()
         assert int(cnt.item()) == U
         for a, b in zip(ref, vol):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
-        # the older entry point does read the per-thread table: the poison shows (this is what the struct calls are immune to)
-        vol = volume()
-        cnt.zero_()
-        capi.integrate_scaled_ex(*common(vol, T["Rv2c"], T["tv2c"]), 0, updated=cnt, depth_max=dmax, workspace=ws)
-        torch.cuda.synchronize()
-        assert int(cnt.item()) < U
-    finally:
-        capi.integrate_set_depth_tiles(None)
+    # ... and classified ahead through the struct
+    vol = volume()
+    cnt.zero_()
+    capi.integrate_classify_ex(synth.HEIGHT, synth.WIDTH, intr_of(prm), res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), ws,
+                               capi.integrate_opts(flags=0, depth_tiles=tiles), slack_scale=2.0, depth_max=dmax)
+    capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=4 | 1, depth_tiles=tiles), updated=cnt, depth_max=dmax, workspace=ws)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == U
+    for a, b in zip(ref, vol):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # the classes a classification left in a workspace are this call's only if they were decided for ITS tile table (and slab, camera,
+    # band): classes decided from another frame's table — here a poisoned one, all zeros: every box "sees nothing valid" and would be skipped —
+    # followed by LIST_IS_READY with the real table must be decided again, not trusted (round 5 kept workspace, pose and slack only)
+    poison = torch.zeros_like(tiles)
+    vol = volume()
+    cnt.zero_()
+    capi.integrate_classify_ex(synth.HEIGHT, synth.WIDTH, intr_of(prm), res, prm["tsdf_voxel_size"], T["Rv2c"], T["tv2c"], tranc_dist(prm), ws,
+                               capi.integrate_opts(flags=0, depth_tiles=poison), slack_scale=2.0, depth_max=dmax)
+    capi.integrate_scaled_ex2(*common(vol, T["Rv2c"], T["tv2c"]), capi.integrate_opts(flags=4 | 1, depth_tiles=tiles), updated=cnt, depth_max=dmax, workspace=ws)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == U
+    for a, b in zip(ref, vol):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # the entry point without a struct is the same call with an empty one (ABI 2: no per-thread state is left for it to read)
+    vol = volume()
+    cnt.zero_()
+    capi.integrate_scaled(*common(vol, T["Rv2c"], T["tv2c"]), updated=cnt, depth_max=dmax, workspace=ws)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == U
     with pytest.raises(capi.XsError):
         bad = capi.integrate_opts()
         bad.struct_bytes = 8

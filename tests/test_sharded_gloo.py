@@ -164,7 +164,7 @@ class ProtocolKinFu:
         self.frame_id += 1
 
 
-def _worker(rank, world, port, n, nframes):
+def _worker(rank, world, port, n, nframes, threads=2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -176,7 +176,7 @@ def _worker(rank, world, port, n, nframes):
     sh = importlib.import_module("x-slam_amd.sharded")
     capi = importlib.import_module("x-slam_amd.capi")
     o = Oracle()
-    o._set_num_threads(2)
+    o._set_num_threads(threads)
     prm = synth.s1_params(n)
     frames = [synth.s1_frame(k) for k in range(nframes)]
     whole = ProtocolKinFu(o, sh, capi, synth, prm, 0, 1, None)
@@ -235,6 +235,16 @@ def test_sharded_protocol_world4_gloo(oracle):
     gloo collectives: min-key all-reduce, counts, the four-way gather-v of the owned pixels, the 440-byte ICP all-reduce."""
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(4, _free_port(), 48, 2), nprocs=4, join=True)
+
+
+@pytest.mark.timeout(1200)
+def test_sharded_protocol_world8_gloo(oracle):
+    """Eight ranks, each a process (the shape of the driver's 8-GPU launch; the GPU tests reach world 8 only as threads of one process): a
+    128-plane volume in 16-plane slabs, so every inner rank's 6-plane halos lie wholly inside both neighbours; the eight-way rendezvous, the
+    min-key all-reduce, the eight-part gather-v descriptor of the owned pixels, the ICP all-reduce over eight pixel-row shards (60 / 30 / 15 rows
+    per rank and level).  One oracle thread per rank: eight processes on the container's eight cores."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(8, _free_port(), 128, 2, 1), nprocs=8, join=True)
 
 
 def test_slab_and_row_bounds_tile():

@@ -31,19 +31,15 @@ def fuse(torch, capi, prm, res, frames, signmap=None, shift=3, bricks=True, dept
     ws = torch.zeros(capi.integrate_workspace_bytes(res, Z), dtype=torch.uint8, device="cuda") if bricks else None
     if signmap is not None:
         capi.signmap_reset(signmap, res, shift, tranc_dist(prm))
-    capi.integrate_set_signmap(signmap)
-    try:
-        for k in frames:
-            d = depth_fn(k) if depth_fn else synth.s1_frame(k)
-            depth = torch.from_numpy(d.astype(np.int16)).cuda()
-            T = s1_transforms(k, prm)
-            capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
-            capi.integrate_scaled_ex(scaled, W * 4, H, W, intr_of(prm), prm["max_integration_weight"], res, prm["tsdf_voxel_size"],
-                                     T["Rv2c"], T["tv2c"], tranc_dist(prm), value, weight, grad, X * 4, 0, threshold=threshold,
-                                     depth_max=dmax, workspace=ws)
-        torch.cuda.synchronize()
-    finally:
-        capi.integrate_set_signmap(None)
+    for k in frames:
+        d = depth_fn(k) if depth_fn else synth.s1_frame(k)
+        depth = torch.from_numpy(d.astype(np.int16)).cuda()
+        T = s1_transforms(k, prm)
+        capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
+        capi.integrate_scaled_ex(scaled, W * 4, H, W, intr_of(prm), prm["max_integration_weight"], res, prm["tsdf_voxel_size"],
+                                 T["Rv2c"], T["tv2c"], tranc_dist(prm), value, weight, grad, X * 4, 0, threshold=threshold,
+                                 depth_max=dmax, workspace=ws, signmap=signmap)
+    torch.cuda.synchronize()
     return value, weight, grad
 
 
@@ -54,15 +50,10 @@ def cast(torch, capi, prm, res, value, grad, T, signmap=None, shift=3, tranc=Non
     ws = torch.zeros(H * W, dtype=torch.float32, device="cuda")
     steps = torch.zeros(H * W, dtype=torch.int32, device="cuda")
     hits = torch.zeros(1, dtype=torch.int64, device="cuda")
-    capi.raycast_set_step_buffer(steps)
-    capi.raycast_set_signmap(signmap, shift, tranc_dist(prm) if tranc is None else tranc)
-    try:
-        capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], value, grad,
-                     X * 4, vm, nm, W * 8, H, W, hits=hits, workspace=ws)
-        torch.cuda.synchronize()
-    finally:
-        capi.raycast_set_step_buffer(None)
-        capi.raycast_set_signmap(None)
+    capi.raycast(intr_of(prm), T["Rc2v"], T["tc2v"], T["Rv2w"], T["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], value, grad,
+                 X * 4, vm, nm, W * 8, H, W, hits=hits, workspace=ws, steps=steps, signmap=signmap, signmap_shift=shift,
+                 signmap_tranc_dist=tranc_dist(prm) if tranc is None else tranc)
+    torch.cuda.synchronize()
     return [t.cpu().numpy() for t in (vm, nm, ws, steps, hits)]
 
 
@@ -252,14 +243,10 @@ def test_sign_map_misuse_is_refused(dev):
         depth = torch.from_numpy(synth.s1_frame(0).astype(np.int16)).cuda()
         capi.scale_depth(depth, W * 2, H, W, scaled2, W * 4)
         T2 = s1_transforms(0, prm2)
-        capi.integrate_set_signmap(sm2)
-        try:
-            for z0, z1 in zip(bounds[:-1], bounds[1:]):
-                off = z0 * 96
-                capi.integrate_scaled(scaled2, W * 4, H, W, intr_of(prm2), 100, res2, prm2["tsdf_voxel_size"], T2["Rv2c"], T2["tv2c"], tranc_dist(prm2),
-                                      v[off:], w[off:], g[off:], 96 * 4, z0=z0, z1=z1)
-        finally:
-            capi.integrate_set_signmap(None)
+        for z0, z1 in zip(bounds[:-1], bounds[1:]):
+            off = z0 * 96
+            capi.integrate_scaled_ex(scaled2, W * 4, H, W, intr_of(prm2), 100, res2, prm2["tsdf_voxel_size"], T2["Rv2c"], T2["tv2c"], tranc_dist(prm2),
+                                     v[off:], w[off:], g[off:], 96 * 4, 0, z0=z0, z1=z1, signmap=sm2)
         torch.cuda.synchronize()
         raw2 = bricks_of(torch, sm2, res2, 3)[0]
         neg2 = negatives_by_brick(torch, v, res2, 3)

@@ -74,13 +74,10 @@ _SIGS = {
                                         C.c_float, C.c_uint, _vp]),
     "xs_integrate_list_covers": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_integrate_workspace_bytes": (_sz, [_i32p, C.c_int]),
-    "xs_integrate_set_timing_events": (None, [_vp, _vp]),
-    "xs_integrate_set_classify_event": (None, [_vp]),
     "xs_scale_depth_max": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "xs_scale_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "xs_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_depth_tiles_bytes": (_sz, [C.c_int, C.c_int]),
-    "xs_integrate_set_depth_tiles": (None, [_vp]),
     "xs_tsdf_reduce_workspace_bytes": (_sz, []),
     "xs_compute_local_tsdf_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
                                                 _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -102,15 +99,18 @@ _SIGS = {
                                   C.c_int, C.c_int, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_raycast_compose_mask": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_raycast_compose_finish": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
-    "xs_raycast_set_pyramid": (None, [_vp, _vp, _sz, _vp, _vp, _sz]),
-    "xs_raycast_pyramid_built": (C.c_int, []),
-    "xs_raycast_set_completion_event": (None, [_vp]),
     "xs_raycast_compose_entry_bytes": (_sz, []),
     "xs_raycast_compose_pack": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp]),
     "xs_raycast_compose_scatter": (C.c_int, [_vp, C.c_long, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "xs_resize_pyramid": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "xs_tsdf_gauss_newton_terms": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, C.c_int,
                                              C.c_int, _vp, _vp, _vp]),
+    "xs_tsdf_gauss_newton_terms_ex": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp, C.c_int,
+                                                C.c_int, _vp, _vp, _vp, _vp]),
+    "xs_gn_publish_bytes": (_sz, []),
+    "xs_gn_mailbox_bytes": (_sz, []),
+    "xs_gn_post_poses": (None, [_vp, _f32p, _f32p, C.c_uint, C.c_int]),
+    "xs_gn_publish_sums": (C.c_int, [_vp, C.c_int, _vp, C.c_ulonglong, _vp]),
     "xs_extract_workspace_bytes": (_sz, [_i32p]),
     "xs_extract_points": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp]),
     "xs_extract_normals": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
@@ -143,9 +143,6 @@ _SIGS = {
     "xs_csfd_array_op": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
     "xs_dcsfd_f1": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     "xs_complex_table": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
-    "xs_raycast_set_step_buffer": (None, [_vp]),
-    "xs_resize_pyramid_set_completion_event": (None, [_vp]),
-    "xs_integrate_set_pose_mailbox": (None, [_vp, C.c_uint, C.c_float, _vp]),
     "xs_integrate_pose_covered": (C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _f32p, _f32p]),
     "xs_const_div_prepare": (C.c_uint, [C.c_float]),
     "xs_raycast_signmap_shift": (C.c_int, [_f32p, C.c_float, C.c_float]),
@@ -153,8 +150,6 @@ _SIGS = {
     "xs_signmap_reset": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp]),
     "xs_signmap_rebuild": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp, C.c_size_t, _vp]),
     "xs_signmap_rebuild_slab": (C.c_int, [_vp, _i32p, C.c_int, C.c_float, _vp, C.c_size_t, C.c_int, C.c_int, _vp]),
-    "xs_integrate_set_signmap": (None, [_vp]),
-    "xs_raycast_set_signmap": (None, [_vp, C.c_int, C.c_float]),
     "xs_const_div_state": (C.c_uint, [C.c_float]),
     "xs_const_div_enable": (C.c_int, [C.c_int]),
 }
@@ -269,11 +264,6 @@ def depth_tiles(scaled, scaled_step, rows, cols, tiles, stream=None):
     check(_lib.xs_depth_tiles(_ptr(scaled), scaled_step, rows, cols, _ptr(tiles), _stream(stream)))
 
 
-def integrate_set_depth_tiles(tiles):
-    """The depth-tile table the following integrate calls classify their bricks with (None: each call builds its own)."""
-    _lib.xs_integrate_set_depth_tiles(_ptr(tiles))
-
-
 def integrate_scaled(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight,
                      grad, vol_step, threshold=0.0, z0=0, z1=None, updated=None, depth_max=None, workspace=None, stream=None):
     r = _ia(res, 3)
@@ -286,15 +276,12 @@ def integrate_scaled(depth_scaled, scaled_step, rows, cols, intr, max_weight, re
 
 
 def integrate_scaled_ex(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight,
-                        grad, vol_step, flags, threshold=0.0, z0=0, z1=None, updated=None, depth_max=None, workspace=None, stream=None):
-    """xs_integrate_scaled with flags: 1 = the header was cleared by the caller (integrate_workspace_clear), 2 = the caller folds the count."""
-    r = _ia(res, 3)
-    k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
-    z1 = int(r[2]) if z1 is None else z1
-    check(_lib.xs_integrate_scaled_ex(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), max_weight,
-                                      r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), tranc_dist,
-                                      _ptr(value), _ptr(weight), _ptr(grad), vol_step, threshold, z0, z1, _ptr(updated), _ptr(depth_max),
-                                      _ptr(workspace), flags, _stream(stream)))
+                        grad, vol_step, flags, threshold=0.0, z0=0, z1=None, updated=None, depth_max=None, workspace=None, stream=None, **opts):
+    """xs_integrate_scaled_ex2 with its options as keyword arguments (integrate_opts' fields: depth_tiles, signmap, start_event, stop_event,
+    pose_mailbox, mailbox_seq, mailbox_slack, pose_dev) and the flags positional, as the tests write it."""
+    return integrate_scaled_ex2(depth_scaled, scaled_step, rows, cols, intr, max_weight, res, voxel_size, Rv2c, tv2c, tranc_dist, value, weight, grad, vol_step,
+                                integrate_opts(flags=flags, **opts), threshold=threshold, z0=z0, z1=z1, updated=updated, depth_max=depth_max,
+                                workspace=workspace, stream=stream)
 
 
 def integrate_opts(flags=0, depth_tiles=None, signmap=None, start_event=None, stop_event=None, pose_mailbox=None, mailbox_seq=0, mailbox_slack=2.0,
@@ -332,13 +319,11 @@ def integrate_classify_ex(rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_d
 
 
 def integrate_classify(rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, workspace, slack_scale=2.0, flags=0, z0=0, z1=None,
-                       depth_max=None, stream=None):
-    """The brick classification of an integrate call on its own, for a pose near the final one (xs_integrate_classify)."""
-    r = _ia(res, 3)
-    k, R, t = _fa(intr, 4), _fa(Rv2c, 18), _fa(tv2c, 6)
-    check(_lib.xs_integrate_classify(rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p), voxel_size, R.ctypes.data_as(_f32p),
-                                     t.ctypes.data_as(_f32p), tranc_dist, z0, int(r[2]) if z1 is None else z1, _ptr(depth_max), _ptr(workspace),
-                                     slack_scale, flags, _stream(stream)))
+                       depth_max=None, stream=None, **opts):
+    """The brick classification of an integrate call on its own, for a pose near the final one (xs_integrate_classify_ex; options — depth_tiles,
+    stop_event — as keyword arguments)."""
+    return integrate_classify_ex(rows, cols, intr, res, voxel_size, Rv2c, tv2c, tranc_dist, workspace, integrate_opts(flags=flags, **opts), slack_scale=slack_scale,
+                                 z0=z0, z1=z1, depth_max=depth_max, stream=stream)
 
 
 def integrate_list_covers(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_list, slack_scale, Rv2c, tv2c):
@@ -347,12 +332,6 @@ def integrate_list_covers(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_lis
     a, b, c, d = _fa(Rv2c_list, 18), _fa(tv2c_list, 6), _fa(Rv2c, 18), _fa(tv2c, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
     return int(_lib.xs_integrate_list_covers(rows, cols, P(k), r.ctypes.data_as(_i32p), voxel_size, P(a), P(b), slack_scale, P(c), P(d)))
-
-
-def integrate_set_pose_mailbox(mailbox, mailbox_seq, slack_scale=2.0, pose_dev=None):
-    """Names the mailbox / sequence number / plane widening / 128-byte device hand-over buffer of the next integrate_scaled_ex call with
-    flag 16 (XS_INTEGRATE_POSE_POSTED)."""
-    _lib.xs_integrate_set_pose_mailbox(_ptr(mailbox), mailbox_seq, slack_scale, _ptr(pose_dev))
 
 
 def integrate_pose_covered(rows, cols, intr, res, voxel_size, Rv2c_list, tv2c_list, slack_scale, Rv2c, tv2c):
@@ -500,13 +479,30 @@ def resize_nmap(src, src_step, src_rows, src_cols, dst, dst_step, stream=None):
 
 
 def raycast(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols,
-            hits=None, workspace=None, stream=None):
+            hits=None, workspace=None, stream=None, **opts):
+    """xs_raycast; with options (signmap, signmap_shift, signmap_tranc_dist, pyramid, completion_event, steps) xs_raycast_ex — returns the options
+    struct then (its pyramid_built field says whether the call built the pyramid)."""
+    if opts:
+        o = _ray_opts(opts)
+        raycast_ex(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols, o, hits=hits,
+                   workspace=workspace, stream=stream)
+        return o
     r = _ia(res, 3)
     _prep(voxel_size)
     k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
     check(_lib.xs_raycast(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
                           vol_step, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _ptr(workspace), _stream(stream)))
+
+
+def _ray_opts(kw):
+    """raycast_opts from the keyword options of raycast / raycast_slab (whose own tranc_dist argument is the march's)."""
+    kw = dict(kw)
+    if "signmap_shift" in kw:
+        kw["shift"] = kw.pop("signmap_shift")
+    if "signmap_tranc_dist" in kw:
+        kw["tranc_dist"] = kw.pop("signmap_tranc_dist")
+    return raycast_opts(**kw)
 
 
 def raycast_opts(signmap=None, shift=3, tranc_dist=0.0, pyramid=None, completion_event=None, steps=None):
@@ -534,11 +530,6 @@ def raycast_ex(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value,
                              _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _ptr(workspace), C.byref(opts), _stream(stream)))
 
 
-def raycast_set_step_buffer(buf):
-    """Per-ray march lengths of the following raycast calls go to buf (rows x cols int32 on the device); None switches it off."""
-    _lib.xs_raycast_set_step_buffer(_ptr(buf))
-
-
 def raycast_signmap_shift(intr, voxel_size, tranc_dist):
     """xs_raycast_signmap_shift: the finest sign map the march can use for this configuration (log2 of the brick edge in voxels), 0 if none."""
     return int(_lib.xs_raycast_signmap_shift(_fa(intr, 4).ctypes.data_as(_f32p), voxel_size, tranc_dist))
@@ -557,22 +548,18 @@ def signmap_rebuild(signmap, res, shift, tranc_dist, value, vol_step, stream=Non
     check(_lib.xs_signmap_rebuild(_ptr(signmap), _ia(res, 3).ctypes.data_as(_i32p), shift, tranc_dist, _ptr(value), vol_step, _stream(stream)))
 
 
-def integrate_set_signmap(signmap):
-    """The sign map the following integrate calls mark (None: none)."""
-    _lib.xs_integrate_set_signmap(_ptr(signmap))
-
-
-def raycast_set_signmap(signmap, shift=3, tranc_dist=0.0):
-    """The sign map the following raycast calls (with a workspace) start their rays from (None: every ray from t = 0.2)."""
-    _lib.xs_raycast_set_signmap(_ptr(signmap), shift, tranc_dist)
-
-
 def raycast_slab(intr, Rc2v, tc2v, Rv2w, tv2w, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap,
-                 map_step, rows, cols, keys, stream=None):
+                 map_step, rows, cols, keys, stream=None, **opts):
+    """xs_raycast_slab; with options (signmap, signmap_shift, signmap_tranc_dist) xs_raycast_slab_ex."""
     r = _ia(res, 3)
     _prep(voxel_size)
     k, a, b, c, d = _fa(intr, 4), _fa(Rc2v, 18), _fa(tc2v, 6), _fa(Rv2w, 18), _fa(tv2w, 6)
     P = lambda x: x.ctypes.data_as(_f32p)
+    if opts:
+        o = _ray_opts(opts)
+        check(_lib.xs_raycast_slab_ex(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
+                                      vol_step, zs0, zs1, z0, z1, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(keys), C.byref(o), _stream(stream)))
+        return o
     check(_lib.xs_raycast_slab(P(k), P(a), P(b), P(c), P(d), tranc_dist, r.ctypes.data_as(_i32p), voxel_size, _ptr(value), _ptr(grad),
                                vol_step, zs0, zs1, z0, z1, _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(keys), _stream(stream)))
 
@@ -583,15 +570,6 @@ def raycast_compose_mask(own_keys, min_keys, vmap, nmap, map_step, rows, cols, s
 
 def raycast_compose_finish(min_keys, vmap, nmap, map_step, rows, cols, hits=None, stream=None):
     check(_lib.xs_raycast_compose_finish(_ptr(min_keys), _ptr(vmap), _ptr(nmap), map_step, rows, cols, _ptr(hits), _stream(stream)))
-
-
-def raycast_set_pyramid(vmap1, nmap1, step1, vmap2, nmap2, step2):
-    """The model-map pyramid the next raycast call (workspace + sign map) builds inside its kernel; (None, ...) clears."""
-    _lib.xs_raycast_set_pyramid(_ptr(vmap1), _ptr(nmap1), step1, _ptr(vmap2), _ptr(nmap2), step2)
-
-
-def raycast_pyramid_built():
-    return bool(_lib.xs_raycast_pyramid_built())
 
 
 def raycast_compose_entry_bytes():

@@ -10,4 +10,4 @@ extern "C" int xs_set_error(hipError_t e, const char *what) {
     return (int)e;
 }
 extern "C" const char *xs_last_error(void) { return g_err; }
-extern "C" int xs_abi_version(void) { return 1; }
+extern "C" int xs_abi_version(void) { return 2; }   // 2 (round 6): the per-thread setters are gone (options structs only), the Gauss-Newton loop protocol (xs_gn_*), the integrate workspace layout of round 5

@@ -372,19 +372,16 @@ __global__ void __launch_bounds__(256) k_resize_pyramid(const PyramidArgs a) {
     if (blockIdx.z == 0) resize_two_levels<false>(a, 0, x2, y2);
     else resize_two_levels<true>(a, 1, x2, y2);
 }
-// an event that rides on the next xs_resize_pyramid dispatch of this thread (its completion: hipExtLaunchKernelGGL's stop event) — another
-// stream can then wait for the end of a frame's raycast + pyramid without a marker packet in this one; NULL = none
-static thread_local hipEvent_t g_pyramid_done = nullptr;
-extern "C" void xs_resize_pyramid_set_completion_event(void *event) { g_pyramid_done = (hipEvent_t)event; }
 
 /* The orchestrator's model-map pyramid in one launch: level 1 and level 2 of the vertex map (as
  * resizeVMap twice) and of the normal map (as resizeNMap twice), Map.h:46-54.  rows0 / cols0: one plane
  * of the level-0 maps; all level-0 maps share in_step, level-1 mid_step, level-2 out_step. */
 extern "C" int xs_resize_pyramid(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
                                  size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *stream) {
-    return xs_resize_pyramid_ex(vmap0, nmap0, in_step, rows0, cols0, vmap1, nmap1, mid_step, vmap2, nmap2, out_step, g_pyramid_done, stream);
+    return xs_resize_pyramid_ex(vmap0, nmap0, in_step, rows0, cols0, vmap1, nmap1, mid_step, vmap2, nmap2, out_step, nullptr, stream);
 }
-// (the same with the completion event as an argument: reads no per-thread state)
+// (the same with a completion event: it rides on the dispatch — hipExtLaunchKernelGGL's stop event — so another stream can wait for the end
+// of a frame's raycast + pyramid without a marker packet in this one; NULL = none)
 extern "C" int xs_resize_pyramid_ex(const float *vmap0, const float *nmap0, size_t in_step, int rows0, int cols0, float *vmap1, float *nmap1,
                                     size_t mid_step, float *vmap2, float *nmap2, size_t out_step, void *completion_event, void *stream) {
     if (!vmap0 || !nmap0 || !vmap1 || !nmap1 || !vmap2 || !nmap2) return xs_set_error(hipErrorInvalidValue, "xs_resize_pyramid: null pointer");

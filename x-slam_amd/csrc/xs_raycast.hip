@@ -717,11 +717,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(raycas
     }
 }
 
-// What the per-thread setters hold for the older entry points (xs_raycast, xs_raycast_slab): one options struct, the same type
-// xs_raycast_ex / xs_raycast_slab_ex take as an argument (and read nothing else).
-static thread_local xs_raycast_opts g_ray_legacy = {};
-// measurement hook (bench.py): a device buffer of rows x cols ints that the single-GPU march fills with every ray's step count
-extern "C" void xs_raycast_set_step_buffer(int *steps_dev) { g_ray_legacy.steps_dev = steps_dev; }
 
 static int ray_wshift() {
     static const int env_ws = exp_env_int("XS_RAY_WSHIFT", 3);
@@ -746,10 +741,6 @@ extern "C" int xs_raycast_signmap_shift(const float *intr4, float voxel_size, fl
     return 0;
 }
 
-// the sign map (xs_signmap.h) the following xs_raycast / xs_raycast_slab calls of this thread start their rays from; null = every ray from t = 0.2
-extern "C" void xs_raycast_set_signmap(const void *signmap, int shift, float tranc_dist) {
-    g_ray_legacy.signmap = signmap; g_ray_legacy.signmap_shift = shift; g_ray_legacy.signmap_tranc_dist = tranc_dist;
-}
 
 // do the resident planes of one volume array span at most 4 GiB (and the 24-bit products hold)?
 static bool fits32(const RaycastArgs &a) {
@@ -779,25 +770,15 @@ static void ld_vec(const float *p, cfloat3 &v) { v.x = cfloat(p[0], p[1]); v.y =
  * vertex.  workspace: optional rows*cols floats; with it the ray is split into a march kernel
  * and a crossing kernel (same arithmetic, higher occupancy).  No synchronisation (neither does
  * the reference, :367). */
-// The model-map pyramid handed to the next xs_raycast call of this thread (levels 1 and 2 of the vertex and of the normal map, as
-// xs_resize_pyramid takes them): the one-launch form of the raycast (workspace + sign map) then builds it inside the raycast kernel, and
-// xs_raycast_pyramid_built() says whether that call did (else the caller launches xs_resize_pyramid as before).  A completion event rides
-// on that launch like xs_resize_pyramid_set_completion_event's on the pyramid kernel.
-extern "C" void xs_raycast_set_pyramid(float *vmap1, float *nmap1, size_t step1, float *vmap2, float *nmap2, size_t step2) {
-    g_ray_legacy.pyr_vmap1 = vmap1; g_ray_legacy.pyr_nmap1 = nmap1; g_ray_legacy.pyr_step1 = step1;
-    g_ray_legacy.pyr_vmap2 = vmap2; g_ray_legacy.pyr_nmap2 = nmap2; g_ray_legacy.pyr_step2 = step2;
-}
-extern "C" int xs_raycast_pyramid_built(void) { return g_ray_legacy.pyramid_built; }
-extern "C" void xs_raycast_set_completion_event(void *event) { g_ray_legacy.completion_event = event; }
-
-// the older entry point: the options are what the per-thread setters left
+// the reference's launcher proper: no sign map, no pyramid, no event (xs_raycast_ex takes those as an options struct)
 extern "C" int xs_raycast(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                           float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                           float *vmap, float *nmap, size_t map_step, int rows, int cols, unsigned long long *hits_dev, float *workspace,
                           void *stream) {
-    g_ray_legacy.struct_bytes = sizeof(xs_raycast_opts);
+    xs_raycast_opts o = {};
+    o.struct_bytes = sizeof(o);
     return xs_raycast_ex(intr4, Rc2v18, tc2v6, Rv2w18, tv2w6, tranc_dist, res, voxel_size, value, grad, vol_step, vmap, nmap, map_step, rows, cols, hits_dev,
-                         workspace, &g_ray_legacy, stream);
+                         workspace, &o, stream);
 }
 extern "C" int xs_raycast_ex(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                              float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
@@ -890,9 +871,10 @@ extern "C" int xs_raycast_slab(const float *intr4, const float *Rc2v18, const fl
                                float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,
                                int zs0, int zs1, int z0, int z1, float *vmap, float *nmap, size_t map_step, int rows, int cols,
                                int *keys_dev, void *stream) {
-    g_ray_legacy.struct_bytes = sizeof(xs_raycast_opts);
+    xs_raycast_opts o = {};
+    o.struct_bytes = sizeof(o);
     return xs_raycast_slab_ex(intr4, Rc2v18, tc2v6, Rv2w18, tv2w6, tranc_dist, res, voxel_size, value, grad, vol_step, zs0, zs1, z0, z1, vmap, nmap, map_step, rows,
-                              cols, keys_dev, &g_ray_legacy, stream);
+                              cols, keys_dev, &o, stream);
 }
 extern "C" int xs_raycast_slab_ex(const float *intr4, const float *Rc2v18, const float *tc2v6, const float *Rv2w18, const float *tv2w6,
                                   float tranc_dist, const int *res, float voxel_size, const float *value, const float *grad, size_t vol_step,

@@ -23,6 +23,7 @@
 #include "xs_signmap.h"
 #include "xs_env.h"
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 #include "../../include/xslam_amd.h"
 
@@ -1295,22 +1296,6 @@ static void host_frustum(IntegrateArgs &a, float slack_scale = 1.0f) {
     }
 }
 
-// What the per-thread setters hold for the OLDER entry points (xs_integrate_scaled*, xs_integrate_classify): one options struct of the type
-// xs_integrate_scaled_ex2 / xs_integrate_classify_ex take as an argument — those read no per-thread state at all.
-//   start / stop event   HIP events riding on the integrate kernel's own dispatch (after the brick classification)
-//   classify event       completion of xs_integrate_classify's launches (rides on the last dispatch): classify on one stream, integrate on another
-//   pose mailbox         see k_integrate_bricks<., true>: the mailbox the next XS_INTEGRATE_POSE_POSTED call's gate polls, its number, the
-//                        factor by which that call widens the frustum planes of the pose it is given (the list's pose), the hand-over buffer
-//   sign map             the map (xs_signmap.h) the launches mark; depth tiles: the frame's table (xs_scale_depth_tiles), null = the call builds its own
-static thread_local xs_integrate_opts g_legacy = {sizeof(xs_integrate_opts), 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 2.0f, nullptr};
-static thread_local void *g_legacy_class_ev = nullptr;
-extern "C" void xs_integrate_set_classify_event(void *done_event) { g_legacy_class_ev = done_event; }
-extern "C" void xs_integrate_set_timing_events(void *start_event, void *stop_event) { g_legacy.start_event = start_event; g_legacy.stop_event = stop_event; }
-extern "C" void xs_integrate_set_pose_mailbox(const void *mailbox, unsigned mailbox_seq, float slack_scale, void *pose_dev) {
-    g_legacy.pose_mailbox = mailbox; g_legacy.mailbox_seq = mailbox_seq; g_legacy.mailbox_slack = slack_scale; g_legacy.pose_dev = pose_dev;
-}
-extern "C" void xs_integrate_set_signmap(void *signmap) { g_legacy.signmap = signmap; }
-extern "C" void xs_integrate_set_depth_tiles(const void *tiles) { g_legacy.depth_tiles = tiles; }
 enum { TILE_ROOM_BYTES = 1 << 20 };   // the workspace's own tile table: images of up to 131 072 tiles (e.g. 4096 x 2048 pixels); larger ones take the exact walk everywhere
 // workspace: 256-byte header | the update counts' room (COUNT_ROOM_WORDS words) | brick list (int per brick) | box classes (BOXES_PER_BRICK words per list entry) | the call's own depth tiles
 static size_t workspace_bricks(const int *res, int nz) { return (size_t)div_up(res[0], BRICK_X) * div_up(res[1], BRICK_Y) * div_up(nz, 2); }   // room for 2-plane bricks
@@ -1322,11 +1307,38 @@ extern "C" size_t xs_integrate_workspace_bytes(const int *res, int nz) {
     if (!res || nz <= 0) return 0;
     return workspace_order_offset(res, nz) + ((workspace_bricks(res, nz) * sizeof(int) + 255) & ~(size_t)255);
 }
-// What xs_integrate_classify* last classified on this thread's behalf: the workspace whose box classes it wrote, the pose and the slack
-// they were padded for.  The integrate call with XS_INTEGRATE_LIST_IS_READY that follows uses those classes only if ITS pose lies within
-// that slack (box_slack_covers) — checked here, whatever the caller says — and decides the boxes again with its own pose otherwise.
-struct ClassesAhead { const void *workspace; float R18[18], t6[6]; float slack_scale; };
-static thread_local ClassesAhead g_classes_ahead = {nullptr, {}, {}, 1.0f};
+// What xs_integrate_classify* last classified into a workspace: the pose and the slack its box classes were padded for, and everything else
+// they depend on — the slab, the volume, the camera, the band, the tile table.  The integrate call with XS_INTEGRATE_LIST_IS_READY that follows
+// on that workspace uses those classes only if all of that is ITS OWN and its pose lies within the slack (box_slack_covers) — checked here,
+// whatever the caller says — and decides the boxes again with its own pose otherwise.  A process-wide table keyed by the workspace (round 6;
+// it was a per-thread record holding workspace, pose and slack only): classifying on one host thread and integrating on another works, and
+// a list classified for another slab, frame size or tile table of the same workspace is not mistaken for this call's.
+struct ClassesAhead {
+    const void *workspace, *tiles;
+    float R18[18], t6[6], slack_scale, voxel_size, tranc_dist, intr[4];
+    int res[3], z0, z1, rows, cols;
+};
+namespace {
+std::mutex g_ca_mu;
+ClassesAhead g_ca_tab[16];
+int g_ca_n = 0, g_ca_next = 0;
+void classes_ahead_forget(const void *workspace) {
+    std::lock_guard<std::mutex> lk(g_ca_mu);
+    for (int i = 0; i < g_ca_n; ++i) if (g_ca_tab[i].workspace == workspace) g_ca_tab[i].workspace = nullptr;
+}
+void classes_ahead_put(const ClassesAhead &r) {
+    std::lock_guard<std::mutex> lk(g_ca_mu);
+    for (int i = 0; i < g_ca_n; ++i) if (g_ca_tab[i].workspace == r.workspace || g_ca_tab[i].workspace == nullptr) { g_ca_tab[i] = r; return; }
+    if (g_ca_n < 16) { g_ca_tab[g_ca_n++] = r; return; }
+    g_ca_tab[g_ca_next] = r; g_ca_next = (g_ca_next + 1) % 16;   // (more than 16 workspaces with classes pending: the oldest record goes — its call classifies again)
+}
+bool classes_ahead_take(const void *workspace, ClassesAhead &out) {   // the record is consumed
+    std::lock_guard<std::mutex> lk(g_ca_mu);
+    for (int i = 0; i < g_ca_n; ++i)
+        if (g_ca_tab[i].workspace == workspace) { out = g_ca_tab[i]; g_ca_tab[i].workspace = nullptr; return true; }
+    return false;
+}
+}  // namespace
 
 /* The two tiny launches xs_integrate_scaled wraps around its kernels, for a caller that takes them off its critical path
  * (xs_integrate_scaled_ex with XS_INTEGRATE_HEADER_IS_CLEAR | XS_INTEGRATE_NO_FOLD): the clear of the workspace's 256-byte
@@ -1462,8 +1474,8 @@ static void classify_args(IntegrateArgs &a, int rows, int cols, const float *int
 extern "C" int xs_integrate_classify(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
                                      float tranc_dist, int z0, int z1, const float *depth_max_dev, void *workspace, float slack_scale, unsigned flags,
                                      void *stream) {
-    xs_integrate_opts o = g_legacy;   // the older entry point: the options are what the per-thread setters left
-    o.flags = flags; o.start_event = nullptr; o.stop_event = g_legacy_class_ev;
+    xs_integrate_opts o = {};   // the plain entry point: the list alone (no tile table: the integrate call decides the boxes itself)
+    o.struct_bytes = sizeof(o); o.flags = flags; o.mailbox_slack = 2.0f;
     return xs_integrate_classify_ex(rows, cols, intr4, res, voxel_size, Rv2c18, tv2c6, tranc_dist, z0, z1, depth_max_dev, workspace, slack_scale, &o, stream);
 }
 extern "C" int xs_integrate_classify_ex(int rows, int cols, const float *intr4, const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6,
@@ -1485,15 +1497,18 @@ extern "C" int xs_integrate_classify_ex(int rows, int cols, const float *intr4, 
     // the boxes' classes, valid for every pose xs_integrate_list_covers accepts for this list (needs the frame's tile table:
     // xs_integrate_set_depth_tiles; without it the integrate call classifies with its own pose)
     static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");
-    g_classes_ahead.workspace = nullptr;
+    classes_ahead_forget(workspace);
     // (the 32-bit-offset condition on the tightest pitch: the integrate call tests the real one and decides the boxes itself when it disagrees)
     const bool off32 = ((size_t)a.brick_z * a.Y + BRICK_Y) * ((size_t)res[0] * 4) < (1ull << 32);
     const bool boxes = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES) && off32 && depth_tiles;
     if (flags & XS_INTEGRATE_COUNT_CLASSES) a.kflags |= KF_COUNT_CLASSES;
     // (the caller's completion event — xs_integrate_set_classify_event — rides on the dispatch)
     if (launch_classification(a, res, z1 - z0, workspace, boxes ? depth_tiles : nullptr, box_slack(a, slack_scale), st, (hipEvent_t)opts->stop_event)) {
-        g_classes_ahead.workspace = workspace; g_classes_ahead.slack_scale = slack_scale;
-        memcpy(g_classes_ahead.R18, Rv2c18, sizeof(g_classes_ahead.R18)); memcpy(g_classes_ahead.t6, tv2c6, sizeof(g_classes_ahead.t6));
+        ClassesAhead r;
+        r.workspace = workspace; r.tiles = depth_tiles; r.slack_scale = slack_scale; r.voxel_size = voxel_size; r.tranc_dist = tranc_dist;
+        memcpy(r.R18, Rv2c18, sizeof(r.R18)); memcpy(r.t6, tv2c6, sizeof(r.t6)); memcpy(r.intr, intr4, sizeof(r.intr)); memcpy(r.res, res, sizeof(r.res));
+        r.z0 = z0; r.z1 = z1; r.rows = rows; r.cols = cols;
+        classes_ahead_put(r);
     }
     XS_CHECK(hipGetLastError());
     return 0;
@@ -1547,8 +1562,8 @@ extern "C" int xs_integrate_scaled_ex(const float *depth_scaled, size_t scaled_s
                                       const int *res, float voxel_size, const float *Rv2c18, const float *tv2c6, float tranc_dist,
                                       float *value, int *weight, float *grad, size_t vol_step, float threshold, int z0, int z1,
                                       unsigned long long *updated_dev, const float *depth_max_dev, void *workspace, unsigned flags, void *stream) {
-    xs_integrate_opts o = g_legacy;   // the older entry point: the options are what the per-thread setters left
-    o.flags = flags;
+    xs_integrate_opts o = {};   // the plain entry point: flags alone
+    o.struct_bytes = sizeof(o); o.flags = flags; o.mailbox_slack = 2.0f;
     return xs_integrate_scaled_ex2(depth_scaled, scaled_step, rows, cols, intr4, max_weight, res, voxel_size, Rv2c18, tv2c6, tranc_dist, value, weight, grad,
                                    vol_step, threshold, z0, z1, updated_dev, depth_max_dev, workspace, &o, stream);
 }
@@ -1617,14 +1632,17 @@ extern "C" int xs_integrate_scaled_ex2(const float *depth_scaled, size_t scaled_
         static const bool env_no_tiles = exp_env_set("XS_INTEGRATE_NO_TILES");   // A/B aid, as the flag
         // the classes xs_integrate_classify* left hold for this launch only if its pose lies within the slack they were padded for: checked
         // here (a posted launch is handed the list's own pose and receives a covered one through its mailbox: xs_integrate_pose_covered)
-        bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && g_classes_ahead.workspace == workspace && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
+        ClassesAhead ca;
+        bool classes_ahead = (flags & XS_INTEGRATE_LIST_IS_READY) && classes_ahead_take(workspace, ca) && !(flags & XS_INTEGRATE_RECLASSIFY_BOXES);
+        if (classes_ahead)   // ... for this slab of this volume, this camera and band, this frame's tile table?
+            classes_ahead = ca.z0 == z0 && ca.z1 == z1 && !memcmp(ca.res, res, sizeof(ca.res)) && ca.rows == rows && ca.cols == cols && !memcmp(ca.intr, intr4, sizeof(ca.intr)) &&
+                            ca.voxel_size == voxel_size && ca.tranc_dist == tranc_dist && (ca.tiles == depth_tiles || posted);
         if (classes_ahead && !posted) {
             IntegrateArgs l = a;
-            load_mat(g_classes_ahead.R18, l.R); load_vec(g_classes_ahead.t6, l.t);
+            load_mat(ca.R18, l.R); load_vec(ca.t6, l.t);
             // (classes decided for a pose whose imaginary parts passed stream_margins do not hold for one whose do not)
-            classes_ahead = box_slack_covers(l, a, res, g_classes_ahead.slack_scale) && !(a.kflags & KF_NO_TESTED_STREAM);
+            classes_ahead = box_slack_covers(l, a, res, ca.slack_scale) && !(a.kflags & KF_NO_TESTED_STREAM);
         }
-        g_classes_ahead.workspace = nullptr;
         const bool use_tiles = !env_no_tiles && !(flags & XS_INTEGRATE_NO_TILES);
         auto tile_table = [&]() -> const DepthTile * {   // the caller's, or one built in the workspace's tile room
             if (depth_tiles || xs_depth_tiles_bytes(rows, cols) > TILE_ROOM_BYTES) return depth_tiles;
