@@ -467,8 +467,10 @@ int xs_icp_iterate(const float *Rcurr18, const float *tcurr6, const float *vmap_
                    const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, void *workspace,
                    double *sums_dev, double *sums_host, void *pose_state, void *pose_state_host, unsigned long long *done_flag,
                    unsigned long long done_seq, void *stream);
-/* estimateCombined(...) whole: accumulate, synchronise the stream, download, unpack into the
- * symmetric A (36 complex<double>, A[i*6+j] = A[j*6+i]) and b (6)          ICP.cu:365-429 */
+/* estimateCombined(...) whole: accumulate, wait for the launch (the host spins on a pinned record the kernel's last workgroup writes: everything
+ * before it on the stream has completed when the call returns — what the reference's device synchronisation gives, without the stream drain),
+ * unpack into the symmetric A (36 complex<double>, A[i*6+j] = A[j*6+i]) and b (6).  sums_dev: optional device copy of the 55 doubles.
+ *                                                                              ICP.cu:365-429 */
 int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
                          const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                          const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,

@@ -23,6 +23,7 @@ inline void sync() { hipSafeCall(hipStreamSynchronize(current_stream())); }
 struct Scratch {
     DeviceArray<unsigned char> icp_ws, reduce_ws, integrate_ws;
     DeviceArray<double> sums;
+    DeviceArray<float> ray_ws;
     static Scratch &get() { static Scratch s; return s; }
     void *icp() {
         if (icp_ws.size() != xs_icp_workspace_bytes()) {
@@ -37,6 +38,8 @@ struct Scratch {
         if (integrate_ws.size() != bytes) integrate_ws.create(bytes);
         return integrate_ws.ptr();
     }
+    // the raycast's crossing-time plane (rows x cols floats): with it the ray is a march kernel + a crossing kernel (same maps, higher occupancy)
+    float *ray(int rows, int cols) { if (ray_ws.size() != (size_t)rows * cols) ray_ws.create((size_t)rows * cols); return ray_ws.ptr(); }
     void *reduce() { if (reduce_ws.size() != xs_tsdf_reduce_workspace_bytes()) reduce_ws.create(xs_tsdf_reduce_workspace_bytes()); return reduce_ws.ptr(); }
     double *sum_buf() { if (sums.size() != 64) sums.create(64); return sums.ptr(); }
 };
@@ -78,11 +81,13 @@ inline void raycast(const Intr &intr, const MatS33 &Rc2v, const devComplex3 &tc2
     const int res[3] = {volume_resolution.x, volume_resolution.y, volume_resolution.z};
     xs_host::check_rc(xs_raycast_ex(&intr.fx, &Rc2v.data[0].x.re, &tc2v.x.re, &Rv2w.data[0].x.re, &tv2w.x.re, tranc_dist, res, voxel_size,
                                     value_volume.data, grad_volume.data, value_volume.step, &vmap.ptr()->re, &nmap.ptr()->re, vmap.step(),
-                                    vmap.rows() / 3, vmap.cols(), hits_dev, workspace, opts, xs_host::current_stream()), "raycast");
+                                    vmap.rows() / 3, vmap.cols(), hits_dev, workspace ? workspace : xs_host::Scratch::get().ray(vmap.rows() / 3, vmap.cols()), opts,
+                                    xs_host::current_stream()), "raycast");
 }
 
 // ICP.h:24-31.  gbuf / mbuf are accepted for signature compatibility; the single-launch
-// reduction keeps its own workspace.
+// reduction keeps its own workspace.  Returns when the launch has completed (the host spins on the
+// pinned record its last workgroup writes: what the reference's cudaDeviceSynchronize + download give).
 inline void estimateCombined(const MatS33 &Rcurr, const devComplex3 &tcurr, const MapArr &vmap_curr, const MapArr &nmap_curr,
                              const MatS33 &Rprev_inv, const devComplex3 &tprev, const Intr &intr, const MapArr &vmap_g_prev,
                              const MapArr &nmap_g_prev, float distThres, float angleThres, DeviceArray2D<devComplexICP> & /*gbuf*/,
@@ -92,7 +97,7 @@ inline void estimateCombined(const MatS33 &Rcurr, const devComplex3 &tcurr, cons
     xs_host::check_rc(xs_estimate_combined(&Rcurr.data[0].x.re, &tcurr.x.re, &vmap_curr.ptr()->re, &nmap_curr.ptr()->re,
                                            &Rprev_inv.data[0].x.re, &tprev.x.re, &intr.fx, &vmap_g_prev.ptr()->re, &nmap_g_prev.ptr()->re,
                                            vmap_curr.step(), vmap_curr.rows() / 3, vmap_curr.cols(), distThres, angleThres, S.icp(),
-                                           S.sum_buf(), reinterpret_cast<double *>(matrixA_host), reinterpret_cast<double *>(vectorB_host),
+                                           nullptr /* no device copy of the sums: they arrive in pinned memory */, reinterpret_cast<double *>(matrixA_host), reinterpret_cast<double *>(vectorB_host),
                                            inliers, xs_host::current_stream()), "estimateCombined");
 }
 
