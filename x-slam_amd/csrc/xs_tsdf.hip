@@ -1947,7 +1947,13 @@ __device__ __forceinline__ void walk_band(const HessArgs &a, F &&body) {
     band_queue_take(a, Q, wave, lane, Q.tail - Q.head, body);   // what is left: fewer than sixty-four
 }
 
-__global__ void __launch_bounds__(256) k_tsdf_hessian(const HessArgs a, const HessPoseD Pk) {
+// Three waves per SIMD (168 VGPRs; left alone the compiler takes 176 = two waves; four = 128 VGPRs spill): the band's dual-complex evaluation is
+// VALU work that only another wave's scan can hide.  0.1035 -> 0.1005 ms at 512^3 alternating on one box; four waves 0.1215 (profiles/r06_hess_scan.txt 6).
+#ifndef XS_HESS_WAVES_PER_EU
+#define XS_HESS_WAVES_PER_EU 3
+#endif
+#define XS_HESS_OCC __attribute__((amdgpu_waves_per_eu(XS_HESS_WAVES_PER_EU, XS_HESS_WAVES_PER_EU)))
+__global__ void __launch_bounds__(256) XS_HESS_OCC k_tsdf_hessian(const HessArgs a, const HessPoseD Pk) {
     __shared__ HessPoseD P;   // 48 floats of pose through LDS rather than through vector registers (see k_tsdf_gauss_newton)
     {
         const float *src = reinterpret_cast<const float *>(&Pk);
@@ -2082,8 +2088,13 @@ __device__ __forceinline__ bool tsdf_error_c(const HessArgs &a, const MatS33 &R,
 // POSTED: the launch was enqueued before its poses existed (the host is still solving the previous pass): wave 0 polls the mailbox — six pose
 // mailboxes of xs_mailbox.h in a row, written in order, so box 5 carrying the sequence number means boxes 0 .. 4 do — and fills P from it.
 // An abandoned launch (cmd 1) or one whose poses never come publishes the sequence number with bit 63 set and leaves.
+#ifdef XS_GN_WAVES_PER_EU   // experiment switch (three waves per SIMD = 168 VGPRs spill 31 registers here: 206 -> 172 relocalisations/s; left at the compiler's 228 = two waves)
+#define XS_GN_OCC __attribute__((amdgpu_waves_per_eu(XS_GN_WAVES_PER_EU, XS_GN_WAVES_PER_EU)))
+#else
+#define XS_GN_OCC
+#endif
 template <bool POSTED>
-__global__ void __launch_bounds__(256) k_tsdf_gauss_newton(const HessArgs a, const GnPoses Pk) {
+__global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessArgs a, const GnPoses Pk) {
     // The six poses (144 floats) do not fit the scalar registers next to everything else, and the compiler then keeps them
     // in vector registers for the whole kernel (256 of them: one wave per SIMD).  They go through LDS instead: broadcast
     // reads where an evaluation needs them.
