@@ -6,6 +6,7 @@
 // Pure streaming: 16 B in + 8 B out per element for the binary ops; two complex per lane per
 // access (16 B) so a wave moves 1 KiB per instruction.
 #include "xs_device.h"
+#include "xs_env.h"
 #include "../../include/xslam_amd.h"
 
 using namespace xs;
@@ -42,17 +43,22 @@ template <int WHICH, int OUR> __device__ __forceinline__ cfloat apply(cfloat x, 
 }
 }  // namespace
 
-template <int WHICH, int OUR>
+// NT: arrays that cannot stay in the 256 MiB Infinity Cache (launcher: more than 128 MB moved) are read and written with nontemporal
+// accesses — each element is touched once, and not allocating its lines spares the eviction of what the previous launch left dirty
+// (64 M elements, 1.5 GB per launch: mul 5.1 -> see profiles/r06_csfd_nt.txt; the same lever as the residual kernels' scan)
+typedef float xs_v4 __attribute__((ext_vector_type(4)));
+template <int WHICH, int OUR, bool NT>
 __global__ void __launch_bounds__(256) k_csfd(const cfloat *a, const cfloat *b, cfloat *out, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
     const long n2 = n / 2;
-    const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
-    float4 *o4 = reinterpret_cast<float4 *>(out);
+    const xs_v4 *a4 = reinterpret_cast<const xs_v4 *>(a), *b4 = reinterpret_cast<const xs_v4 *>(b);
+    xs_v4 *o4 = reinterpret_cast<xs_v4 *>(out);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        const float4 x = a4[i], y = b4[i];
+        const xs_v4 x = NT ? __builtin_nontemporal_load(a4 + i) : a4[i], y = NT ? __builtin_nontemporal_load(b4 + i) : b4[i];
         const cfloat r0 = apply<WHICH, OUR>(cfloat(x.x, x.y), cfloat(y.x, y.y));
         const cfloat r1 = apply<WHICH, OUR>(cfloat(x.z, x.w), cfloat(y.z, y.w));
-        o4[i] = make_float4(r0.re, r0.im, r1.re, r1.im);
+        const xs_v4 r = {r0.re, r0.im, r1.re, r1.im};
+        if (NT) __builtin_nontemporal_store(r, o4 + i); else o4[i] = r;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = apply<WHICH, OUR>(a[n - 1], b[n - 1]);
 }
@@ -69,7 +75,10 @@ template <int W, int O> static void launch(const float *a, const float *b, float
     long blocks = (n / 2 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_csfd<W, O>), dim3((unsigned)blocks), dim3(256), 0, s, (const cfloat *)a, (const cfloat *)b, (cfloat *)out, n);
+    static const int env_nt = exp_env_int("XS_CSFD_NT", -1);   // A/B aid: 0 never, 1 always
+    const bool nt = env_nt < 0 ? n * 24 > (128L << 20) : env_nt != 0;
+    if (nt) hipLaunchKernelGGL((k_csfd<W, O, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const cfloat *)a, (const cfloat *)b, (cfloat *)out, n);
+    else hipLaunchKernelGGL((k_csfd<W, O, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const cfloat *)a, (const cfloat *)b, (cfloat *)out, n);
 }
 
 /* test_CSFD part 1 over arrays.  which: 0 multiplication, 1 division, 2 exp(a+b), 3 sin(a+b),
