@@ -253,3 +253,50 @@ def test_sign_map_misuse_is_refused(dev):
         assert int(neg2.sum()) > 20 and bool((raw2[neg2] == 1).all())     # a superset either way (the column walk marks a column's whole span)
         marks.append(v.clone())
     assert torch.equal(marks[0], marks[1])
+
+
+def test_randomized_poses_march_from_the_sign_map_like_the_full_march(dev):
+    """The sign-map march rests on a geometric argument (samples every dt along the ray of a wave's pixel tile cannot miss a brick that holds a
+    negative voxel: xs_raycast.hip sign_map_spacing) — so, beside the hand-picked poses above, RANDOM ones (round 6): a 256^3 map of the box room
+    (walls in every orientation, fused with the map marked), 360 cameras (60 per sensor and brick shift) drawn within the march's reach of a random surface point (inside the
+    volume or not, from in front of the surface or from behind it), looking at it, rolled by up to +-pi, intrinsics of three sensors scaled to the 640 x 480 maps (fx 481 / 585 / 350: the pixel tile's half diagonal changes the sample
+    spacing), both usable brick shifts: vertex map, normal map, crossing times, per-ray step counts and hit count against the march that evaluates
+    every step, bit for bit."""
+    torch, capi = dev
+    n = 256
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    rng = np.random.default_rng(0x51617)
+    td = tranc_dist(prm)
+    for fx, fy in ((synth.FX, synth.FY), (585.0, -585.0), (350.0, -350.0)):
+        intr = np.array([fx, fy, synth.CX, synth.CY], np.float32)
+        finest = capi.raycast_signmap_shift(intr, prm["tsdf_voxel_size"], td)
+        assert finest
+        for shift in sorted({finest, min(finest + 1, 6)}):
+            sm = torch.zeros(capi.signmap_bytes(res, shift), dtype=torch.uint8, device="cuda")
+            value, weight, grad = fuse(torch, capi, prm, res, [0, 3, 6, 9], signmap=sm, shift=shift, depth_fn=synth.s3_frame)
+            vs = prm["tsdf_voxel_size"]
+            neg = torch.nonzero(value.view(n, n, n) < 0).cpu().numpy()      # (z, y, x) of the voxels behind a surface: what a camera can look at
+            assert len(neg) > 1000
+            hit_total = 0
+            for trial in range(60):
+                zyx = neg[rng.integers(len(neg))]
+                target = (zyx[::-1] + 0.5) * vs
+                d = rng.normal(size=3); d /= np.linalg.norm(d) + 1e-12
+                eye = target + d * rng.uniform(0.4, 4.5)                    # anywhere within the march's 5 m of it: inside the volume or not
+                z = target - eye
+                z /= np.linalg.norm(z) + 1e-12
+                x = np.cross(rng.normal(size=3), z); x /= np.linalg.norm(x) + 1e-12
+                y = np.cross(z, x)
+                roll = rng.uniform(-np.pi, np.pi)
+                x, y = np.cos(roll) * x + np.sin(roll) * y, -np.sin(roll) * x + np.cos(roll) * y
+                Rc2v = np.zeros((3, 3, 2), np.float32); Rc2v[..., 0] = np.stack([x, y, z], 1); Rc2v[..., 1] = rng.normal(size=(3, 3)) * 1e-7
+                tc2v = np.zeros((3, 2), np.float32); tc2v[:, 0] = eye; tc2v[:, 1] = rng.normal(size=3) * 1e-7
+                I = np.zeros((3, 3, 2), np.float32); I[[0, 1, 2], [0, 1, 2], 0] = 1
+                T = {"Rc2v": Rc2v, "tc2v": tc2v, "Rv2w": I, "tv2w": np.zeros((3, 2), np.float32)}
+                p2 = dict(prm, fx=float(fx), fy=float(fy))
+                full = cast(torch, capi, p2, res, value, grad, T)
+                fast = cast(torch, capi, p2, res, value, grad, T, signmap=sm, shift=shift)
+                same_bits(full, fast)
+                hit_total += int(full[4][0])
+            assert hit_total > 60 * 0.05 * H * W, (fx, shift, hit_total)
