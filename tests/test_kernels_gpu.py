@@ -373,6 +373,52 @@ def test_icp_normal_equations(dev, oracle, level):
     assert np.array_equal(A, A2) and np.array_equal(b, b2)
 
 
+def test_icp_normal_equations_randomized_poses(dev, oracle):
+    """The fixed-pose tests above hold the reduction at the pose the maps were made for.  Round 6: 60 random current poses (20 per level) — the
+    previous pose moved by up to 3 degrees about a random axis and 4 cm, random first-order imaginary parts on every entry — at the three pyramid
+    levels, on noisy current-frame maps: many pixels then sit near the distance and angle gates and near the image border of the projective
+    association.  Inlier count and the 27 complex sums against the CPU oracle (values and derivatives within 1e-6 of the largest entry, a pixel
+    flipped across a gate allowed for)."""
+    torch, capi = dev
+    prm, T0, pv0, pn0, _, _ = icp_inputs(oracle)
+    rng = np.random.default_rng(0x1C9)
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    d0 = oracle.bilateral(synth.s1_frame(1, noise_mm=3.0))
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    sums = torch.zeros(55, dtype=torch.float64, device="cuda")
+    worst = np.zeros(3)
+    for level in (0, 1, 2):
+        pv, pn, d = pv0, pn0, d0
+        for _ in range(level):
+            pv, pn, d = oracle.resize_map(pv, False), oracle.resize_map(pn, True), oracle.pyr_down(d)
+        k = intr_of(prm, level)
+        cv = oracle.create_vmap(k, d)
+        cn = oracle.create_nmap(cv)
+        rows, cols = cv.shape[0] // 3, cv.shape[1]
+        dcv, dcn, dpv, dpn = (to_dev(torch, m) for m in (cv, cn, pv, pn))
+        Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+        for trial in range(20):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            ang = np.radians(rng.uniform(0, 3.0))
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+            Rc = np.zeros((3, 3, 2), np.float32); tc = np.zeros((3, 2), np.float32)
+            Rc[..., 0] = Rm @ T0["Rc2w"][..., 0].astype(np.float64); Rc[..., 1] = rng.normal(size=(3, 3)) * 1e-7
+            tc[:, 0] = T0["tc2w"][:, 0] + rng.uniform(-0.04, 0.04, 3); tc[:, 1] = rng.normal(size=3) * 1e-7
+            osum, oA, ob, oinl = oracle.icp_combined(Rc, tc, cv, cn, Rprev_inv, T0["tc2w"], k, pv, pn, 0.10, angle)
+            A, b, inl = capi.estimate_combined(Rc, tc, dcv, dcn, Rprev_inv, T0["tc2w"], k, dpv, dpn, cols * 8, rows, cols, 0.10, angle, ws, sums)
+            s_ = sums.cpu().numpy()[:54]
+            flips = abs(inl - oinl)
+            assert flips <= max(2, 2e-5 * oinl), (level, trial, inl, oinl)
+            scale_re, scale_im = np.abs(osum[0::2]).max(), np.abs(osum[1::2]).max()
+            room = 1e-6 + 4.0 * flips / max(oinl, 1)          # (a flipped pixel moves a sum by about its share of it)
+            dr, di = np.abs(s_[0::2] - osum[0::2]).max() / scale_re, np.abs(s_[1::2] - osum[1::2]).max() / scale_im
+            assert dr <= room and di <= room, (level, trial, dr, di, flips)
+            worst = np.maximum(worst, [dr, di, flips])
+            assert oinl > 0.02 * rows * cols
+    assert worst[0] <= 1e-5 and worst[1] <= 1e-5
+
+
 @pytest.mark.parametrize("shape", ["crop_150x200", "double_960x1280"])
 def test_icp_other_image_sizes(dev, oracle, shape):
     """The reduction kernel away from 640 x 480: a ragged crop (200 columns = three full 64-pixel tiles and one of eight
