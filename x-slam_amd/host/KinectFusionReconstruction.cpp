@@ -139,6 +139,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     shard_composite_gather = config.as<bool>("shard_composite_gather", true);
     raycast_builds_pyramid = config.as<bool>("raycast_builds_pyramid", true);
     gn_post_pose = config.as<bool>("gn_post_pose", true);
+    gn_publish_sharded = config.as<bool>("gn_publish_sharded", true);
     profile_integrate_every = std::max(1, config.as<int>("profile_integrate_every", 4));
     AllocateBuffers();
     tsdf_volume_d_ptr = new TsdfVolume(Vector3i(resolutionX, resolutionY, zs1 - zs0), voxel_size, thres_range);
@@ -1287,7 +1288,12 @@ void KinectFusionReconstruction::GaussNewtonEnqueue(const DeviceArray2D<ushort> 
     if (e1) hipSafeCall(hipEventRecord(e1, st));
     if (sharded) {
         collective(collective_user, 0, gn_sums_.ptr(), 29);
-        check_rc(xs_gn_publish_sums(gn_sums_.ptr(), 29, gn_publish_, seq, st), "GaussNewtonTerms");
+        if (gn_publish_sharded) check_rc(xs_gn_publish_sums(gn_sums_.ptr(), 29, gn_publish_, seq, st), "GaussNewtonTerms");
+        else {   // (YAML gn_publish_sharded: false — the round-5 way: copy + stream drain, then the record is filled by the host itself)
+            hipSafeCall(hipMemcpyAsync(gn_publish_, gn_sums_.ptr(), 29 * sizeof(double), hipMemcpyDeviceToHost, st));
+            hipSafeCall(hipStreamSynchronize(st));
+            reinterpret_cast<volatile unsigned long long *>(gn_publish_)[32] = seq;
+        }
     }
 }
 // spins on the record's sequence word; false if the launch reported that it left without summing (abandoned, or its poses never came)

@@ -210,6 +210,7 @@ public:
                               std::vector<double> *loss_history = nullptr);
     // the loop protocol of the Gauss-Newton passes (see RelocalizeGaussNewton): YAML gn_post_pose, default true
     bool gn_post_pose = true;
+    bool gn_publish_sharded = true;   // shard mode: the all-reduced sums reach the host through a publish kernel + pinned record (false: copy + stream drain)
     double gn_pass_us = 0, gn_kernel_ms = 0;       // wall clock of the passes RelocalizeGaussNewton ran (from its first kernel enqueued to its last sums seen) / kernel durations of the profiled passes
     long long gn_passes = 0, gn_kernel_calls = 0;
     const float *GaussNewtonPrepare(const DeviceArray2D<ushort> &depth_frame_d);
