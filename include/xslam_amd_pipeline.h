@@ -128,6 +128,13 @@ void xs_kf_tail_host_times(void *kf, double *us4, long long *frames);
  * *kernel_ms / *kernel_calls = the kernels' own durations, of passes run with profiling on (xs_kf_set_profiling >= 1: an event pair around each).
  * reset != 0 zeroes the four.  pass - kernel is what the host's side of a pass costs (bench.py: workloads.reloc.host_us_per_pass). */
 void xs_kf_gn_times(void *kf, double *pass_us, long long *passes, double *kernel_ms, long long *kernel_calls, int reset);
+/* The host's side of a Gauss-Newton pass as the DEVICE sees it: *poll_us = microseconds the kernels that were enqueued ahead waited for their poses (from
+ * resident — i.e. the previous pass's kernel gone — to poses seen, on the device's 100 MHz clock), summed over *poll_passes such passes since the last
+ * reset: the record's way to the host, the solve, the six pose inversions, the post and its way back.  No events involved. */
+void xs_kf_gn_poll_times(void *kf, double *poll_us, long long *poll_passes, int reset);
+/* YAML gn_post_pose at run time (0: every Gauss-Newton pass launched with its poses as arguments, after the solve — a kernel's event pair then times
+ * the kernel alone; a pass enqueued ahead also spends the host's turnaround polling its mailbox inside the pair) */
+void xs_kf_set_gn_post_pose(void *kf, int on);
 /* Test aids.  Start the ICP launch sequence numbers at v (exercises the 2^32 wrap of the mailbox numbers); make the determinant gate of
  * iteration n (0-based, over all levels) of the next alignment fail as for a singular system (KinectFusionReconstruction.cpp:203-210). */
 void xs_kf_debug_set_icp_sequence(void *kf, unsigned long long v);

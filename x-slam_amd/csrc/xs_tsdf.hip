@@ -2104,7 +2104,10 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
         __shared__ unsigned s_cmd;
         if (threadIdx.y == 0) {
             const int lane = threadIdx.x;
+            const unsigned long long t_resident = wall_clock64();   // (100 MHz: what this launch waits for its poses is the host's side of the loop)
             xs::mailbox_wait(a.mailbox + 5 * xs::MAILBOX_WORDS, a.mailbox_seq, s_mail, lane);
+            if (a.publish && blockIdx.x == 0 && lane == 0)   // word [30] of the record: ticks from resident to poses seen (the record's sequence word follows ~0.8 ms later)
+                __hip_atomic_store(&a.publish[30], (double)(wall_clock64() - t_resident), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mail[1]);
             float *dst = reinterpret_cast<float *>(&P);
             for (int k = 0; k < 6 && cmd == 0; ++k) {   // (issued after box 5's sequence words were seen: complete payloads)

@@ -1375,6 +1375,7 @@ int KinectFusionReconstruction::RelocalizeGaussNewton(const DeviceArray2D<ushort
         double s[29];
         if (!GaussNewtonWait(seq, s)) { leave(0); break; }
         ++done;
+        if (p > 0 && ahead) { gn_poll_us += gn_publish_[30] * 0.01; ++gn_poll_passes; }   // (this pass was enqueued ahead: what its kernel waited for its poses, 100 MHz ticks)
         if (loss_history) loss_history->push_back(s[28] > 0 ? s[27] / s[28] : 0.0);
         if (p == iterations) break;                           // the final loss pass
         if (s[28] < 6) { leave(0); break; }                   // nothing to align to

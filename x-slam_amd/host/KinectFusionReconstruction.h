@@ -213,6 +213,8 @@ public:
     bool gn_publish_sharded = true;   // shard mode: the all-reduced sums reach the host through a publish kernel + pinned record (false: copy + stream drain)
     double gn_pass_us = 0, gn_kernel_ms = 0;       // wall clock of the passes RelocalizeGaussNewton ran (from its first kernel enqueued to its last sums seen) / kernel durations of the profiled passes
     long long gn_passes = 0, gn_kernel_calls = 0;
+    double gn_poll_us = 0;             // summed over the passes enqueued ahead: what the resident kernel waited for its poses (its own 100 MHz clock): the host's side of a pass
+    long long gn_poll_passes = 0;
     const float *GaussNewtonPrepare(const DeviceArray2D<ushort> &depth_frame_d);
     void GaussNewtonEnqueue(const DeviceArray2D<ushort> &depth_frame_d, const float *gt, const float (*R)[18], const float (*t)[6], unsigned mail_seq,
                             unsigned long long seq);

@@ -258,6 +258,13 @@ void xs_kf_icp_iteration_times(void *kf, double *us4, long long *calls4) {
     KF *k = (KF *)kf;
     for (int i = 0; i < 4; ++i) { if (us4) us4[i] = k->icp_level_us[i]; if (calls4) calls4[i] = k->icp_level_calls[i]; }
 }
+void xs_kf_set_gn_post_pose(void *kf, int on) { ((KF *)kf)->gn_post_pose = on != 0; }
+void xs_kf_gn_poll_times(void *kf, double *poll_us, long long *poll_passes, int reset) {
+    KF *k = (KF *)kf;
+    if (poll_us) *poll_us = k->gn_poll_us;
+    if (poll_passes) *poll_passes = k->gn_poll_passes;
+    if (reset) { k->gn_poll_us = 0; k->gn_poll_passes = 0; }
+}
 void xs_kf_gn_times(void *kf, double *pass_us, long long *passes, double *kernel_ms, long long *kernel_calls, int reset) {
     KF *k = (KF *)kf;
     if (pass_us) *pass_us = k->gn_pass_us;

@@ -53,6 +53,8 @@ _SIGS = {
     "xs_kf_reset_stage_times": (None, [_vp]),
     "xs_kf_icp_iteration_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
     "xs_kf_tail_host_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong)]),
+    "xs_kf_set_gn_post_pose": (None, [_vp, C.c_int]),
+    "xs_kf_gn_poll_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong), C.c_int]),
     "xs_kf_gn_times": (None, [_vp, _f64p, C.POINTER(C.c_longlong), _f64p, C.POINTER(C.c_longlong), C.c_int]),
     "xs_kf_debug_set_icp_sequence": (None, [_vp, C.c_ulonglong]),
     "xs_kf_debug_fail_icp_iteration": (None, [_vp, C.c_int]),
@@ -299,6 +301,15 @@ class KinectFusion:
         k = max(int(n.value), 1)
         return {"frames": int(n.value), "sums_seen_to_integrate_entered": round(float(us[0]) / k, 2), "entered_to_launch_call": round(float(us[1]) / k, 2),
                 "integrate_launch_call": round(float(us[2]) / k, 2), "launch_returned_to_raycast_launched": round(float(us[3]) / k, 2)}
+
+    def gn_poll_times(self, reset=False):
+        """Mean microseconds a Gauss-Newton kernel that was enqueued ahead waited for its poses (the device's own clock), and how many such passes."""
+        pu, n = C.c_double(0), C.c_longlong(0)
+        _lib.xs_kf_gn_poll_times(self.h, C.byref(pu), C.byref(n), int(reset))
+        return {"passes": int(n.value), "wait_us": pu.value / max(n.value, 1)}
+
+    def set_gn_post_pose(self, on):
+        _lib.xs_kf_set_gn_post_pose(self.h, int(bool(on)))
 
     def gn_times(self, reset=False):
         """Gauss-Newton passes run by relocalize since the last reset: mean wall clock per pass and (profiling on) mean kernel duration, microseconds."""
