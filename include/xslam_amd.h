@@ -197,6 +197,10 @@ int xs_resize_pyramid_ex(const float *vmap0, const float *nmap0, size_t in_step,
 
 /* ---- Dual-complex Hessian / real loss over the volume ----------------------------------- */
 size_t xs_tsdf_reduce_workspace_bytes(void);
+/* The workspace of the three residual kernels (Hessian, loss, Gauss-Newton terms): its first 256 bytes must be ZERO on first use — call this once after
+ * allocating it (or zero-fill it) — and every launch leaves them zero (the last workgroup resets the arrival ticket), so a launch carries no fill of
+ * its own.  One launch at a time per workspace; initialise again after a launch that did not complete.  (ABI 2; ABI 1 filled the ticket per launch.) */
+int xs_tsdf_reduce_workspace_init(void *workspace, void *stream);
 /* float4 ComputeLocalTsdf_hessian(depth, Intr, depthScaled, res, voxel_size, const MatD33& Rv2c,
  *     const devDComplex3& tv2c, tranc_dist, threshold, k, gt, real, grad, hessian, count)
  *                                                  TsdfFusion.h:55-60, TsdfFusion.cu:204-331

@@ -79,6 +79,7 @@ _SIGS = {
     "xs_depth_tiles": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _vp]),
     "xs_depth_tiles_bytes": (_sz, [C.c_int, C.c_int]),
     "xs_tsdf_reduce_workspace_bytes": (_sz, []),
+    "xs_tsdf_reduce_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_compute_local_tsdf_hessian": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
                                                 _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "xs_compute_local_tsdf_loss": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _f32p, _i32p, C.c_float, _f32p, _f32p, C.c_float, _vp,
@@ -372,6 +373,11 @@ def integrate_list_layout(res, nz=None):
     list_bytes = (first + cap * 4 + 255) // 256 * 256
     class_bytes = (cap * 16 + 255) // 256 * 256
     return first, cap, list_bytes, list_bytes + class_bytes + (1 << 20)
+
+
+def tsdf_reduce_workspace_init(workspace, stream=None):
+    """Zero the residual kernels' workspace ticket (once after allocation; torch.zeros does the same)."""
+    check(_lib.xs_tsdf_reduce_workspace_init(_ptr(workspace), _stream(stream)))
 
 
 def tsdf_reduce_workspace_bytes():

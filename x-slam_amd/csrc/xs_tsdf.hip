@@ -1802,6 +1802,8 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
             // sequence word by its first lane: a host that sees the word sees the sums (the protocol of the ICP records, xs_icp.hip)
             if (publish) __hip_atomic_store(&publish[tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        // the ticket goes back to zero for the next launch on this workspace (xs_tsdf_reduce_workspace_init zeroes it once): no fill per launch
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (publish && wave == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(publish) + 32, publish_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2162,6 +2164,14 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
 
 enum { XS_TSDF_REDUCE_MAX_BLOCKS = 4096 };  // workgroups per launch (they stride over the tiles); records of up to 32 doubles
 extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_REDUCE_MAX_BLOCKS * 32 * sizeof(double) + 256; }
+/* Zero the workspace's arrival ticket once after allocation (any zero fill of the first 256 bytes does): every launch of the three residual kernels
+ * leaves it zero — their last workgroup resets it — so a launch needs no fill of its own (round 6: that fill was a dispatch in front of every pass).
+ * One launch at a time per workspace.  After a launch that did not complete (a device fault), initialise again. */
+extern "C" int xs_tsdf_reduce_workspace_init(void *workspace, void *stream) {
+    if (!workspace) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_reduce_workspace_init: null pointer");
+    XS_CHECK(hipMemsetAsync(workspace, 0, 256, (hipStream_t)stream));
+    return 0;
+}
 
 static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_step, int rows, int cols, const float *intr4, const int *res,
                        float voxel_size, float tranc_dist, const float *gt, int z0, int z1, void *workspace, double *out_dev, dim3 &grid,
@@ -2220,7 +2230,6 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.tiles_z;
     grid = dim3((unsigned)(ntiles < cap ? ntiles : cap));
     if ((long long)grid.x * grid.y * grid.z > XS_TSDF_REDUCE_MAX_BLOCKS) return xs_set_error(hipErrorInvalidValue, "xs_tsdf_hessian/loss: volume too large for the reduce workspace");
-    XS_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
     return 0;
 }
 

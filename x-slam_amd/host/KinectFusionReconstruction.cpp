@@ -1248,7 +1248,10 @@ const float *KinectFusionReconstruction::GaussNewtonPrepare(const DeviceArray2D<
     check_rc(xs_scale_depth(depth_frame_d.ptr(), depth_frame_d.step(), depth_frame_d.rows(), depth_frame_d.cols(), depthRawScaled_d.ptr(),
                             depthRawScaled_d.step(), st), "scaleDepth");
     if (gn_sums_.size() < 32) gn_sums_.create(32);
-    if (gn_ws_.size() < xs_tsdf_reduce_workspace_bytes()) gn_ws_.create(xs_tsdf_reduce_workspace_bytes());
+    if (gn_ws_.size() < xs_tsdf_reduce_workspace_bytes()) {
+        gn_ws_.create(xs_tsdf_reduce_workspace_bytes());
+        check_rc(xs_tsdf_reduce_workspace_init(gn_ws_.ptr(), st), "reduce workspace");
+    }
     if (!gn_publish_) {
         hipSafeCall(hipHostMalloc((void **)&gn_publish_, xs_gn_publish_bytes(), hipHostMallocCoherent | hipHostMallocMapped));
         std::memset(gn_publish_, 0, xs_gn_publish_bytes());

@@ -40,7 +40,13 @@ struct Scratch {
     }
     // the raycast's crossing-time plane (rows x cols floats): with it the ray is a march kernel + a crossing kernel (same maps, higher occupancy)
     float *ray(int rows, int cols) { if (ray_ws.size() != (size_t)rows * cols) ray_ws.create((size_t)rows * cols); return ray_ws.ptr(); }
-    void *reduce() { if (reduce_ws.size() != xs_tsdf_reduce_workspace_bytes()) reduce_ws.create(xs_tsdf_reduce_workspace_bytes()); return reduce_ws.ptr(); }
+    void *reduce() {
+        if (reduce_ws.size() != xs_tsdf_reduce_workspace_bytes()) {
+            reduce_ws.create(xs_tsdf_reduce_workspace_bytes());
+            check_rc(xs_tsdf_reduce_workspace_init(reduce_ws.ptr(), current_stream()), "reduce workspace");
+        }
+        return reduce_ws.ptr();
+    }
     double *sum_buf() { if (sums.size() != 64) sums.create(64); return sums.ptr(); }
 };
 }  // namespace xs_host
