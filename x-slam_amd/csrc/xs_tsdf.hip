@@ -2221,6 +2221,8 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
         static const int env_zt = exp_env_int("XS_HESS_TILE_PLANES", 0);   // tuning aid: planes per group
         int G = nz >= 64 ? 4 : (nz >= 32 ? 2 : 1);
         if (env_zt >= 8) { G = 1; while (G * 2 * env_zt <= nz) G *= 2; }
+        static const int env_g = exp_env_int("XS_HESS_GROUPS", 0);   // tuning aid: G itself (any number)
+        if (env_g >= 1 && env_g * 8 <= nz) G = env_g;
         a.tiles_x = gx; a.tiles_y = gy; a.tiles_z = G; a.zchunk = div_up(nz, G);
     } else {
         while ((long long)gx * gy * zsplit < cap && zsplit < nz && nz / (zsplit * 2) >= 16) zsplit *= 2;
