@@ -2192,10 +2192,10 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
     // sixteen bytes per lane where the rows allow it (for_band_voxels_wide): X a multiple of four and the slab's first voxel 16-byte aligned
     // Which planes a workgroup takes: runs of consecutive planes stream fastest (eight ADJACENT planes per request: 6.1 TB/s scan alone at
     // 512^3 against 5.7 for planes four apart), but a band is a thin sheet and a wall across z then lies in ONE workgroup's run per column — the
-    // kernels whose band voxels are expensive (dual-complex Hessian, six-pose Gauss-Newton) take four groups of planes interleaved in pairs
-    // (below), the loss kernel takes runs (profiles/r06_hess_scan.txt).
-    static const int env_ilg = exp_env_int("XS_HESS_IL", 2);
-    a.il = (env_ilg == 1 || env_ilg == 4 || env_ilg == 8) ? env_ilg : 2;
+    // kernels whose band voxels are expensive (dual-complex Hessian, six-pose Gauss-Newton) take five interleaved groups of planes (below), the
+    // loss kernel takes runs (profiles/r06_hess_scan.txt).
+    static const int env_ilg = exp_env_int("XS_HESS_IL", 1);   // tuning aid: consecutive planes a group takes together (pairs measured the same or worse)
+    a.il = (env_ilg == 2 || env_ilg == 4 || env_ilg == 8) ? env_ilg : 1;
     static const int env_il = exp_env_int("XS_HESS_INTERLEAVE", -1);   // A/B aid: 0 = runs, 1 = interleaved, whatever the kernel
     const bool interleave = env_il < 0 ? heavy_body : env_il != 0;
     a.wide = (a.X % 4 == 0 && (reinterpret_cast<uintptr_t>(gt) % 16) == 0 && !env_narrow) ? (interleave ? 2 : 1) : 0;
@@ -2210,16 +2210,19 @@ static int hess_common(HessArgs &a, const float *depth_scaled, size_t scaled_ste
                     : a.wide ? (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy))
                     : (int)(cols_xy < 1024 ? 1024 : (cols_xy > XS_TSDF_REDUCE_MAX_BLOCKS ? XS_TSDF_REDUCE_MAX_BLOCKS : cols_xy));
     if (a.wide == 2) {
-        // FOUR z groups per column of tiles, their planes interleaved in pairs (a tile: 256 x 4 columns x a quarter of the planes).  A kernel
-        // is as slow as its busiest wave, and a wave that lies IN a surface holds nothing but band voxels: a wall across z is a sheet one or
-        // two planes thick — pairs put it into two to four groups; a floor (a wall along z and x) fills whole rows of a column — with whole
-        // columns per wave (round 5: 64 x 1024 voxels at 1024^3; 256 x 1024 with four columns per lane) the box room's floor kept a few dozen
-        // waves busy long after the rest had left: 0.89 ms per Gauss-Newton pass of the relocalisation workload then, 2.0 ms with four columns per
-        // lane and whole columns, 0.81 ms now.  More, smaller groups balance better and stream worse (requests of a batch further apart:
-        // 32-plane groups 0.139 ms for the Hessian kernel at 512^3 against 0.103): profiles/r06_hess_scan.txt section 5.  Workgroup b takes
-        // tiles b, b + grid, ... of an enumeration with the z group fastest, skewed by one group per round (walk_band).
+        // FIVE z groups per column of tiles, their planes interleaved one by one (a tile: 256 x 4 columns x every fifth plane).  A kernel is as
+        // slow as its busiest wave, and a wave that lies IN a surface holds nothing but band voxels: a wall across z is a sheet one or two planes
+        // thick — plane by plane it goes to different groups; a floor (a wall along z and x) fills whole rows of a column — with whole columns per
+        // wave (round 5: 64 x 1024 voxels at 1024^3; 256 x 1024 with four columns per lane) the box room's floor kept a few dozen waves busy long
+        // after the rest had left: 0.89 ms per Gauss-Newton pass of the relocalisation workload then, 2.0 ms with four columns per lane and whole
+        // columns, 0.80 ms now.  More, smaller groups balance better and stream worse (32-plane groups: 0.139 ms for the Hessian kernel at 512^3
+        // against 0.097).  FIVE, not four: the eight requests of a batch lie G planes apart, and with a power of two between them (4 MiB at 512^3,
+        // 16 MiB at 1024^3) the scan alone loses 10 % at 512^3 (0.098 against 0.087 ms with three or six groups: the requests of a lane fall on the
+        // same memory channels) — five keeps the balance of four and the rate of an odd stride: Gauss-Newton 1024^3 0.79 -> 0.73 ms, relocalisation
+        // 206 -> 209 frames/s, Hessian 512^3 0.098 -> 0.097 (profiles/r06_hess_scan.txt 5, 7).  Workgroup b takes tiles b, b + grid, ... of an
+        // enumeration with the z group fastest, skewed by one group per round (walk_band).
         static const int env_zt = exp_env_int("XS_HESS_TILE_PLANES", 0);   // tuning aid: planes per group
-        int G = nz >= 64 ? 4 : (nz >= 32 ? 2 : 1);
+        int G = nz >= 80 ? 5 : (nz >= 48 ? 3 : (nz >= 24 ? 2 : 1));
         if (env_zt >= 8) { G = 1; while (G * 2 * env_zt <= nz) G *= 2; }
         static const int env_g = exp_env_int("XS_HESS_GROUPS", 0);   // tuning aid: G itself (any number)
         if (env_g >= 1 && env_g * 8 <= nz) G = env_g;
