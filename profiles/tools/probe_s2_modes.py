@@ -81,9 +81,11 @@ class Smi(threading.Thread):
 def main():
     n = 512
     prm = synth.s2_params(n); res = [n, n, n]; vs = np.float32(prm["tsdf_voxel_size"]); trunc = synth.tranc_dist(prm)
-    value = torch.empty((n * n, n), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, n), dtype=torch.int32, device="cuda")
-    grad = torch.empty((n * n, n), dtype=torch.float32, device="cuda")
-    capi.init_volume(value, weight, grad, n * 4, res)
+    pad = int(os.environ.get("PROBE_PITCH_PAD_FLOATS", "0"))     # round 6: a row pitch that is no power of two (plane stride 1 MiB + pad * 2 KiB)
+    pitch = n + pad
+    value = torch.empty((n * n, pitch), dtype=torch.float32, device="cuda"); weight = torch.empty((n * n, pitch), dtype=torch.int32, device="cuda")
+    grad = torch.empty((n * n, pitch), dtype=torch.float32, device="cuda")
+    capi.init_volume(value, weight, grad, pitch * 4, res)
     depth = torch.from_numpy(synth.render_s2().view(np.int16)).cuda()
     scaled = torch.empty((H, W), dtype=torch.float32, device="cuda"); dmax = torch.zeros(1, dtype=torch.float32, device="cuda")
     capi.scale_depth_max(depth, W * 2, H, W, scaled, W * 4, dmax)
@@ -93,7 +95,7 @@ def main():
     intr = np.array([synth.FX, synth.FY, synth.CX, synth.CY], np.float32)
     counter = torch.zeros(1, dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
-    args = (scaled, W * 4, H, W, intr, 100, res, float(vs), R, t, trunc, value, weight, grad, n * 4)
+    args = (scaled, W * 4, H, W, intr, 100, res, float(vs), R, t, trunc, value, weight, grad, pitch * 4)
     capi.integrate_scaled(*args, updated=counter, depth_max=dmax, workspace=ws, stream=s)
     torch.cuda.synchronize()
     U = int(counter.item()); nbytes = 24.0 * U + 2.0 * W * H
@@ -102,7 +104,7 @@ def main():
     for e in ev:
         assert hip.hipEventCreate(C.byref(e)) == 0
     smi = Smi(); smi.start()
-    fresh = lambda: capi.init_volume(value, weight, grad, n * 4, res, stream=s)
+    fresh = lambda: capi.init_volume(value, weight, grad, pitch * 4, res, stream=s)
     sweep = lambda: sweep_buf.sum()
 
     def regime(name, flags, before=(), min_s=0.4, max_reps=400):
