@@ -339,7 +339,10 @@ int xs_tsdf_gauss_newton_terms(const float *depth_scaled, size_t scaled_step, in
  *   pose_mailbox / mailbox_seq   with Rv2c108 = tv2c36 = NULL: the launch is enqueued BEFORE its poses exist (the host is still solving the
  *                                previous pass) and takes them from the mailbox — xs_icp_mailbox_alloc memory, written by xs_gn_post_poses with
  *                                the same number.  xs_gn_post_poses(..., cmd = 1) makes the launch leave; so does a pose that never comes (about a
- *                                second): nothing is summed and the publish word becomes publish_seq | 1 << 63.  A posted launch also leaves, in
+ *                                second): nothing is summed, out29_dev is not written and the publish word becomes publish_seq | 1 << 63 — written by
+ *                                the launch's LAST workgroup like the sums would be (every workgroup arrives whatever it did, so a launch publishes
+ *                                exactly one record and leaves the workspace's ticket at zero; a launch of which only some workgroups saw their poses
+ *                                before the deadline counts as left).  A posted launch also leaves, in
  *                                double [30] of the record, the 100 MHz ticks its first workgroup waited for the poses (from resident to poses seen:
  *                                the host's side of the loop as the device sees it). */
 typedef struct xs_gn_opts {

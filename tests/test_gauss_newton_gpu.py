@@ -114,6 +114,102 @@ def test_gn_terms_equal_oracle(dev, oracle):
             assert abs(fd - csfd) <= 0.05 * max(abs(csfd), 1e-3 * np.abs(got[21:27]).max() * 2 / float(HSTEP))
 
 
+def test_posted_launch_publishes_one_record_whatever_happens(dev, oracle):
+    """xs_tsdf_gauss_newton_terms_ex through the C ABI: a launch enqueued before its poses exist takes them from the mailbox and publishes the same
+    29 sums, bit for bit, as the launch that got them as arguments; a launch that is told to leave, and one whose poses never come, publish the
+    sequence word with bit 63 set, sum nothing, and leave the workspace's arrival ticket at zero (every workgroup arrives, whatever it did: a launch
+    some of whose workgroups saw poses and others not could otherwise never finish, and would leave a ticket the next launch trips over) — the next
+    launch on the same workspace is unaffected.  At 512^3, where not every workgroup is resident at once, the workgroups that start after one
+    has given up do not wait their own second out."""
+    import time
+    torch, capi, _ = dev
+    n = 64
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    v, w, g = oracle.new_volume(res)
+    for k in (0, 1, 2):
+        T = s1_transforms(k, prm)
+        oracle.integrate(oracle.scale_depth(synth.s1_frame(k)), v, w, g, res, tranc_dist(prm), 100, T["Rv2c"], T["tv2c"], intr_of(prm),
+                         prm["tsdf_voxel_size"])
+    T3 = s1_transforms(3, prm)
+    v2c = np.eye(4); v2c[:3, :3] = np.asarray(T3["Rv2c"])[..., 0]; v2c[:3, 3] = np.asarray(T3["tv2c"])[..., 0]
+    Rs, ts = seeded_poses(np.linalg.inv(v2c))
+    ds = torch.from_numpy(oracle.scale_depth(synth.s1_frame(3))).cuda()
+    gt = torch.from_numpy(v).cuda()
+    ws = torch.zeros(capi.tsdf_reduce_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(32, dtype=torch.float64, device="cuda")
+    publish = torch.zeros(capi.gn_publish_bytes() // 8, dtype=torch.float64).pin_memory()
+    record = publish.numpy()
+    word = record.view(np.uint64)
+    mailbox, in_device = capi.icp_mailbox_alloc()
+    LEFT = 1 << 63
+    common = (ds, W * 4, H, W, intr_of(prm), res, prm["tsdf_voxel_size"])
+
+    def wait(limit_s=30.0):
+        t0 = time.perf_counter()
+        while int(word[32]) == wait.last and time.perf_counter() - t0 < limit_s:
+            pass
+        wait.last = int(word[32])
+        return wait.last, time.perf_counter() - t0
+    wait.last = 0
+    ticket = lambda: int(ws[:4].view(torch.int32).item())
+    try:
+        # poses as arguments, sums published
+        capi.tsdf_gauss_newton_terms_ex(*common, Rs, ts, tranc_dist(prm), gt, ws, out, publish_host=publish, publish_seq=11)
+        assert wait()[0] == 11
+        want = record[:29].copy()
+        torch.cuda.synchronize()
+        assert want[28] > 1000 and np.array_equal(out.cpu().numpy()[:29], want) and ticket() == 0
+        # enqueued ahead: the poses come through the mailbox
+        capi.tsdf_gauss_newton_terms_ex(*common, None, None, tranc_dist(prm), gt, ws, out, pose_mailbox=mailbox, mailbox_seq=1, publish_host=publish,
+                                        publish_seq=12)
+        time.sleep(0.01)
+        assert int(word[32]) == 11                                   # (still waiting)
+        capi.gn_post_poses(mailbox, Rs, ts, 1)
+        assert wait()[0] == 12
+        assert np.array_equal(record[:29], want) and record[30] > 0   # ([30]: the ticks it waited)
+        torch.cuda.synchronize()
+        assert ticket() == 0
+        # told to leave
+        out.fill_(-1.0)
+        capi.tsdf_gauss_newton_terms_ex(*common, None, None, tranc_dist(prm), gt, ws, out, pose_mailbox=mailbox, mailbox_seq=2, publish_host=publish,
+                                        publish_seq=13)
+        capi.gn_post_poses(mailbox, None, None, 2, cmd=1)
+        assert wait()[0] == (13 | LEFT)
+        torch.cuda.synchronize()
+        assert ticket() == 0 and np.all(out.cpu().numpy() == -1.0)     # nothing summed, nothing written
+        # poses that never come: the launch gives up after about a second
+        capi.tsdf_gauss_newton_terms_ex(*common, None, None, tranc_dist(prm), gt, ws, out, pose_mailbox=mailbox, mailbox_seq=3, publish_host=publish,
+                                        publish_seq=14)
+        seen, waited = wait()
+        assert seen == (14 | LEFT), (hex(seen), waited)
+        torch.cuda.synchronize()
+        assert ticket() == 0 and np.all(out.cpu().numpy() == -1.0)
+        # ... and the workspace is as good as new
+        capi.tsdf_gauss_newton_terms_ex(*common, Rs, ts, tranc_dist(prm), gt, ws, out, publish_host=publish, publish_seq=15)
+        assert wait()[0] == 15 and np.array_equal(record[:29], want)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy()[:29], want) and ticket() == 0
+        # 512^3: 1024 workgroups, not all resident at once; nobody posts
+        big = 512
+        gt_big = torch.zeros(big ** 3, dtype=torch.float32, device="cuda")
+        capi.tsdf_gauss_newton_terms_ex(ds, W * 4, H, W, intr_of(prm), [big] * 3, prm["tsdf_voxel_size"] * n / big, None, None, tranc_dist(prm), gt_big, ws,
+                                        out, pose_mailbox=mailbox, mailbox_seq=4, publish_host=publish, publish_seq=16)
+        seen, waited = wait()
+        torch.cuda.synchronize()
+        assert seen == (16 | LEFT) and ticket() == 0
+        first = waited
+        capi.tsdf_gauss_newton_terms_ex(*common, None, None, tranc_dist(prm), gt, ws, out, pose_mailbox=mailbox, mailbox_seq=5, publish_host=publish,
+                                        publish_seq=17)
+        seen, one_wave = wait()
+        assert seen == (17 | LEFT)
+        torch.cuda.synchronize()
+        assert first < 1.6 * one_wave + 0.2, (first, one_wave)       # (one time-out, not one per round of resident workgroups)
+    finally:
+        torch.cuda.synchronize()
+        capi.icp_mailbox_free(mailbox, in_device)
+
+
 def test_relocalize_recovers_a_perturbed_pose(dev):
     """Map from six frames, then the last frame's pose is perturbed (4 cm at the camera, 0.5 degrees) and refined
     against the map: the mean squared residual falls monotonically to less than half and the camera moves back

@@ -445,6 +445,45 @@ def tsdf_gauss_newton_terms(depth_scaled, scaled_step, rows, cols, intr, res, vo
                                           _ptr(workspace), _ptr(out29), _stream(stream)))
 
 
+class GnOpts(C.Structure):
+    """xs_gn_opts (include/xslam_amd.h)"""
+    _fields_ = [("struct_bytes", C.c_uint), ("mailbox_seq", C.c_uint), ("pose_mailbox", C.c_void_p), ("publish_host", C.c_void_p),
+                ("publish_seq", C.c_ulonglong)]
+
+
+def tsdf_gauss_newton_terms_ex(depth_scaled, scaled_step, rows, cols, intr, res, voxel_size, Rv2c6, tv2c6, tranc_dist, gt, workspace, out29,
+                               z0=0, z1=None, stream=None, pose_mailbox=None, mailbox_seq=0, publish_host=None, publish_seq=0):
+    """xs_tsdf_gauss_newton_terms_ex: the pass with the loop protocol's options.  Rv2c6 / tv2c6 None: the launch takes its six poses from
+    `pose_mailbox` (gn_post_poses); publish_host: a pinned host tensor of gn_publish_bytes() bytes the last workgroup writes."""
+    r = _ia(res, 3)
+    k = _fa(intr, 4)
+    z1 = int(r[2]) if z1 is None else z1
+    o = GnOpts()
+    o.struct_bytes = C.sizeof(GnOpts)
+    o.mailbox_seq, o.pose_mailbox, o.publish_host, o.publish_seq = mailbox_seq, _ptr(pose_mailbox), _ptr(publish_host), publish_seq
+    if Rv2c6 is None:
+        pR = pt = None
+    else:
+        R, t = _fa(Rv2c6, 108), _fa(tv2c6, 36)
+        pR, pt = R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p)
+    check(_lib.xs_tsdf_gauss_newton_terms_ex(_ptr(depth_scaled), scaled_step, rows, cols, k.ctypes.data_as(_f32p), r.ctypes.data_as(_i32p),
+                                             voxel_size, pR, pt, tranc_dist, _ptr(gt), z0, z1, _ptr(workspace), _ptr(out29), C.byref(o),
+                                             _stream(stream)))
+
+
+def gn_publish_bytes():
+    return int(_lib.xs_gn_publish_bytes())
+
+
+def gn_post_poses(mailbox, Rv2c6, tv2c6, mailbox_seq, cmd=0):
+    """Host side of the six-pose mailbox (an icp_mailbox_alloc address): cmd 0 = run with these poses, 1 = leave."""
+    if Rv2c6 is None:
+        _lib.xs_gn_post_poses(_ptr(mailbox), None, None, mailbox_seq, cmd)
+    else:
+        R, t = _fa(Rv2c6, 108), _fa(tv2c6, 36)
+        _lib.xs_gn_post_poses(_ptr(mailbox), R.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p), mailbox_seq, cmd)
+
+
 def extract_workspace_bytes(res):
     r = _ia(res, 3)
     return _lib.xs_extract_workspace_bytes(r.ctypes.data_as(_i32p))

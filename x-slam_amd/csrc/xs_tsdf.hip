@@ -1740,9 +1740,15 @@ struct HessArgs {
 struct HessPoseD { MatD33 R; dcfloat3 t; };
 struct HessPoseF { float R[9]; float t[3]; };
 
+// The arrival ticket: bits 0 .. 15 count the workgroups that arrived (at most XS_TSDF_REDUCE_MAX_BLOCKS = 4096 per launch), bits 16 .. 31 those of
+// them that LEFT without summing (k_tsdf_gauss_newton<true>: told to, or their poses never came).  Every workgroup of a launch arrives exactly once,
+// whatever it did, so the last one always exists: it puts the ticket back to zero and publishes — the sums, or, if any workgroup left (some may
+// have seen their poses just before the deadline and others not), the sequence word with bit 63 set and no sums.
+enum { XS_TSDF_REDUCE_MAX_BLOCKS_C = 4096 };   // workgroups per launch (they stride over the tiles); records of up to 32 doubles
+enum : unsigned { TICKET_ARRIVED = 1u, TICKET_LEFT = 0x10000u, TICKET_COUNT_MASK = 0xffffu };
 template <int NV>
 __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *partials, unsigned *ticket, double *out, double *publish = nullptr,
-                                                      unsigned long long publish_seq = 0) {
+                                                      unsigned long long publish_seq = 0, bool left = false) {
     constexpr int STRIDE = NV <= 8 ? 8 : 32;  // doubles per workgroup record
     __shared__ double sm[4][NV];
     __shared__ unsigned s_last;
@@ -1750,28 +1756,38 @@ __device__ __forceinline__ void block_fold_and_finish(double (&v)[NV], double *p
     const int lane = tid & 63, wave = tid >> 6;
     const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;
     const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (!left) {   // (workgroup-uniform)
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const double s = wave_sum_f64(v[k]);
-        if (lane == 0) sm[wave][k] = s;
-    }
-    __syncthreads();
-    if (tid < NV) {
-        const double s = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
-        __hip_atomic_store(&partials[(size_t)bid * STRIDE + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < NV; ++k) {
+            const double s = wave_sum_f64(v[k]);
+            if (lane == 0) sm[wave][k] = s;
+        }
+        __syncthreads();
+        if (tid < NV) {
+            const double s = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
+            __hip_atomic_store(&partials[(size_t)bid * STRIDE + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // The record went out with agent-scope write-through stores from lanes of wave 0 (NV <= 64): once they are acknowledged the
     // record is in memory, and the same wave's first lane takes the ticket — no release fence, whose write-back of the whole
     // L2 per workgroup is what used to cap the grid at 1024 workgroups (xs_icp.hip has the measurements)
     static_assert(NV <= 64, "the record is stored by one wave");
+    static_assert(XS_TSDF_REDUCE_MAX_BLOCKS_C <= (int)TICKET_COUNT_MASK, "the ticket counts arrivals in sixteen bits");
     if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
-        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == nblocks - 1) ? 1u : 0u;
+        const unsigned tk = __hip_atomic_fetch_add(ticket, left ? TICKET_ARRIVED + TICKET_LEFT : TICKET_ARRIVED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk & TICKET_COUNT_MASK) != nblocks - 1 ? 0u : ((tk >> 16) != 0 || left ? 2u : 1u);   // 2: the last one of a launch some workgroup left
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    if (s_last == 2u) {
+        if (tid == 0) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (publish) __hip_atomic_store(reinterpret_cast<unsigned long long *>(publish) + 32, publish_seq | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (s_last) {
         // After the acquire + barrier plain loads see every record.  All 256 threads take part: thread (g, c)
         // adds column c of records g, g + G, g + 2G, ... in that order with 16 loads in flight, and the G row
@@ -2089,7 +2105,9 @@ __device__ __forceinline__ bool tsdf_error_c(const HessArgs &a, const MatS33 &R,
 }
 // POSTED: the launch was enqueued before its poses existed (the host is still solving the previous pass): wave 0 polls the mailbox — six pose
 // mailboxes of xs_mailbox.h in a row, written in order, so box 5 carrying the sequence number means boxes 0 .. 4 do — and fills P from it.
-// An abandoned launch (cmd 1) or one whose poses never come publishes the sequence number with bit 63 set and leaves.
+// A workgroup that is told to leave (cmd 1) or whose poses never come sums nothing but still takes its arrival ticket, marked: the launch's last
+// workgroup then publishes the sequence number with bit 63 set instead of sums (block_fold_and_finish) — one record per launch whatever happened,
+// and the ticket back at zero.
 #ifdef XS_GN_WAVES_PER_EU   // experiment switch (three waves per SIMD = 168 VGPRs spill 31 registers here: 206 -> 172 relocalisations/s; left at the compiler's 228 = two waves)
 #define XS_GN_OCC __attribute__((amdgpu_waves_per_eu(XS_GN_WAVES_PER_EU, XS_GN_WAVES_PER_EU)))
 #else
@@ -2101,16 +2119,19 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
     // in vector registers for the whole kernel (256 of them: one wave per SIMD).  They go through LDS instead: broadcast
     // reads where an evaluation needs them.
     __shared__ GnPoses P;
+    bool left = false;
     if constexpr (POSTED) {
         __shared__ unsigned s_mail[xs::MAILBOX_WORDS];
         __shared__ unsigned s_cmd;
         if (threadIdx.y == 0) {
             const int lane = threadIdx.x;
             const unsigned long long t_resident = wall_clock64();   // (100 MHz: what this launch waits for its poses is the host's side of the loop)
-            xs::mailbox_wait(a.mailbox + 5 * xs::MAILBOX_WORDS, a.mailbox_seq, s_mail, lane);
+            // (a workgroup of this launch has left already — told to, or it waited its second out: the ones that become resident later do not wait theirs)
+            const bool somebody_left = (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) != 0;
+            if (!somebody_left) xs::mailbox_wait(a.mailbox + 5 * xs::MAILBOX_WORDS, a.mailbox_seq, s_mail, lane);
             if (a.publish && blockIdx.x == 0 && lane == 0)   // word [30] of the record: ticks from resident to poses seen (the record's sequence word follows ~0.8 ms later)
                 __hip_atomic_store(&a.publish[30], (double)(wall_clock64() - t_resident), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mail[1]);
+            unsigned cmd = somebody_left ? 1u : (unsigned)__builtin_amdgcn_readfirstlane((int)s_mail[1]);
             float *dst = reinterpret_cast<float *>(&P);
             for (int k = 0; k < 6 && cmd == 0; ++k) {   // (issued after box 5's sequence words were seen: complete payloads)
                 const unsigned w = __hip_atomic_load(a.mailbox + k * xs::MAILBOX_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2123,11 +2144,7 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
             if (lane == 0) s_cmd = cmd;
         }
         __syncthreads();
-        if (s_cmd != 0) {
-            if (a.publish && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.publish) + 32, a.publish_seq | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
+        left = s_cmd != 0;   // (the workgroup still arrives: block_fold_and_finish)
     } else {
         const float *src = reinterpret_cast<const float *>(&Pk);
         float *dst = reinterpret_cast<float *>(&P);
@@ -2137,7 +2154,7 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
     double acc[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-    walk_band(a, [&](int xq, int yq, int z, size_t index, float gt) {
+    if (!left) walk_band(a, [&](int xq, int yq, int z, size_t index, float gt) {
         const float vgx = (float(xq) + 0.5f) * a.voxel_size, vgy = (float(yq) + 0.5f) * a.voxel_size, vgz = (float(z) + 0.5f) * a.voxel_size;
         cfloat e[6];
         bool ok = true;
@@ -2159,10 +2176,10 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
         acc[27] += r * r;
         acc[28] += 1.0;
     });
-    block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out, a.publish, a.publish_seq);
+    block_fold_and_finish<29>(acc, a.partials, a.ticket, a.out, a.publish, a.publish_seq, left);
 }
 
-enum { XS_TSDF_REDUCE_MAX_BLOCKS = 4096 };  // workgroups per launch (they stride over the tiles); records of up to 32 doubles
+enum { XS_TSDF_REDUCE_MAX_BLOCKS = XS_TSDF_REDUCE_MAX_BLOCKS_C };
 extern "C" size_t xs_tsdf_reduce_workspace_bytes(void) { return (size_t)XS_TSDF_REDUCE_MAX_BLOCKS * 32 * sizeof(double) + 256; }
 /* Zero the workspace's arrival ticket once after allocation (any zero fill of the first 256 bytes does): every launch of the three residual kernels
  * leaves it zero — their last workgroup resets it — so a launch needs no fill of its own (round 6: that fill was a dispatch in front of every pass).
