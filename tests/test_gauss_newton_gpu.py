@@ -411,6 +411,86 @@ def test_residual_kernels_non_cubic_volume(dev, oracle):
     assert np.all(np.abs(got[21:27] - want[21:27]) <= 1e-6 * np.abs(want[21:27]).max())
 
 
+def test_residual_kernels_random_shapes_poses_and_slabs(dev, oracle):
+    """Round 6 rewrote the residual kernels' scan (sixteen bytes per lane, interleaved z groups, nontemporal loads; the one-column form where a
+    row is no multiple of 16 bytes or the map is not 16-byte aligned).  Ten seeded trials: a volume of random extent (rows of 90 .. 100 voxels,
+    most of them no multiple of four), a randomly perturbed pose, a random dual seed — Hessian, loss and Gauss-Newton sums against the ORACLE over
+    the whole map, over three random slabs (whose plane counts pick one, two, three or five z groups), and over the same map at an address that
+    is only 4-byte aligned (the one-column scan): counts exact, sums to the tolerances of the fixed-shape tests; the two scan forms agree with each
+    other to double rounding."""
+    torch, capi, _ = dev
+    rng = np.random.default_rng(20261004)
+    prm = synth.s1_params(96)
+    trunc, vs, k4 = tranc_dist(prm), prm["tsdf_voxel_size"], intr_of(prm)
+    ws = torch.zeros(capi.tsdf_reduce_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    out4 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    out2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    out = torch.zeros(32, dtype=torch.float64, device="cuda")
+    widths_seen = set()
+    for trial in range(10):
+        X, Y, Z = int(rng.integers(90, 101)), int(rng.integers(60, 73)), int(rng.integers(70, 97))
+        if trial == 0:
+            X = 96      # (at least one wide case and one narrow one whatever the generator gives)
+        if trial == 1:
+            X = 97
+        widths_seen.add(X % 4 == 0)
+        res = [X, Y, Z]
+        v, w, g = oracle.new_volume(res)
+        for k in (0, 1):
+            T = s1_transforms(k, prm)
+            oracle.integrate(oracle.scale_depth(synth.s1_frame(k)), v, w, g, res, trunc, 100, T["Rv2c"], T["tv2c"], k4, vs)
+        T2 = s1_transforms(2, prm)
+        v2c = np.eye(4); v2c[:3, :3] = np.asarray(T2["Rv2c"])[..., 0]; v2c[:3, 3] = np.asarray(T2["tv2c"])[..., 0]
+        v2c = np.linalg.inv(twist_matrix(rng.normal(size=6) * [0.01, 0.01, 0.01, 0.004, 0.004, 0.004]) @ np.linalg.inv(v2c))
+        ds = oracle.scale_depth(synth.s1_frame(2))
+        dds = torch.from_numpy(ds).cuda()
+        store = torch.zeros(X * Y * Z + 5, dtype=torch.float32, device="cuda")   # the map at a 16-byte aligned address and at one that is not
+        aligned, shifted = store[4:4 + X * Y * Z], store[5:5 + X * Y * Z]
+        assert aligned.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+        Rd = np.zeros((3, 3, 4), np.float32); td = np.zeros((3, 4), np.float32)
+        Rd[..., 0] = v2c[:3, :3]; td[..., 0] = v2c[:3, 3]
+        dof = int(rng.integers(0, 3)); td[dof, 1] = 1e-6; td[dof, 2] = 1e-6
+        R9, t3 = Rd[..., 0].reshape(9).copy(), td[..., 0].reshape(3).copy()
+        Rs, ts = seeded_poses(np.linalg.inv(v2c.astype(np.float32).astype(np.float64)))
+        cuts = sorted(int(c) for c in rng.choice(np.arange(8, Z - 8), size=2, replace=False))
+        slabs = [(0, Z), (0, cuts[0]), (cuts[0], cuts[1]), (cuts[1], Z)]
+
+        def run(gt, z0, z1):
+            out4.zero_(); out2.zero_(); out.zero_()
+            capi.compute_local_tsdf_hessian(dds, W * 4, H, W, k4, res, vs, Rd, td, trunc, gt[z0 * X * Y:], ws, out4, z0=z0, z1=z1)
+            capi.compute_local_tsdf_loss(dds, W * 4, H, W, k4, res, vs, R9, t3, trunc, gt[z0 * X * Y:], ws, out2, z0=z0, z1=z1)
+            capi.tsdf_gauss_newton_terms(dds, W * 4, H, W, k4, res, vs, Rs, ts, trunc, gt[z0 * X * Y:], ws, out, z0=z0, z1=z1)
+            torch.cuda.synchronize()
+            return out4.cpu().numpy().copy(), out2.cpu().numpy().copy(), out.cpu().numpy()[:29].copy()
+
+        for z0, z1 in slabs:
+            sl = v[z0 * X * Y:z1 * X * Y]
+            w4 = oracle.tsdf_hessian(ds, res, vs, Rd, td, trunc, k4, sl, z0=z0, z1=z1)
+            w4 = w4[0] if isinstance(w4, tuple) else w4
+            w2 = oracle.tsdf_loss(ds, res, vs, R9, t3, trunc, k4, v, z0=z0, z1=z1)     # (this wrapper takes the whole map and absolute planes)
+            w29 = oracle.tsdf_gn_terms(ds, res, vs, Rs, ts, trunc, k4, sl, z0=z0, z1=z1)
+            results = []
+            for gt in (aligned, shifted):
+                gt.copy_(torch.from_numpy(v))
+                g4, g2, g29 = run(gt, z0, z1)
+                results.append((g4, g2, g29))
+                tag = (trial, res, (z0, z1), gt.data_ptr() % 16)
+                assert g4[3] == w4[3] and g2[1] == w2[1] and g29[28] == w29[28], tag
+                if w4[3] > 0:
+                    assert abs(g4[0] - w4[0]) <= 1e-6 * abs(w4[0]) and abs(g4[1] - w4[1]) <= 1e-6 * max(abs(w4[1]), 1e-3 * abs(w4[0])), tag
+                    assert abs(g4[2] - w4[2]) <= 1e-5 * max(abs(w4[2]), 1e-3 * abs(w4[0])), tag
+                    assert abs(g2[0] - w2[0]) <= 1e-6 * abs(w2[0]), tag
+                if w29[28] > 0:
+                    assert np.allclose(g29[27], w29[27], rtol=1e-9), tag
+                    assert np.all(np.abs(g29[:21] - w29[:21]) <= 1e-6 * np.abs(w29[:21]).max()), tag
+                    assert np.all(np.abs(g29[21:27] - w29[21:27]) <= 1e-6 * np.abs(w29[21:27]).max()), tag
+            for a, b in zip(*results):   # sixteen bytes per lane against one column per lane: the same voxels, another order of the double sums
+                assert np.allclose(a, b, rtol=1e-10, atol=1e-13 * max(np.abs(a).max(), 1e-30))
+            if (z0, z1) == (0, Z):
+                assert w4[3] > 200 and w29[28] > 200, (trial, res, w4[3], w29[28])
+    assert widths_seen == {True, False}
+
+
 def test_gn_terms_full_size_1024_eight_slabs(dev):
     """BASELINE config 5's size: a 1024^3 volume (two S1 frames fused into it on the GPU), then the
     Gauss-Newton terms of the next frame over the whole volume and over the eight z-slabs an 8-GPU run
