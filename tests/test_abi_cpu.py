@@ -372,3 +372,18 @@ def test_bench_fails_fast_without_a_gpu_per_rank():
     assert r.returncode == 3, (r.returncode, r.stderr[-400:])
     assert "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
     assert time.perf_counter() - t0 < 120
+
+
+def test_host_code_runs_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The header-only host code that needs no GPU (flat YAML reader on well-formed and hostile text, the fixed-size complex algebra, the 6x6
+    solvers, DoubleComplex) compiled with -fsanitize=address,undefined -fno-sanitize-recover and run: tests/cxx/host_selftest.cpp.  (GPU
+    sanitizers do not exist on this pool; this is the CPU build the task allows them on.)"""
+    import subprocess
+    exe = str(tmp_path / "host_selftest")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off", "-Wall", "-Werror",
+           "-I" + os.path.join(ROOT, "x-slam_amd", "host"), "-I" + os.path.join(ROOT, "x-slam_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cxx", "host_selftest.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "all checks held" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
