@@ -19,12 +19,13 @@ inline void check_rc(int rc, const char *what) {
     }
 }
 inline void sync() { hipSafeCall(hipStreamSynchronize(current_stream())); }
-// per-process scratch the launchers need (the reference allocates gbuf / thrust vectors per call)
+// scratch the launchers need (the reference allocates gbuf / thrust vectors per call): one set per HOST THREAD, like current_stream() — two
+// threads driving two streams must not share a workspace (a reduce workspace serves one launch at a time)
 struct Scratch {
     DeviceArray<unsigned char> icp_ws, reduce_ws, integrate_ws;
     DeviceArray<double> sums;
     DeviceArray<float> ray_ws;
-    static Scratch &get() { static Scratch s; return s; }
+    static Scratch &get() { static thread_local Scratch s; return s; }
     void *icp() {
         if (icp_ws.size() != xs_icp_workspace_bytes()) {
             icp_ws.create(xs_icp_workspace_bytes());
@@ -62,7 +63,7 @@ inline void initVolume(PtrStep<short> /*volume: allocated but never read in the 
 
 // TsdfFusion.h:40-45.  depthScaled is kept resident (create() is a no-op when the size is unchanged); the two launches of
 // TsdfFusion.cu:173-201 — scaleDepthKernal, tsdfFusionKernal — with the second one walking the brick list the library keeps in the
-// per-process scratch (the same voxels bit for bit as the walk over every voxel: tests/test_integrate_gpu.py).
+// per-thread scratch (the same voxels bit for bit as the walk over every voxel: tests/test_integrate_gpu.py).
 inline void integrateTsdfVolume(const PtrStepSz<ushort> &depth, const Intr &intr, int max_weight, const int3 &volume_resolution,
                                 float voxel_size, const MatS33 &Rv2c, const devComplex3 &tv2c, const devComplex3 & /*tc2v*/,
                                 float tranc_dist, PtrStep<float> value_volume, PtrStep<int> weight_volume, PtrStep<float> grad_volume,
