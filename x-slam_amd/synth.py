@@ -46,7 +46,7 @@ def s1_pose(k, T=300):
 
 def _hash_noise(frame, n, seed=0xC5FD):
     """Counter-based integer hash (splitmix64 finaliser) -> uniform in [-1, 1)."""
-    idx = np.arange(n, dtype=np.uint64) + np.uint64(frame) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+    idx = np.arange(n, dtype=np.uint64) + np.uint64((int(frame) * 0x9E3779B97F4A7C15 + int(seed)) & 0xFFFFFFFFFFFFFFFF)   # (wraps mod 2^64, as the scalar product did)
     z = idx
     with np.errstate(over="ignore"):
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
