@@ -1070,6 +1070,27 @@ def test_csfd_array_ops_config1(dev, oracle):
     capi.csfd_array_op("mul", "raw", da, db, out, 12345)
     torch.cuda.synchronize()
     assert ulp_diff(out.cpu().numpy()[:12345], oracle.csfd_op("mul", "raw", a[:12345], b[:12345])).max() == 0
+    # ragged lengths around the kernel's pieces (256 lanes x 2 elements x U pieces per round), nothing written past the end
+    for m in (1, 2, 3, 511, 512, 513, 1023, 1024, 1025, 2047, 2049, 4095, 4097, 8191, 8193, 99_999):
+        out.fill_(-7.0)
+        capi.csfd_array_op("div", "our", da, db, out, m)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert ulp_diff(got[:m], oracle.csfd_op("div", "our", a[:m], b[:m])).max() == 0 and np.all(got[m:m + 4096] == -7.0), m
+    # an array that takes the nontemporal, four-pieces-per-round instance (more than 128 MB per launch), odd length
+    big = 6_000_001
+    rb = np.random.default_rng(2)
+    ab = np.stack([rb.uniform(-2, 2, big), np.full(big, 1e-6)], -1).astype(np.float32)
+    bb = np.stack([rb.uniform(0.05, 2, big), np.full(big, 1e-6)], -1).astype(np.float32)
+    dab, dbb = to_dev(torch, ab), to_dev(torch, bb)
+    ob = torch.full((big + 1024, 2), -7.0, dtype=torch.float32, device="cuda")
+    for name in ("mul", "div"):
+        for variant in ("raw", "our"):
+            capi.csfd_array_op(name, variant, dab, dbb, ob, big)
+            torch.cuda.synchronize()
+            got = ob.cpu().numpy()
+            assert ulp_diff(got[:big], oracle.csfd_op(name, variant, ab, bb)).max() == 0 and np.all(got[big:] == -7.0), (name, variant)
+    del dab, dbb, ob
     t = load_golden("scalar_tables.npz")
     dx, dy = to_dev(torch, t["d_a"]), to_dev(torch, t["d_b"])
     o = torch.zeros_like(dx)

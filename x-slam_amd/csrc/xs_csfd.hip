@@ -47,18 +47,34 @@ template <int WHICH, int OUR> __device__ __forceinline__ cfloat apply(cfloat x, 
 // accesses — each element is touched once, and not allocating its lines spares the eviction of what the previous launch left dirty
 // (64 M elements, 1.5 GB per launch: mul 5.1 -> see profiles/r06_csfd_nt.txt; the same lever as the residual kernels' scan)
 typedef float xs_v4 __attribute__((ext_vector_type(4)));
-template <int WHICH, int OUR, bool NT>
+template <int WHICH, int OUR, bool NT, int U>
 __global__ void __launch_bounds__(256) k_csfd(const cfloat *a, const cfloat *b, cfloat *out, long n) {
-    const long stride = (long)gridDim.x * blockDim.x;
+    // a workgroup takes U consecutive 4 KiB pieces of each array per round (a lane's U requests per array lie 4 KiB apart and are issued before
+    // the first result is needed); the rounds of a workgroup lie gridDim.x * U pieces apart
     const long n2 = n / 2;
+    const long round = (long)gridDim.x * 256 * U;
     const xs_v4 *a4 = reinterpret_cast<const xs_v4 *>(a), *b4 = reinterpret_cast<const xs_v4 *>(b);
     xs_v4 *o4 = reinterpret_cast<xs_v4 *>(out);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        const xs_v4 x = NT ? __builtin_nontemporal_load(a4 + i) : a4[i], y = NT ? __builtin_nontemporal_load(b4 + i) : b4[i];
-        const cfloat r0 = apply<WHICH, OUR>(cfloat(x.x, x.y), cfloat(y.x, y.y));
-        const cfloat r1 = apply<WHICH, OUR>(cfloat(x.z, x.w), cfloat(y.z, y.w));
-        const xs_v4 r = {r0.re, r0.im, r1.re, r1.im};
-        if (NT) __builtin_nontemporal_store(r, o4 + i); else o4[i] = r;
+    for (long base = (long)blockIdx.x * 256 * U + threadIdx.x; base < n2; base += round) {
+        xs_v4 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = base + u * 256;
+            if (i < n2) {
+                x[u] = NT ? __builtin_nontemporal_load(a4 + i) : a4[i];
+                y[u] = NT ? __builtin_nontemporal_load(b4 + i) : b4[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = base + u * 256;
+            if (i < n2) {
+                const cfloat r0 = apply<WHICH, OUR>(cfloat(x[u].x, x[u].y), cfloat(y[u].x, y[u].y));
+                const cfloat r1 = apply<WHICH, OUR>(cfloat(x[u].z, x[u].w), cfloat(y[u].z, y[u].w));
+                const xs_v4 r = {r0.re, r0.im, r1.re, r1.im};
+                if (NT) __builtin_nontemporal_store(r, o4 + i); else o4[i] = r;
+            }
+        }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = apply<WHICH, OUR>(a[n - 1], b[n - 1]);
 }
@@ -72,13 +88,23 @@ __global__ void __launch_bounds__(256) k_dcsfd_f1(const dcfloat *x, const dcfloa
 }
 
 template <int W, int O> static void launch(const float *a, const float *b, float *out, long n, hipStream_t s) {
-    long blocks = (n / 2 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
     static const int env_nt = exp_env_int("XS_CSFD_NT", -1);   // A/B aid: 0 never, 1 always
+    static const int env_u = exp_env_int("XS_CSFD_UNROLL", 0);  // A/B aid: pieces per round (1, 2, 4, 8)
+    static const int env_blocks = exp_env_int("XS_CSFD_BLOCKS", 0);
     const bool nt = env_nt < 0 ? n * 24 > (128L << 20) : env_nt != 0;
-    if (nt) hipLaunchKernelGGL((k_csfd<W, O, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const cfloat *)a, (const cfloat *)b, (cfloat *)out, n);
-    else hipLaunchKernelGGL((k_csfd<W, O, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const cfloat *)a, (const cfloat *)b, (cfloat *)out, n);
+    // pieces per round and workgroups (profiles/r06_ab_csfd_unroll.txt, 64 M elements: one piece per round and 2048 workgroups 5.4-5.6 TB/s for the
+    // product, 4.5 for exp, 3.5-3.6 for sin; four pieces and 4096 workgroups 6.2 / 6.2 / 5.2; at 1e6 elements — cache-resident, launches of 4 us —
+    // two pieces help sin and exp and leave the rest alone)
+    const int U = env_u == 1 || env_u == 2 || env_u == 4 || env_u == 8 ? env_u : (nt ? 4 : 2);
+    long blocks = (n / 2 + 256 * U - 1) / (256 * U);
+    const long cap = env_blocks > 0 ? env_blocks : (nt ? 4096 : 2048);
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), block(256);
+#define XS_CSFD_LAUNCH(NTV, UV) hipLaunchKernelGGL((k_csfd<W, O, NTV, UV>), grid, block, 0, s, (const cfloat *)a, (const cfloat *)b, (cfloat *)out, n)
+    if (nt) { if (U == 8) XS_CSFD_LAUNCH(true, 8); else if (U == 4) XS_CSFD_LAUNCH(true, 4); else if (U == 2) XS_CSFD_LAUNCH(true, 2); else XS_CSFD_LAUNCH(true, 1); }
+    else    { if (U == 8) XS_CSFD_LAUNCH(false, 8); else if (U == 4) XS_CSFD_LAUNCH(false, 4); else if (U == 2) XS_CSFD_LAUNCH(false, 2); else XS_CSFD_LAUNCH(false, 1); }
+#undef XS_CSFD_LAUNCH
 }
 
 /* test_CSFD part 1 over arrays.  which: 0 multiplication, 1 division, 2 exp(a+b), 3 sin(a+b),
