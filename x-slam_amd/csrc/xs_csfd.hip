@@ -24,14 +24,25 @@ __device__ __forceinline__ cfloat exp_our(cfloat a) { return cfloat(expf(a.re), 
 __device__ __forceinline__ cfloat exp_raw(cfloat a) { return cfloat(expf(a.re) * cosf(a.im), expf(a.re) * sinf(a.im)); }
 __device__ __forceinline__ cfloat sin_our(cfloat a) { return cfloat(sinf(a.re), -sinhf(-a.im) * cosf(a.re)); }
 __device__ __forceinline__ cfloat sin_raw(cfloat a) { return cfloat(sinf(a.re) * coshf(-a.im), -sinhf(-a.im) * cosf(a.re)); }
-// std::pow(float, int) promotes to double in the reference's host code (main.cpp:74-86)
+// std::pow(float, int) promotes to double in the reference's host code (main.cpp:74-86): pow(double(x), double(n)).  For the small integer
+// exponents of the demo (3) the double power is formed by multiplication — at most |n| - 1 roundings of 2^-53 each, i.e. closer to the exact
+// power than a general pow() implementation promises (glibc's and the device library's agree with each other only to their own last bits), and a
+// float result that differs from a correctly rounded pow's with probability ~1e-8 per element; the general double pow() of the device library
+// is two hundred instructions per call and made this op VALU-bound at 1.8 TB/s.  Larger exponents take pow().
+__device__ __forceinline__ double pow_int(double x, int n) {
+    const int m = n < 0 ? -n : n;
+    if (m > 8) return pow(x, (double)n);
+    double r = 1.0, b = x;
+    for (int k = m; k; k >>= 1) { if (k & 1) r = r * b; b = b * b; }   // (n = 3: x * x^2, two roundings)
+    return n < 0 ? 1.0 / r : r;
+}
 __device__ __forceinline__ cfloat pow_our(cfloat a, int n) {
     const float nr = a.re * a.re + a.im * a.im, ar = atan2f(a.im, a.re);
-    return cfloat((float)pow((double)a.re, (double)n), (float)(pow((double)nr, (double)n) * (double)sinf(n * ar)));
+    return cfloat((float)pow_int((double)a.re, n), (float)(pow_int((double)nr, n) * (double)sinf(n * ar)));
 }
 __device__ __forceinline__ cfloat pow_raw(cfloat a, int n) {
     const float nr = a.re * a.re + a.im * a.im, ar = atan2f(a.im, a.re);
-    return cfloat((float)(pow((double)nr, (double)n) * (double)cosf(n * ar)), (float)(pow((double)nr, (double)n) * (double)sinf(n * ar)));
+    return cfloat((float)(pow_int((double)nr, n) * (double)cosf(n * ar)), (float)(pow_int((double)nr, n) * (double)sinf(n * ar)));
 }
 template <int WHICH, int OUR> __device__ __forceinline__ cfloat apply(cfloat x, cfloat y) {
     if (WHICH == 0) return OUR ? mul_our(x, y) : mul_raw(x, y);
