@@ -8,7 +8,7 @@ for nb in (1000000, 64 << 20):
     ba[:, 1] = 1e-6; bb[:, 1] = 1e-6
     bo = torch.empty_like(ba)
     row = {}
-    for name in ("mul", "pow"):
+    for name in ("mul", "exp", "sin", "pow"):
         for variant in ("our", "raw"):
             reps = 50 if nb < (1 << 22) else 8
             capi.csfd_array_op(name, variant, ba, bb, bo, nb, stream=s)

@@ -20,10 +20,11 @@ __device__ __forceinline__ cfloat div_our(cfloat a, cfloat b) {
 __device__ __forceinline__ cfloat div_raw(cfloat a, cfloat b) {
     return cfloat((a.re * b.re + a.im * b.im) / (b.re * b.re + b.im * b.im), (a.im * b.re - a.re * b.im) / (b.re * b.re + b.im * b.im));
 }
+// (sine and cosine of one argument through sincosf: one range reduction, the same two values)
 __device__ __forceinline__ cfloat exp_our(cfloat a) { return cfloat(expf(a.re), expf(a.re) * sinf(a.im)); }
-__device__ __forceinline__ cfloat exp_raw(cfloat a) { return cfloat(expf(a.re) * cosf(a.im), expf(a.re) * sinf(a.im)); }
-__device__ __forceinline__ cfloat sin_our(cfloat a) { return cfloat(sinf(a.re), -sinhf(-a.im) * cosf(a.re)); }
-__device__ __forceinline__ cfloat sin_raw(cfloat a) { return cfloat(sinf(a.re) * coshf(-a.im), -sinhf(-a.im) * cosf(a.re)); }
+__device__ __forceinline__ cfloat exp_raw(cfloat a) { float sn, cs; sincosf(a.im, &sn, &cs); return cfloat(expf(a.re) * cs, expf(a.re) * sn); }
+__device__ __forceinline__ cfloat sin_our(cfloat a) { float sn, cs; sincosf(a.re, &sn, &cs); return cfloat(sn, -sinhf(-a.im) * cs); }
+__device__ __forceinline__ cfloat sin_raw(cfloat a) { float sn, cs; sincosf(a.re, &sn, &cs); return cfloat(sn * coshf(-a.im), -sinhf(-a.im) * cs); }
 // std::pow(float, int) promotes to double in the reference's host code (main.cpp:74-86): pow(double(x), double(n)).  For the small integer
 // exponents of the demo (3) the double power is formed by multiplication — at most |n| - 1 roundings of 2^-53 each, i.e. closer to the exact
 // power than a general pow() implementation promises (glibc's and the device library's agree with each other only to their own last bits), and a
