@@ -2355,11 +2355,41 @@ extern "C" int xs_tsdf_gauss_newton_terms_ex(const float *depth_scaled, size_t s
 extern "C" size_t xs_gn_publish_bytes(void) { return 33 * sizeof(double); }
 extern "C" size_t xs_gn_mailbox_bytes(void) { return 6 * xs::MAILBOX_WORDS * sizeof(unsigned); }
 /* Host: the six seeded poses (or a command: cmd 1 = leave) for the launch that polls `mailbox_host` for `mailbox_seq` — six mailboxes of the
- * xs_icp_post_pose form in a row, written in order. */
+ * xs_icp_post_pose layout in a row.  The launch polls the LAST box and then reads all six, checking each one's sequence words: so the payloads of
+ * all six go out first, then the sequence words of boxes 0 .. 4, then those of box 5 — three store fences (the mailbox is write-combining
+ * BAR memory on the CPU side: stores may pass each other between fences) instead of the twelve of six xs_icp_post_pose calls, each of which
+ * drains the write-combining buffers while the launch waits. */
 extern "C" void xs_gn_post_poses(void *mailbox_host, const float *Rv2c108, const float *tv2c36, unsigned mailbox_seq, int cmd) {
-    for (int k = 0; k < 6; ++k)
-        xs_icp_post_pose(static_cast<char *>(mailbox_host) + (size_t)k * xs::MAILBOX_WORDS * sizeof(unsigned), Rv2c108 ? Rv2c108 + 18 * k : nullptr,
-                         tv2c36 ? tv2c36 + 6 * k : nullptr, mailbox_seq, cmd);
+    static const bool twelve = exp_env_set("XS_GN_POST_TWELVE_FENCES");   // A/B aid: box by box, as until round 6
+    if (twelve) {
+        for (int k = 0; k < 6; ++k)
+            xs_icp_post_pose(static_cast<char *>(mailbox_host) + (size_t)k * xs::MAILBOX_WORDS * sizeof(unsigned), Rv2c108 ? Rv2c108 + 18 * k : nullptr,
+                             tv2c36 ? tv2c36 + 6 * k : nullptr, mailbox_seq, cmd);
+        return;
+    }
+    auto fence = [] {
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();
+#else
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+    };
+    volatile unsigned *base = static_cast<volatile unsigned *>(mailbox_host);
+    for (int k = 0; k < 6; ++k) {   // line 0 = {seq, cmd, f[0..13]}, line 1 = {seq, 0, f[14..23], pad} with f = 18 floats of R, 6 of t
+        volatile unsigned *w = base + (size_t)k * xs::MAILBOX_WORDS;
+        unsigned f[24] = {0};
+        if (Rv2c108) memcpy(f, Rv2c108 + 18 * k, 18 * sizeof(float));
+        if (tv2c36) memcpy(f + 18, tv2c36 + 6 * k, 6 * sizeof(float));
+        w[1] = (unsigned)cmd;
+        for (int i = 0; i < 14; ++i) w[2 + i] = f[i];
+        w[17] = 0;
+        for (int i = 0; i < 10; ++i) w[18 + i] = f[14 + i];
+    }
+    fence();
+    for (int k = 0; k < 5; ++k) { base[(size_t)k * xs::MAILBOX_WORDS] = mailbox_seq; base[(size_t)k * xs::MAILBOX_WORDS + 16] = mailbox_seq; }
+    fence();
+    base[5 * (size_t)xs::MAILBOX_WORDS] = mailbox_seq; base[5 * (size_t)xs::MAILBOX_WORDS + 16] = mailbox_seq;
+    fence();
 }
 __global__ void k_publish_sums(const double *sums, int n, double *publish, unsigned long long seq) {
     const int tid = threadIdx.x;
