@@ -961,30 +961,26 @@ extern "C" int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_se
                       distThres, angleThres, y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream,
                       "xs_icp_accumulate_posted: null pointer", mailbox, mailbox_seq);
 }
-/* Host side of the mailbox: the payload first, the two sequence words last (the poller accepts a
- * line only with its sequence word, and a 64-byte line is read as one unit).  The mailbox may be
- * device memory mapped through the PCIe BAR (write-combining on the CPU side): the store fences push
- * the payload out before the sequence words, and the sequence words out before returning. */
-static inline void store_fence() {
-#if defined(__x86_64__)
-    __builtin_ia32_sfence();
-#else
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-#endif
-}
+/* Host side of the mailbox (xs_mailbox.h has the layout and the reasons).  With MOVDIR64B each of the two lines goes out as one 64-byte write,
+ * sequence word and payload together; without it: the payload first, a store fence, the two sequence words, a store fence (the poller accepts a
+ * line only with its sequence word and reads the payload again after it has seen both). */
 extern "C" void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const float *tcurr6, unsigned mailbox_seq, int cmd) {
+    static const bool direct = mailbox_cpu_has_direct_store() && !exp_env_set("XS_MAILBOX_NO_DIRECT_STORE");
+    alignas(64) unsigned img[MAILBOX_WORDS];
+    mailbox_image(img, Rcurr18, tcurr6, mailbox_seq, cmd);
+    if (direct && (reinterpret_cast<uintptr_t>(mailbox_host) % 64) == 0) {
+        mailbox_store_fence();   // (behind whatever this thread posted before: nothing is pending, so this costs nothing)
+        mailbox_direct_store_64(mailbox_host, img);
+        mailbox_direct_store_64(static_cast<char *>(mailbox_host) + 64, img + 16);
+        return;
+    }
     volatile unsigned *w = (volatile unsigned *)mailbox_host;
-    unsigned f[24] = {0};
-    if (Rcurr18) memcpy(f, Rcurr18, 18 * sizeof(float));
-    if (tcurr6) memcpy(f + 18, tcurr6, 6 * sizeof(float));
-    w[1] = (unsigned)cmd;
-    for (int i = 0; i < 14; ++i) w[2 + i] = f[i];
-    w[17] = 0;
-    for (int i = 0; i < 10; ++i) w[18 + i] = f[14 + i];
-    store_fence();
+    for (int i = 1; i < 16; ++i) w[i] = img[i];
+    for (int i = 17; i < MAILBOX_WORDS; ++i) w[i] = img[i];
+    mailbox_store_fence();
     w[0] = mailbox_seq;
     w[16] = mailbox_seq;
-    store_fence();
+    mailbox_store_fence();
 }
 /* A mailbox where polling is cheapest: fine-grained device memory the CPU writes through the large
  * BAR (512 workgroups then poll local memory, not the PCIe link), or — without a large BAR —

@@ -42,3 +42,42 @@ __device__ __forceinline__ float mailbox_float(const unsigned *s_mail, int i) {
     return __int_as_float(__builtin_amdgcn_readfirstlane((int)s_mail[i < 14 ? 2 + i : 18 + (i - 14)]));
 }
 }  // namespace xs
+
+// ---- host side: how the CPU writes a mailbox line ---------------------------------------------------------------------------------
+// The mailbox is device memory behind the PCIe BAR: write-combining on the CPU side.  Ordinary stores wait in the core's write-combining
+// buffers until something drains them, and may pass each other until a store fence — so a post was payload, sfence, sequence words, sfence,
+// each fence a round of draining while the kernel waits (profiles/r06_ab_gn_post_fences.txt: a quarter of a microsecond apiece).  Where the CPU
+// has MOVDIR64B (cpuid 7.0 ecx bit 28: Sapphire Rapids, Zen 5) a whole 64-byte line — its sequence word and its payload together — goes out as
+// ONE write transaction that never sits in a buffer: no fence between payload and sequence word (they cannot be seen apart), none behind it.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cpuid.h>
+#include <immintrin.h>
+namespace xs {
+__attribute__((target("movdir64b"))) static inline void mailbox_direct_store_64(void *dst64, const void *src64) { _movdir64b(dst64, src64); }
+static inline bool mailbox_cpu_has_direct_store() {
+    static const bool has = [] { unsigned a = 0, b = 0, c = 0, d = 0; return __get_cpuid_count(7, 0, &a, &b, &c, &d) && ((c >> 28) & 1u); }();
+    return has;
+}
+static inline void mailbox_store_fence() { __builtin_ia32_sfence(); }
+}  // namespace xs
+#else   // (the device pass parses host functions too: it sees these)
+namespace xs {
+static inline void mailbox_direct_store_64(void *, const void *) {}
+static inline bool mailbox_cpu_has_direct_store() { return false; }
+static inline void mailbox_store_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+}  // namespace xs
+#endif
+#include <cstring>
+namespace xs {
+// the two lines of one mailbox as they lie in memory: line 0 = {seq, cmd, f[0..13]}, line 1 = {seq, 0, f[14..23], pad}
+static inline void mailbox_image(unsigned img[MAILBOX_WORDS], const float *R18, const float *t6, unsigned seq, int cmd) {
+    unsigned f[24] = {0};
+    if (R18) std::memcpy(f, R18, 18 * sizeof(float));
+    if (t6) std::memcpy(f + 18, t6, 6 * sizeof(float));
+    std::memset(img, 0, MAILBOX_WORDS * sizeof(unsigned));
+    img[0] = seq; img[1] = (unsigned)cmd;
+    for (int i = 0; i < 14; ++i) img[2 + i] = f[i];
+    img[16] = seq;
+    for (int i = 0; i < 10; ++i) img[18 + i] = f[14 + i];
+}
+}  // namespace xs

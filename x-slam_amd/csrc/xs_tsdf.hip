@@ -2358,7 +2358,7 @@ extern "C" size_t xs_gn_mailbox_bytes(void) { return 6 * xs::MAILBOX_WORDS * siz
  * xs_icp_post_pose layout in a row.  The launch polls the LAST box and then reads all six, checking each one's sequence words: so the payloads of
  * all six go out first, then the sequence words of boxes 0 .. 4, then those of box 5 — three store fences (the mailbox is write-combining
  * BAR memory on the CPU side: stores may pass each other between fences) instead of the twelve of six xs_icp_post_pose calls, each of which
- * drains the write-combining buffers while the launch waits. */
+ * drains the write-combining buffers while the launch waits.  With MOVDIR64B (xs_mailbox.h): twelve direct 64-byte writes and one fence. */
 extern "C" void xs_gn_post_poses(void *mailbox_host, const float *Rv2c108, const float *tv2c36, unsigned mailbox_seq, int cmd) {
     static const bool twelve = exp_env_set("XS_GN_POST_TWELVE_FENCES");   // A/B aid: box by box, as until round 6
     if (twelve) {
@@ -2367,29 +2367,32 @@ extern "C" void xs_gn_post_poses(void *mailbox_host, const float *Rv2c108, const
                              tv2c36 ? tv2c36 + 6 * k : nullptr, mailbox_seq, cmd);
         return;
     }
-    auto fence = [] {
-#if defined(__x86_64__)
-        __builtin_ia32_sfence();
-#else
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
-#endif
-    };
+    static const bool direct = mailbox_cpu_has_direct_store() && !exp_env_set("XS_MAILBOX_NO_DIRECT_STORE");
+    alignas(64) unsigned img[6][xs::MAILBOX_WORDS];
+    for (int k = 0; k < 6; ++k) mailbox_image(img[k], Rv2c108 ? Rv2c108 + 18 * k : nullptr, tv2c36 ? tv2c36 + 6 * k : nullptr, mailbox_seq, cmd);
     volatile unsigned *base = static_cast<volatile unsigned *>(mailbox_host);
-    for (int k = 0; k < 6; ++k) {   // line 0 = {seq, cmd, f[0..13]}, line 1 = {seq, 0, f[14..23], pad} with f = 18 floats of R, 6 of t
-        volatile unsigned *w = base + (size_t)k * xs::MAILBOX_WORDS;
-        unsigned f[24] = {0};
-        if (Rv2c108) memcpy(f, Rv2c108 + 18 * k, 18 * sizeof(float));
-        if (tv2c36) memcpy(f + 18, tv2c36 + 6 * k, 6 * sizeof(float));
-        w[1] = (unsigned)cmd;
-        for (int i = 0; i < 14; ++i) w[2 + i] = f[i];
-        w[17] = 0;
-        for (int i = 0; i < 10; ++i) w[18 + i] = f[14 + i];
+    if (direct && (reinterpret_cast<uintptr_t>(mailbox_host) % 64) == 0) {
+        // MOVDIR64B: every line is one write with its sequence word inside; boxes 0 .. 4, one fence, box 5 (the one the launch polls)
+        mailbox_store_fence();
+        for (int k = 0; k < 5; ++k) {
+            mailbox_direct_store_64(const_cast<unsigned *>(base) + (size_t)k * xs::MAILBOX_WORDS, img[k]);
+            mailbox_direct_store_64(const_cast<unsigned *>(base) + (size_t)k * xs::MAILBOX_WORDS + 16, img[k] + 16);
+        }
+        mailbox_store_fence();
+        mailbox_direct_store_64(const_cast<unsigned *>(base) + 5 * (size_t)xs::MAILBOX_WORDS, img[5]);
+        mailbox_direct_store_64(const_cast<unsigned *>(base) + 5 * (size_t)xs::MAILBOX_WORDS + 16, img[5] + 16);
+        return;
     }
-    fence();
+    for (int k = 0; k < 6; ++k) {
+        volatile unsigned *w = base + (size_t)k * xs::MAILBOX_WORDS;
+        for (int i = 1; i < 16; ++i) w[i] = img[k][i];
+        for (int i = 17; i < xs::MAILBOX_WORDS; ++i) w[i] = img[k][i];
+    }
+    mailbox_store_fence();
     for (int k = 0; k < 5; ++k) { base[(size_t)k * xs::MAILBOX_WORDS] = mailbox_seq; base[(size_t)k * xs::MAILBOX_WORDS + 16] = mailbox_seq; }
-    fence();
+    mailbox_store_fence();
     base[5 * (size_t)xs::MAILBOX_WORDS] = mailbox_seq; base[5 * (size_t)xs::MAILBOX_WORDS + 16] = mailbox_seq;
-    fence();
+    mailbox_store_fence();
 }
 __global__ void k_publish_sums(const double *sums, int n, double *publish, unsigned long long seq) {
     const int tid = threadIdx.x;
