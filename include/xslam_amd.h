@@ -391,7 +391,17 @@ int xs_icp_workspace_init(void *workspace, void *stream);
  * doubles — the 27 complex<double> sums in the reference's mbuf order, then the inlier count.
  * workspace replaces gbuf.  [y0, y1): pixel rows covered.  done_flag (optional; with sums_dev in
  * host-coherent pinned memory): the kernel stores done_seq there, system-scope release, after the
- * sums — the host may spin on it instead of copying + synchronising.  No synchronisation. */
+ * sums — the host may spin on it instead of copying + synchronising.  No synchronisation.
+ * done_flag == XS_ICP_PUBLISH_PAIRS (xs_icp_accumulate, _real, _posted, _posted_real): sums_dev is host-coherent pinned memory of
+ * XS_ICP_PAIRS_BYTES taking 55 pairs {u64 done_seq, double sum} — every sum leaves as one 16-byte store that carries its own sequence
+ * word, so no completion word has to be ordered behind the sums (on the device: no wait for the stores' acknowledgement, no barrier, no
+ * release store).  The host spins until all 55 sequence words equal done_seq (xs_icp_wait_pairs does); a posted launch that gave up
+ * writes done_seq | 1 << 63 into the first pair's word.  Use a different done_seq for every launch on a buffer. */
+#define XS_ICP_PUBLISH_PAIRS ((unsigned long long *)(size_t)1)
+#define XS_ICP_PAIRS_BYTES (55 * 16)
+/* host: spin until every pair of `pairs_host` carries `seq`, then copy the 55 sums out.  0 = done, 1 = the launch gave up (its poses never
+ * came), 2 = nothing within max_spins polls. */
+int xs_icp_wait_pairs(const void *pairs_host, unsigned long long seq, double *sums55, long long max_spins);
 int xs_icp_accumulate(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
                       const float *Rprev_inv18, const float *tprev6, const float *intr4, const float *vmap_g_prev,
                       const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0, int y1,

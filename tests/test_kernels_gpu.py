@@ -775,6 +775,65 @@ def test_icp_posted_pose_gives_up(dev):
         free()
 
 
+def test_icp_sums_published_as_self_validating_pairs(dev, oracle):
+    """XS_ICP_PUBLISH_PAIRS: the 55 sums reach pinned host memory as 55 stores of {sequence number, sum} and the host needs no completion word
+    behind them.  The sums equal the plain launch's bit for bit at all three levels (plain and posted launch); a second launch with another
+    number replaces every pair; a posted launch whose pose never comes reports number | 1 << 63 in the first pair and touches no other."""
+    import ctypes as C
+    torch, capi = dev
+    prm, T0, pv, pn, cv, cn = icp_inputs(oracle)
+    Rprev_inv = oracle.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    pairs, free = _coherent_host_bytes(1024)
+    mailbox, in_device = capi.icp_mailbox_alloc()
+    seq = 100
+    try:
+        d = oracle.bilateral(synth.s1_frame(1))
+        for level in range(3):
+            if level:
+                pv, pn = oracle.resize_map(pv, False), oracle.resize_map(pn, True)
+                d = oracle.pyr_down(d)
+            k = intr_of(prm, level)
+            cvl = oracle.create_vmap(k, d); cnl = oracle.create_nmap(cvl)
+            rows, cols = cvl.shape[0] // 3, cvl.shape[1]
+            dev_maps = [to_dev(torch, m) for m in (cvl, cnl, pv, pn)]
+            plain = torch.zeros(55, dtype=torch.float64, device="cuda")
+            common = (dev_maps[0], dev_maps[1], Rprev_inv, T0["tc2w"], k, dev_maps[2], dev_maps[3], cols * 8, rows, cols, 0.10, angle, ws)
+            capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], *common, plain)
+            torch.cuda.synchronize()
+            want = plain.cpu().numpy()
+            assert want[54] > 0.3 * rows * cols
+            seq += 1
+            capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], *common, pairs, done_flag=capi.ICP_PUBLISH_PAIRS, done_seq=seq)
+            rc, got = capi.icp_wait_pairs(pairs, seq)
+            assert rc == 0 and np.array_equal(got, want), level
+            words = np.ctypeslib.as_array((C.c_ulonglong * 110).from_address(pairs))
+            assert np.all(words[0::2] == seq)
+            seq += 1
+            capi.icp_accumulate_posted(mailbox, seq & 0xffffffff, *common, pairs, done_flag=capi.ICP_PUBLISH_PAIRS, done_seq=seq)
+            assert capi.icp_wait_pairs(pairs, seq, max_spins=2000)[0] == 2           # (no pose yet: nothing comes)
+            capi.icp_post_pose(mailbox, T0["Rc2w"], T0["tc2w"], seq & 0xffffffff)
+            rc, got = capi.icp_wait_pairs(pairs, seq)
+            assert rc == 0 and np.array_equal(got, want), level
+            torch.cuda.synchronize()
+        seq += 1
+        capi.icp_accumulate_posted(mailbox, seq & 0xffffffff, *common, pairs, done_flag=capi.ICP_PUBLISH_PAIRS, done_seq=seq)   # never posted
+        rc, _ = capi.icp_wait_pairs(pairs, seq)
+        assert rc == 1
+        torch.cuda.synchronize()
+        assert np.all(words[2::2] == seq - 1)                                        # (only the first pair's word was touched)
+        capi.icp_workspace_init(ws)
+        seq += 1
+        capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], *common, pairs, done_flag=capi.ICP_PUBLISH_PAIRS, done_seq=seq)
+        rc, got = capi.icp_wait_pairs(pairs, seq)
+        assert rc == 0 and np.array_equal(got, want)
+    finally:
+        torch.cuda.synchronize()
+        capi.icp_mailbox_free(mailbox, in_device)
+        free()
+
+
 def test_icp_iterate_singular_system_stops_the_loop(dev):
     """No valid pixel: zero sums, |det| < 1e-15 -> status 1, pose untouched; the next launch returns at
     once (sums buffer not written), as PoseEstimate returns 0 on the host (KinectFusionReconstruction.cpp:203-210)."""

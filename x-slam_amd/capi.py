@@ -115,6 +115,7 @@ _SIGS = {
     "xs_extract_workspace_bytes": (_sz, [_i32p]),
     "xs_extract_points": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp]),
     "xs_extract_normals": (C.c_int, [_vp, _sz, _i32p, C.c_float, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
+    "xs_icp_wait_pairs": (C.c_int, [_vp, C.c_ulonglong, _vp, C.c_longlong]),
     "xs_icp_workspace_bytes": (_sz, []),
     "xs_icp_workspace_init": (C.c_int, [_vp, _vp]),
     "xs_icp_accumulate": (C.c_int, [_f32p, _f32p, _vp, _vp, _f32p, _f32p, _f32p, _vp, _vp, _sz, C.c_int, C.c_int, C.c_float,
@@ -638,13 +639,25 @@ def icp_workspace_init(workspace, stream=None):
     check(_lib.xs_icp_workspace_init(_ptr(workspace), _stream(stream)))
 
 
+ICP_PUBLISH_PAIRS = 1      # XS_ICP_PUBLISH_PAIRS: pass as done_flag; `sums` is then ICP_PAIRS_BYTES of host-coherent pinned memory (icp_wait_pairs)
+ICP_PAIRS_BYTES = 55 * 16
+
+
 def icp_accumulate(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
-                   distThres, angleThres, workspace, sums, y0=0, y1=None, stream=None):
+                   distThres, angleThres, workspace, sums, y0=0, y1=None, stream=None, done_flag=None, done_seq=0):
     a, b, c, d, k = _fa(Rcurr, 18), _fa(tcurr, 6), _fa(Rprev_inv, 18), _fa(tprev, 6), _fa(intr, 4)
     P = lambda x: x.ctypes.data_as(_f32p)
     y1 = rows if y1 is None else y1
     check(_lib.xs_icp_accumulate(P(a), P(b), _ptr(vmap_curr), _ptr(nmap_curr), P(c), P(d), P(k), _ptr(vmap_g_prev), _ptr(nmap_g_prev),
-                                 map_step, rows, cols, distThres, angleThres, y0, y1, _ptr(workspace), _ptr(sums), None, 0, _stream(stream)))
+                                 map_step, rows, cols, distThres, angleThres, y0, y1, _ptr(workspace), _ptr(sums), _ptr(done_flag), done_seq,
+                                 _stream(stream)))
+
+
+def icp_wait_pairs(pairs, seq, max_spins=2_000_000_000):
+    """(rc, sums[55]): spins until all 55 pairs of the pinned buffer carry seq; rc 1 = the launch gave up, 2 = nothing came."""
+    out = np.zeros(55, np.float64)
+    rc = _lib.xs_icp_wait_pairs(_ptr(pairs), seq, out.ctypes.data, max_spins)
+    return rc, out
 
 
 def icp_accumulate_real(Rcurr, tcurr, vmap_curr_real, nmap_curr_real, real_step, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, map_step, rows,

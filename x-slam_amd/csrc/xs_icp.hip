@@ -43,6 +43,7 @@ struct IcpArgs {
     unsigned *ticket;       // zeroed before the launch
     double *out;            // 54 sums (27 x re,im) + [54] = inlier count
     unsigned long long *done_flag; unsigned long long done_seq;  // optional: host-visible completion word
+    int pairs;              // out is host-coherent pinned memory taking 55 x {u64 done_seq, double sum}: every sum carries its own sequence word (XS_ICP_PUBLISH_PAIRS)
     // optional device-side pose update (xs_icp_iterate): the last workgroup solves for the increment and
     // composes it into *pose, which the next launch reads instead of Rcurr / tcurr above
     IcpPoseState *pose; IcpPoseState *pose_host; int load_pose;
@@ -346,6 +347,8 @@ __global__ void __launch_bounds__(64 * WAVES)
         if (cmd != 0) {
             if (cmd == 2 && threadIdx.x == 0 && a.done_flag)
                 __hip_atomic_store(a.done_flag, a.done_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (cmd == 2 && threadIdx.x == 0 && a.pairs)   // (the first pair's sequence word carries the give-up)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.out), a.done_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (cmd == 2 && threadIdx.x == 0 && a.host_records)   // host fold: the give-up shows in the record's sequence word
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.host_records) + (size_t)blockIdx.x * NP + (NP - 1),
                                    a.record_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -642,8 +645,19 @@ __global__ void __launch_bounds__(64 * WAVES)
                 asm volatile("" : "+v"(t.x), "+v"(t.y));
 #endif
             }
-            a.out[2 * threadIdx.x] = t.x;
-            if (2 * threadIdx.x + 1 < NS + 1) a.out[2 * threadIdx.x + 1] = t.y;
+            if (a.pairs) {
+                // Every sum leaves as ONE 16-byte store {sequence number, sum}: a store of one lane cannot be seen in halves, so the host
+                // needs no word that is ordered behind the others — and the kernel no wait for its stores' acknowledgement, barrier and
+                // release store between the sums and that word (profiles/r06_ab_icp_publish_pairs.txt).
+                typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+                ull2 *pairs = reinterpret_cast<ull2 *>(a.out);
+                __builtin_nontemporal_store(ull2{a.done_seq, (unsigned long long)__double_as_longlong(t.x)}, pairs + 2 * threadIdx.x);
+                if (2 * threadIdx.x + 1 < NS + 1)
+                    __builtin_nontemporal_store(ull2{a.done_seq, (unsigned long long)__double_as_longlong(t.y)}, pairs + 2 * threadIdx.x + 1);
+            } else {
+                a.out[2 * threadIdx.x] = t.x;
+                if (2 * threadIdx.x + 1 < NS + 1) a.out[2 * threadIdx.x + 1] = t.y;
+            }
         }
         if (a.done_flag) {
             // out (and the flag) may live in host-coherent pinned memory: push the sums out, then
@@ -822,6 +836,11 @@ static int icp_launch(const float *Rcurr18, const float *tcurr6, const float *vm
     a.partials = workspace ? (double *)((char *)workspace + 256) : nullptr;
     a.host_records = host_records; a.record_seq = record_seq;
     a.out = sums_dev; a.done_flag = done_flag; a.done_seq = done_seq;
+    a.pairs = 0;
+    if (done_flag == XS_ICP_PUBLISH_PAIRS) {
+        if (pose || host_records) return xs_set_error(hipErrorInvalidValue, "xs_icp: XS_ICP_PUBLISH_PAIRS goes with the plain and posted accumulate calls only");
+        a.pairs = 1; a.done_flag = nullptr;
+    }
     a.pose = pose; a.pose_host = pose_host; a.load_pose = (pose && Rcurr18) ? 1 : 0;
     a.mailbox = nullptr; a.mailbox_seq = 0;
     int waves = 4;
@@ -960,6 +979,26 @@ extern "C" int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_se
     return icp_launch(nullptr, nullptr, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step, rows, cols,
                       distThres, angleThres, y0, y1, workspace, sums_dev, done_flag, done_seq, nullptr, nullptr, nullptr, stream,
                       "xs_icp_accumulate_posted: null pointer", mailbox, mailbox_seq);
+}
+/* host half of XS_ICP_PUBLISH_PAIRS: every pair {sequence number, sum} arrives as one 16-byte write; done when all 55 carry `seq` */
+extern "C" int xs_icp_wait_pairs(const void *pairs_host, unsigned long long seq, double *sums55, long long max_spins) {
+    const volatile unsigned long long *p = static_cast<const volatile unsigned long long *>(pairs_host);
+    for (long long spins = 0;; ++spins) {
+        int have = 0;
+        for (int i = 0; i < NS + 1; ++i) have += p[2 * i] == seq;
+        if (have == NS + 1) break;
+        if (p[0] == (seq | kIcpTimeoutBit)) return 1;
+        if (spins >= max_spins) return 2;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < NS + 1; ++i) {
+        const unsigned long long bits = p[2 * i + 1];
+        memcpy(&sums55[i], &bits, sizeof(double));
+    }
+    return 0;
 }
 /* Host side of the mailbox (xs_mailbox.h has the layout and the reasons).  With MOVDIR64B each of the two lines goes out as one 64-byte write,
  * sequence word and payload together; without it: the payload first, a store fence, the two sequence words, a store fence (the poller accepts a

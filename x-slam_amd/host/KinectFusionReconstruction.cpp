@@ -27,6 +27,8 @@ KinectFusionReconstruction::KinectFusionReconstruction() {
     hipSafeCall(hipHostMalloc((void **)&pinned_counters_, COUNTER_RING * 2 * sizeof(unsigned long long)));
     hipSafeCall(hipHostMalloc((void **)&pinned_sums_, PINNED_DOUBLES * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < PINNED_DOUBLES; ++i) pinned_sums_[i] = 0.0;
+    hipSafeCall(hipHostMalloc((void **)&pinned_pairs_, XS_ICP_PAIRS_BYTES, hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(pinned_pairs_, 0, XS_ICP_PAIRS_BYTES);
     hipSafeCall(hipHostMalloc((void **)&pinned_records_, xs_icp_records_bytes(), hipHostMallocCoherent | hipHostMallocMapped));
     std::memset(pinned_records_, 0, xs_icp_records_bytes());
 }
@@ -47,6 +49,7 @@ KinectFusionReconstruction::~KinectFusionReconstruction() {
     if (pinned_counters_) (void)hipHostFree(pinned_counters_);
     if (gather_counts_host_) (void)hipHostFree(gather_counts_host_);
     if (pinned_sums_) (void)hipHostFree(pinned_sums_);
+    if (pinned_pairs_) (void)hipHostFree(pinned_pairs_);
     if (pinned_records_) (void)hipHostFree(pinned_records_);
     if (icp_mailbox_) (void)xs_icp_mailbox_free(icp_mailbox_, icp_mailbox_in_device_);
     if (integrate_mailbox_) (void)xs_icp_mailbox_free(integrate_mailbox_, integrate_mailbox_in_device_);
@@ -135,6 +138,7 @@ void KinectFusionReconstruction::SetYamlParameters(const FlatYaml &config_) {
     raycast_sign_map_shift = std::min(6, std::max(0, config.as<int>("raycast_sign_map_shift", 0)));   // 0: the finest usable one
     icp_lookahead = config.as<int>("icp_lookahead", 1);
     icp_host_fold = config.as<bool>("icp_host_fold", false);
+    icp_publish_pairs = config.as<bool>("icp_publish_pairs", true);
     force_shard_composite = config.as<bool>("force_shard_composite", false);
     shard_composite_gather = config.as<bool>("shard_composite_gather", true);
     raycast_builds_pyramid = config.as<bool>("raycast_builds_pyramid", true);
@@ -340,7 +344,8 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
         MapArr &vc = vmaps_curr_d[level], &nc = nmaps_curr_d[level], &vp = vmaps_g_prev_d[level], &np_ = nmaps_g_prev_d[level];
         const Intr k = kinect_intrinsic(level);
         const int rows = vc.rows() / 3, cols = vc.cols();
-        unsigned long long *flag = reinterpret_cast<unsigned long long *>(pinned_sums_ + 56);
+        unsigned long long *flag = icp_publish_pairs ? XS_ICP_PUBLISH_PAIRS : reinterpret_cast<unsigned long long *>(pinned_sums_ + 56);
+        double *sums_out = icp_publish_pairs ? reinterpret_cast<double *>(pinned_pairs_) : pinned_sums_;
         const unsigned long long seq = ++icp_seq_;
         if (icp_host_fold) {
             check_rc(xs_icp_accumulate_records(R ? &R->data[0].x.re : nullptr, R ? &t->x.re : nullptr, R ? nullptr : mailbox, mail_seq, &vc.ptr()->re,
@@ -353,21 +358,21 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
         if (R && real)
             check_rc(xs_icp_accumulate_real(&R->data[0].x.re, &t->x.re, &vc.ptr()->re, &nc.ptr()->re, vreal_curr_d[level].ptr(), nreal_curr_d[level].ptr(),
                                             vreal_curr_d[level].step(), &device_Rprev_inv.data[0].x.re, &device_tprev.x.re, &k.fx, &vp.ptr()->re,
-                                            &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, 0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq,
+                                            &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, 0, rows, icp_ws_.ptr(), sums_out, flag, seq,
                                             current_stream()), "estimateCombined");
         else if (R)
             check_rc(xs_icp_accumulate(&R->data[0].x.re, &t->x.re, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
                                        &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres,
-                                       0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq, current_stream()), "estimateCombined");
+                                       0, rows, icp_ws_.ptr(), sums_out, flag, seq, current_stream()), "estimateCombined");
         else if (real)
             check_rc(xs_icp_accumulate_posted_real(mailbox, mail_seq, &vc.ptr()->re, &nc.ptr()->re, vreal_curr_d[level].ptr(), nreal_curr_d[level].ptr(),
                                                    vreal_curr_d[level].step(), &device_Rprev_inv.data[0].x.re, &device_tprev.x.re, &k.fx,
                                                    &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres, angleThres, 0, rows, icp_ws_.ptr(),
-                                                   pinned_sums_, flag, seq, current_stream()), "estimateCombined (posted)");
+                                                   sums_out, flag, seq, current_stream()), "estimateCombined (posted)");
         else
             check_rc(xs_icp_accumulate_posted(mailbox, mail_seq, &vc.ptr()->re, &nc.ptr()->re, &device_Rprev_inv.data[0].x.re,
                                               &device_tprev.x.re, &k.fx, &vp.ptr()->re, &np_.ptr()->re, vc.step(), rows, cols, distThres,
-                                              angleThres, 0, rows, icp_ws_.ptr(), pinned_sums_, flag, seq, current_stream()),
+                                              angleThres, 0, rows, icp_ws_.ptr(), sums_out, flag, seq, current_stream()),
                      "estimateCombined (posted)");
         return seq;
     };
@@ -440,6 +445,8 @@ int KinectFusionReconstruction::PoseEstimate(Matrix3frm Rcurr, Vector3cf tcurr, 
                     const int level_cols = vmaps_curr_d[level_index].cols(), level_rows = vmaps_curr_d[level_index].rows() / 3;
                     if (xs_icp_sum_records(pinned_records_, xs_icp_records_count(level_cols, 0, level_rows), seq, pinned_sums_, 2000000000LL) != 0)
                         return launch_gave_up();
+                } else if (icp_publish_pairs) {
+                    if (xs_icp_wait_pairs(pinned_pairs_, seq, pinned_sums_, 2000000000LL) != 0) return launch_gave_up();
                 } else {
                     long spins = 0;
                     unsigned long long seen;

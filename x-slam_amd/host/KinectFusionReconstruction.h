@@ -158,6 +158,10 @@ public:
     // and a system-scope release over PCIe cost what the agent-scope publish + final sum cost), so it is off by default.
     // YAML key icp_host_fold.
     bool icp_host_fold = false;
+    // Every ICP sum reaches the host as one 16-byte store {sequence number, sum} (XS_ICP_PUBLISH_PAIRS, include/xslam_amd.h): no completion word that
+    // has to be ordered behind the sums — the kernel's last workgroup skips the wait for its stores' acknowledgement, a barrier and a release store
+    // per launch.  YAML key icp_publish_pairs; the launches of the host-solve loop only (not icp_host_fold, not the device solve).
+    bool icp_publish_pairs = true;
     // Sharded runs (SetSharding): false (default) — every rank evaluates the whole ICP itself; all ranks hold
     // the same current-frame maps and the composited previous-frame maps, the reduction is deterministic,
     // so they reach the same pose bit for bit with no collective inside the ICP loop.  true — pixel rows
@@ -304,6 +308,7 @@ private:
     // device-side loop, [128 + 64*n ..) the 55 values of its iteration n
     enum { ICP_LOG_MAX = 62, PINNED_DOUBLES = 128 + 64 * ICP_LOG_MAX };
     double *pinned_sums_ = nullptr;
+    unsigned long long *pinned_pairs_ = nullptr;   // XS_ICP_PAIRS_BYTES of host-coherent pinned memory (icp_publish_pairs)
     // the integrate call's header clear / count fold taken off the main stream (SurfaceMeasure, IntegrateFrame)
     bool integrate_split() const;
     void flush_pending_fold(hipStream_t st);
