@@ -1076,9 +1076,10 @@ extern "C" int xs_icp_iterate(const float *Rcurr18, const float *tcurr6, const f
 }
 
 /* estimateCombined whole (ICP.cu:365-429): the reduction, then — where the reference synchronises the device and downloads (:414-417) —
- * the kernel's last workgroup has written the 27 sums, the inlier count and a sequence word straight into host-coherent pinned memory
- * (xs_icp_accumulate's done_flag form) and the host spins on that word: the call returns when the launch, and with it everything before it on
- * the stream, has completed, without a copy or a stream drain (round 6: ~10 us less per iteration for a caller that changes nothing).  Unpacks
+ * the kernel's last workgroup has written the 27 sums and the inlier count straight into host-coherent pinned memory, each with the launch's
+ * number in the same 16-byte store (XS_ICP_PUBLISH_PAIRS), and the host spins until all of them carry it: the call returns when the launch, and
+ * with it everything before it on the stream, has completed, without a copy or a stream drain (round 6: ~10 us less per iteration for a caller
+ * that changes nothing).  Unpacks
  * into the symmetric 6x6 A (A[i*6+j] = A[j*6+i]) and b, both complex<double> (re, im) pairs.  sums_dev (optional): also receives the 55
  * doubles, by an asynchronous copy the call does not wait for.  inliers may be NULL.  One call at a time per host thread. */
 extern "C" int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, const float *vmap_curr, const float *nmap_curr,
@@ -1086,28 +1087,22 @@ extern "C" int xs_estimate_combined(const float *Rcurr18, const float *tcurr6, c
                                     const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres,
                                     void *workspace, double *sums_dev, double *A72_host, double *b12_host, long long *inliers,
                                     void *stream) {
-    static thread_local double *host = nullptr;            // 55 sums + pad + the sequence word at [56]
+    static thread_local double *host = nullptr;            // the 55 sums as doubles (what xs_icp_unpack and the optional copy read)
+    static thread_local void *pairs = nullptr;             // XS_ICP_PUBLISH_PAIRS: 55 x {sequence number, sum} written by the launch
     static thread_local unsigned long long seq = 0;
     if (!host) {
         XS_CHECK(hipHostMalloc((void **)&host, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
         memset(host, 0, 64 * sizeof(double));
+        XS_CHECK(hipHostMalloc(&pairs, XS_ICP_PAIRS_BYTES, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(pairs, 0, XS_ICP_PAIRS_BYTES);
     }
     ++seq;
-    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(host + 56);
     int rc = xs_icp_accumulate(Rcurr18, tcurr6, vmap_curr, nmap_curr, Rprev_inv18, tprev6, intr4, vmap_g_prev, nmap_g_prev, map_step,
-                               rows, cols, distThres, angleThres, 0, rows, workspace, host, const_cast<unsigned long long *>(flag), seq, stream);
+                               rows, cols, distThres, angleThres, 0, rows, workspace, static_cast<double *>(pairs), XS_ICP_PUBLISH_PAIRS, seq, stream);
     if (rc) return rc;
-    if (rows <= 0 || cols <= 0) { XS_CHECK(hipStreamSynchronize((hipStream_t)stream)); }   // (nothing was launched: nothing publishes)
-    else {
-        long long spins = 0;
-        while (*flag != seq) {
-            if (++spins > 4000000000LL) return xs_set_error(hipErrorLaunchTimeOut, "xs_estimate_combined: the launch never published its sums");
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
+    if (rows <= 0 || cols <= 0) { XS_CHECK(hipStreamSynchronize((hipStream_t)stream)); memset(host, 0, 55 * sizeof(double)); }   // (nothing was launched: nothing publishes)
+    else if (xs_icp_wait_pairs(pairs, seq, host, 4000000000LL) != 0)
+        return xs_set_error(hipErrorLaunchTimeOut, "xs_estimate_combined: the launch never published its sums");
     xs_icp_unpack(host, A72_host, b12_host);
     if (inliers) *inliers = (long long)host[54];
     if (sums_dev) XS_CHECK(hipMemcpyAsync(sums_dev, host, 55 * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
