@@ -67,6 +67,54 @@ def test_icp_reduction_5000_launches_eight_wave_instance():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_icp_pairs_publication_read_as_it_arrives_4000_launches(dev):
+    """XS_ICP_PUBLISH_PAIRS under repetition: every launch's 55 sums are read by the host the moment all 55 pairs carry the launch's number —
+    no stream synchronisation, no completion word — at levels 0 and 2 alternating (sixteen- and eight-wave instances, 256 and 45 workgroups).
+    A pair seen in halves, or a number that overtook its sum, would show as a result that differs from the first of its level."""
+    import ctypes as C
+    torch, capi, pl = dev
+    from oracle.oracle import Oracle
+    o = Oracle()
+    n = 96
+    prm = synth.s1_params(n)
+    res = [n, n, n]
+    v, w, g = o.new_volume(res)
+    T0 = s1_transforms(0, prm)
+    o.integrate(o.scale_depth(synth.s1_frame(0)), v, w, g, res, tranc_dist(prm), 100, T0["Rv2c"], T0["tv2c"], intr_of(prm), prm["tsdf_voxel_size"])
+    pv, pn, _ = o.raycast(intr_of(prm), T0["Rc2v"], T0["tc2v"], T0["Rv2w"], T0["tv2w"], tranc_dist(prm), res, prm["tsdf_voxel_size"], v, g, H, W)
+    d = o.bilateral(synth.s1_frame(1))
+    levels = []
+    for level in range(3):
+        if level:
+            pv, pn, d = o.resize_map(pv, False), o.resize_map(pn, True), o.pyr_down(d)
+        k = intr_of(prm, level)
+        cv = o.create_vmap(k, d); cn = o.create_nmap(cv)
+        levels.append((k, cv.shape[0] // 3, cv.shape[1], [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (cv, cn, pv, pn)]))
+    Rprev_inv = o.m3_inverse(T0["Rc2w"])
+    angle = float(np.sin(np.float32(15.0) / np.float32(180.0) * np.pi))
+    ws = torch.zeros(capi.icp_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    pairs = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(pairs), C.c_size_t(1024), C.c_uint(0x40000000 | 0x2)) == 0
+    C.memset(pairs, 0, 1024)
+    try:
+        first = {}
+        for i in range(4000):
+            level = 0 if i % 2 == 0 else 2
+            k, rows, cols, dv = levels[level]
+            capi.icp_accumulate(T0["Rc2w"], T0["tc2w"], dv[0], dv[1], Rprev_inv, T0["tc2w"], k, dv[2], dv[3], cols * 8, rows, cols, 0.10, angle, ws,
+                                pairs.value, done_flag=capi.ICP_PUBLISH_PAIRS, done_seq=i + 1)
+            rc, got = capi.icp_wait_pairs(pairs.value, i + 1)
+            assert rc == 0
+            if level not in first:
+                first[level] = got.copy()
+                assert got[54] > 0.3 * rows * cols
+            assert np.array_equal(got.view(np.int64), first[level].view(np.int64)), (i, level)
+    finally:
+        torch.cuda.synchronize()
+        hip.hipHostFree(pairs)
+
+
 def test_tsdf_residual_kernels_thousands_of_launches_512(dev):
     """2 000 launches of xs_compute_local_tsdf_hessian and 1 000 of xs_tsdf_gauss_newton_terms over a 512^3 map, fixed inputs: every
     result identical to the first."""
