@@ -452,7 +452,7 @@ int xs_icp_accumulate_posted(const void *mailbox, unsigned mailbox_seq, const fl
                              const float *nmap_g_prev, size_t map_step, int rows, int cols, float distThres, float angleThres, int y0,
                              int y1, void *workspace, double *sums_dev, unsigned long long *done_flag, unsigned long long done_seq,
                              void *stream);
-/* host: writes the mailbox (two 64-byte lines, each its sequence word + payload).  On a CPU with MOVDIR64B each line is one direct 64-byte
+/* host: writes the mailbox (four 32-byte sectors, each its sequence word + payload: two 64-byte lines).  On a CPU with MOVDIR64B each line is one direct 64-byte
  * store; otherwise payload, store fence, sequence words, store fence.  One post per posted launch, from one host thread per mailbox. */
 void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const float *tcurr6, unsigned mailbox_seq, int cmd);
 /* xs_icp_accumulate / xs_icp_accumulate_posted reading the current-frame maps' real parts from float planes (xs_create_vnmaps_real;

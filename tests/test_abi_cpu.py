@@ -49,23 +49,30 @@ def test_ctypes_tables_cover_the_headers():
 
 
 def test_pose_mailbox_layout_host_side():
-    """xs_icp_post_pose is host code: the 128-byte mailbox it writes — two 64-byte lines, each led by the sequence number,
-    command in word 1, the 18 floats of Rcurr then the 6 of tcurr in words 2..15 and 18..27 — is what k_icp<POSE_POSTED> reads;
-    an abandon command carries no pose."""
+    """xs_icp_post_pose is host code: the 128-byte mailbox it writes — four 32-byte sectors, each led by the sequence number, the
+    command in word 1, the 18 floats of Rcurr then the 6 of tcurr in words 2..7, 9..15, 18..23 and 25..29 (csrc/xs_mailbox.h) — is what the
+    posted kernels read; an abandon command carries no pose.  Both an aligned mailbox (MOVDIR64B direct stores where the CPU has them) and
+    an unaligned one (the fenced form)."""
     import ctypes as C
     import numpy as np
     capi = importlib.import_module("x-slam_amd.capi")
     assert capi.icp_mailbox_bytes() == 128
-    buf = np.full(40, 0xDEADBEEF, np.uint32)                      # 32 words + guard
     R = (np.arange(18, dtype=np.float32) + 1).reshape(3, 3, 2)
     t = (np.arange(6, dtype=np.float32) + 101).reshape(3, 2)
-    capi.icp_post_pose(buf.ctypes.data, R, t, 77, cmd=0)
     f = np.concatenate([R.reshape(-1), t.reshape(-1)]).view(np.uint32)
-    assert buf[0] == 77 and buf[16] == 77 and buf[1] == 0 and buf[17] == 0
-    assert np.array_equal(buf[2:16], f[:14]) and np.array_equal(buf[18:28], f[14:])
-    assert np.all(buf[32:] == 0xDEADBEEF)
-    capi.icp_post_pose(buf.ctypes.data, None, None, 78, cmd=1)
-    assert buf[0] == 78 and buf[16] == 78 and buf[1] == 1 and not buf[2:16].any() and not buf[18:28].any()
+    words = [2 + i for i in range(6)] + [9 + i for i in range(7)] + [18 + i for i in range(6)] + [25 + i for i in range(5)]
+    raw = np.full(40 + 32, 0xDEADBEEF, np.uint32)                 # 32 words + guard, placed at a 64-byte aligned and at a 4-byte aligned address
+    base = (-raw.ctypes.data // 4) % 16
+    for off in (base, base + 1):
+        raw[:] = 0xDEADBEEF
+        buf = raw[off:off + 40]
+        assert (buf.ctypes.data % 64 == 0) == (off == base)
+        capi.icp_post_pose(buf.ctypes.data, R, t, 77, cmd=0)
+        assert all(buf[w] == 77 for w in (0, 8, 16, 24)) and buf[1] == 0 and buf[17] == 0 and buf[30] == 0 and buf[31] == 0
+        assert np.array_equal(buf[words], f)
+        assert np.all(buf[32:] == 0xDEADBEEF) and np.all(raw[:off] == 0xDEADBEEF)
+        capi.icp_post_pose(buf.ctypes.data, None, None, 78, cmd=1)
+        assert all(buf[w] == 78 for w in (0, 8, 16, 24)) and buf[1] == 1 and not buf[words].any()
 
 
 def test_host_fold_of_records_host_side():

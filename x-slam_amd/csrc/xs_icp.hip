@@ -242,10 +242,9 @@ __device__ __forceinline__ double wave_order_sum(const double (*smem)[NP], int k
 
 // Pose mailbox (xs_icp_post_pose writes it, k_icp<POSE_POSTED> polls it; xs_icp_mailbox_alloc puts it in
 // device memory the CPU reaches through the large BAR, so polling stays off the PCIe link — 512
-// workgroups polling pinned host memory cost 50 us per iteration): two 64-byte lines of 16
-// words, each line starting with the sequence number:   line 0 = {seq, cmd, f[0..13]}   line 1 = {seq, 0, f[14..23], pad}
-// with f = the 18 floats of Rcurr followed by the 6 of tcurr; cmd 0 = run, 1 = abandon the launch.  The poller takes
-// the payload from a second load issued after it has seen both sequence words (see there).
+// workgroups polling pinned host memory cost 50 us per iteration): four 32-byte sectors, each starting
+// with the sequence number, carrying cmd (0 = run, 1 = abandon the launch) and the 18 floats of Rcurr followed by the 6 of
+// tcurr — layout and reasons in xs_mailbox.h.  The load that finds the launch's number in all four sectors holds the payload.
 enum { POSE_ARGS = 0, POSE_DEVICE = 1, POSE_POSTED = 2 };
 constexpr unsigned long long kIcpTimeoutBit = 1ull << 63;
 
@@ -354,7 +353,7 @@ __global__ void __launch_bounds__(64 * WAVES)
                                    a.record_seq | kIcpTimeoutBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
-        auto word = [&](int i) { return uni(__uint_as_float(s_mail[i < 14 ? 2 + i : 18 + (i - 14)])); };
+        auto word = [&](int i) { return uni(__uint_as_float(s_mail[mailbox_word_of(i)])); };
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             Rcurr.data[r].x = cfloat(word(6 * r + 0), word(6 * r + 1));
@@ -1000,9 +999,9 @@ extern "C" int xs_icp_wait_pairs(const void *pairs_host, unsigned long long seq,
     }
     return 0;
 }
-/* Host side of the mailbox (xs_mailbox.h has the layout and the reasons).  With MOVDIR64B each of the two lines goes out as one 64-byte write,
- * sequence word and payload together; without it: the payload first, a store fence, the two sequence words, a store fence (the poller accepts a
- * line only with its sequence word and reads the payload again after it has seen both). */
+/* Host side of the mailbox (xs_mailbox.h has the layout and the reasons).  With MOVDIR64B each of the two 64-byte lines goes out as one write,
+ * sequence words and payload together; without it: the payload first, a store fence, the four sequence words, a store fence (the poller accepts
+ * a 32-byte sector only with its sequence word). */
 extern "C" void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const float *tcurr6, unsigned mailbox_seq, int cmd) {
     static const bool direct = mailbox_cpu_has_direct_store() && !exp_env_set("XS_MAILBOX_NO_DIRECT_STORE");
     alignas(64) unsigned img[MAILBOX_WORDS];
@@ -1013,13 +1012,7 @@ extern "C" void xs_icp_post_pose(void *mailbox_host, const float *Rcurr18, const
         mailbox_direct_store_64(static_cast<char *>(mailbox_host) + 64, img + 16);
         return;
     }
-    volatile unsigned *w = (volatile unsigned *)mailbox_host;
-    for (int i = 1; i < 16; ++i) w[i] = img[i];
-    for (int i = 17; i < MAILBOX_WORDS; ++i) w[i] = img[i];
-    mailbox_store_fence();
-    w[0] = mailbox_seq;
-    w[16] = mailbox_seq;
-    mailbox_store_fence();
+    mailbox_store_fenced((volatile unsigned *)mailbox_host, img);
 }
 /* A mailbox where polling is cheapest: fine-grained device memory the CPU writes through the large
  * BAR (512 workgroups then poll local memory, not the PCIe link), or — without a large BAR —

@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(64) k_pose_gate(const unsigned *mailbox, unsig
     mailbox_wait(mailbox, seq, s_mail, (int)threadIdx.x);
     __syncthreads();
     if (threadIdx.x == 0) pose_dev[0] = s_mail[1];
-    if (threadIdx.x < 24) pose_dev[1 + threadIdx.x] = s_mail[threadIdx.x < 14 ? 2 + threadIdx.x : 18 + (threadIdx.x - 14)];
+    if (threadIdx.x < 24) pose_dev[1 + threadIdx.x] = s_mail[mailbox_word_of((int)threadIdx.x)];
 }
 
 // POSTED: the launch is enqueued before its pose exists — behind the classification, which already runs behind the last ICP launch — and
@@ -2135,10 +2135,10 @@ __global__ void __launch_bounds__(256) XS_GN_OCC k_tsdf_gauss_newton(const HessA
             float *dst = reinterpret_cast<float *>(&P);
             for (int k = 0; k < 6 && cmd == 0; ++k) {   // (issued after box 5's sequence words were seen: complete payloads)
                 const unsigned w = __hip_atomic_load(a.mailbox + k * xs::MAILBOX_WORDS + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned s0 = __builtin_amdgcn_readlane(w, 0), s1 = __builtin_amdgcn_readlane(w, 16);
-                if (s0 != a.mailbox_seq || s1 != a.mailbox_seq) { cmd = 2; break; }
-                const int word = lane & 31;                     // line 0 = {seq, cmd, f[0..13]}, line 1 = {seq, 0, f[14..23], pad}
-                const int f = word >= 2 && word < 16 ? word - 2 : (word >= 18 && word < 28 ? word - 4 : -1);
+                const unsigned s0 = __builtin_amdgcn_readlane(w, 0), s1 = __builtin_amdgcn_readlane(w, 8), s2 = __builtin_amdgcn_readlane(w, 16),
+                               s3 = __builtin_amdgcn_readlane(w, 24);
+                if (s0 != a.mailbox_seq || s1 != a.mailbox_seq || s2 != a.mailbox_seq || s3 != a.mailbox_seq) { cmd = 2; break; }
+                const int f = xs::mailbox_float_of(lane & 31);   // (xs_mailbox.h: four sectors, each {seq, payload})
                 if (lane < 32 && f >= 0) dst[f < 18 ? 18 * k + f : 108 + 6 * k + (f - 18)] = __uint_as_float(w);
             }
             if (lane == 0) s_cmd = cmd;
@@ -2383,15 +2383,12 @@ extern "C" void xs_gn_post_poses(void *mailbox_host, const float *Rv2c108, const
         mailbox_direct_store_64(const_cast<unsigned *>(base) + 5 * (size_t)xs::MAILBOX_WORDS + 16, img[5] + 16);
         return;
     }
-    for (int k = 0; k < 6; ++k) {
-        volatile unsigned *w = base + (size_t)k * xs::MAILBOX_WORDS;
-        for (int i = 1; i < 16; ++i) w[i] = img[k][i];
-        for (int i = 17; i < xs::MAILBOX_WORDS; ++i) w[i] = img[k][i];
-    }
+    for (int k = 0; k < 6; ++k)
+        for (int i = 0; i < xs::MAILBOX_WORDS; ++i) if (i % 8 != 0) base[(size_t)k * xs::MAILBOX_WORDS + i] = img[k][i];
     mailbox_store_fence();
-    for (int k = 0; k < 5; ++k) { base[(size_t)k * xs::MAILBOX_WORDS] = mailbox_seq; base[(size_t)k * xs::MAILBOX_WORDS + 16] = mailbox_seq; }
+    for (int k = 0; k < 5; ++k) for (int i = 0; i < xs::MAILBOX_WORDS; i += 8) base[(size_t)k * xs::MAILBOX_WORDS + i] = mailbox_seq;
     mailbox_store_fence();
-    base[5 * (size_t)xs::MAILBOX_WORDS] = mailbox_seq; base[5 * (size_t)xs::MAILBOX_WORDS + 16] = mailbox_seq;
+    for (int i = 0; i < xs::MAILBOX_WORDS; i += 8) base[5 * (size_t)xs::MAILBOX_WORDS + i] = mailbox_seq;
     mailbox_store_fence();
 }
 __global__ void k_publish_sums(const double *sums, int n, double *publish, unsigned long long seq) {
