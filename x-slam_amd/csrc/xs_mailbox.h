@@ -38,7 +38,10 @@ __device__ __forceinline__ void mailbox_wait(const unsigned *mailbox, unsigned s
             break;
         }
         if (polls >= MAILBOX_MAX_POLLS) { cmd_override = 2; break; }
-        __builtin_amdgcn_s_sleep(8);
+#ifndef XS_MAILBOX_POLL_SLEEP
+#define XS_MAILBOX_POLL_SLEEP 8   // (x 64 clocks between two polls of a workgroup; 2 and 0 measured no faster: profiles/r06_ab_mailbox_poll_sleep.txt)
+#endif
+        if (XS_MAILBOX_POLL_SLEEP > 0) __builtin_amdgcn_s_sleep(XS_MAILBOX_POLL_SLEEP);
     }
     if (lane < MAILBOX_WORDS) s_mail[lane] = lane == 1 && cmd_override ? cmd_override : v;
 }
