@@ -10,7 +10,9 @@
 // to an LDS tile as floats and are added there in double — lanes in a fixed interleaved order, then the waves in order — as the
 // reference accumulates in double (ICP.cu:274); the workgroup writes one 448-byte record with write-through stores and takes a
 // ticket; the last workgroup to arrive adds the records in a fixed order, so the result is deterministic and there is no
-// second launch.  How each phase was measured: profiles/tools/trace_icp.sh, profiles/r02_icp_phases.txt.
+// second launch.  The 55 sums go to device memory, or straight into host-coherent pinned memory with a completion word behind them
+// (done_flag), or — the orchestrator's form since round 6 — as 55 stores of {launch number, sum} that need no word behind them
+// (XS_ICP_PUBLISH_PAIRS).  How each phase was measured: profiles/tools/trace_icp.sh, profiles/r02_icp_phases.txt.
 #include <string.h>
 #include "xs_device.h"
 #include "xs_env.h"
